@@ -1,0 +1,861 @@
+// Conv1d / ConvTranspose1d family for gfx950: channels-last activations, implicit GEMM on MFMA.
+//
+// Reference call sites replaced (file:line under /root/reference):
+//   HiFi-GAN Generator / ResBlock1      src/easevoice/module/models.py:452-471, modules.py:298-311
+//   WN (posterior encoder, flow)        src/easevoice/module/modules.py:187-212
+//   FFN convs                           src/easevoice/module/attentions.py:408-416
+//   DiscriminatorS / DiscriminatorP     src/easevoice/module/models.py:538-587
+//
+// One kernel template (conv_igemm) serves forward, backward-data and ConvTranspose: the launch
+// descriptor maps an output index q of a "unit" to input rows q*s_in + tap*dil + off_in and to the
+// output row q*s_out + off_out (+phase).  Strided backward-data / ConvTranspose forward run as
+// `stride` polyphase sub-convolutions (grid.y = phase).  GEMM view: M = output channels (MFMA rows),
+// N = positions (MFMA columns), K = (tap, input channel) with the channel index contiguous in HBM
+// and in LDS, so both MFMA operands are 16-byte ds_read_b128 fragments.
+//
+// Work decomposition: a wave owns one unit = 16*NT consecutive q of ONE sequence (never straddling a
+// sequence) and all 16*MT output channels of the block's channel tile; the 4 waves of a block own 4
+// consecutive units and share the weight tile staged in LDS.  blockIdx.x is decoded XCD-aware so the
+// channel tiles that re-read the same activation rows sit on the same XCD (same L2).
+#include "evt_common.h"
+#include "../../include/evt.h"
+
+namespace {
+
+struct ConvP {
+  const void* x;     // K-side operand, [nseq][Lin][Cin]
+  const void* xact;  // optional activation OUTPUT with x's shape: x_eff = x * dact(xact)
+  const void* w;     // prepared weights [phase][Cout][nchunk][KHp][CK]
+  const float* bias; // [Cout] or null
+  const void* res;   // [nseq][Lout][Cout] or null (added last)
+  const void* gate;  // [nseq][Lout][Cout] or null: result *= (gate > 0 ? 1 : gate_slope) before res
+  void* y;           // [nseq][Lout][Cout]
+  int nseq, Lin, Lout, Cin, Cout;
+  int KHp;           // taps in the prepared image (zero padded)
+  int s_in, dil, off_in;
+  int s_out, off_out, off_out_phase;
+  int Q, U;          // q per sequence, units per sequence
+  int nchunk;
+  long w_phase_stride;  // elements
+  float in_slope;
+  int xact_kind;
+  float xact_slope;
+  int out_act;
+  float out_slope;
+  float gate_slope;
+  int P, Y;          // position blocks, channel tiles
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+  static constexpr int EPL = 1, KS = 4;
+  typedef float type;
+  static __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<bf16_t> {
+  static constexpr int EPL = 8, KS = 32;
+  typedef bf16x8 type;
+  static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// 16 bytes of T, with the two load-side fusions applied in fp32 and re-rounded to T
+template <typename T>
+__device__ __forceinline__ uint4 fuse_load16(uint4 v, bool has_act, uint4 va, int act_kind, float act_slope,
+                                             float in_slope) {
+  if (!has_act && in_slope == 1.f) return v;
+  if constexpr (sizeof(T) == 4) {
+    float* f = reinterpret_cast<float*>(&v);
+    const float* a = reinterpret_cast<const float*>(&va);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = f[i];
+      if (has_act) t *= dact_from_out(act_kind, a[i], act_slope);
+      f[i] = lrelu_f(t, in_slope);
+    }
+  } else {
+    bf16_t* h = reinterpret_cast<bf16_t*>(&v);
+    const bf16_t* a = reinterpret_cast<const bf16_t*>(&va);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = bf2f(h[i]);
+      if (has_act) t *= dact_from_out(act_kind, bf2f(a[i]), act_slope);
+      h[i] = f2bf(lrelu_f(t, in_slope));
+    }
+  }
+  return v;
+}
+
+template <typename T, int CK, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
+  constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
+  constexpr int TM = 16 * MT, PW = 16 * NT;
+  constexpr int SZ = sizeof(T);
+  constexpr int XROW = CK * SZ + 16;             // bytes per staged x row (pad breaks pow2 pitch)
+  constexpr int WK = (SZ == 2 ? 256 : 128);      // K elements per weight stage
+  constexpr int TG = WK / CK;                    // taps per weight stage
+  constexpr int WROW = WK * SZ + 16;             // bytes per staged weight row
+  constexpr int LPR = CK * SZ / 16;              // 16-byte pieces per x row
+  typedef typename Frag<T>::type frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+
+  // XCD-aware decode: consecutive blockIdx.x round-robin over 8 XCDs; give every XCD whole
+  // position blocks (all Y channel tiles of a position block land on one XCD / one L2).
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int yi = slot % p.Y;
+  const int pb = xcd + 8 * (slot / p.Y);
+  if (pb >= p.P) return;
+  const int phase = blockIdx.y;
+
+  const int R = (PW - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;  // staged rows per unit
+  unsigned char* ws = smem;
+  unsigned char* xs = smem + TM * WROW + wave * (R * XROW);
+
+  const long u = (long)pb * 4 + wave;
+  const bool active = u < (long)p.nseq * p.U;
+  const int seq = active ? (int)(u / p.U) : 0;
+  const int q0 = active ? (int)(u % p.U) * PW : 0;
+  const int row0 = q0 * p.s_in + p.off_in;
+
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long)seq * p.Lin * p.Cin;
+  const T* ag = p.xact ? reinterpret_cast<const T*>(p.xact) + (long)seq * p.Lin * p.Cin : nullptr;
+  const T* wg = reinterpret_cast<const T*>(p.w) + (long)phase * p.w_phase_stride +
+                (long)yi * TM * p.nchunk * p.KHp * CK;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups = (p.KHp + TG - 1) / TG;
+  for (int ch = 0; ch < p.nchunk; ++ch) {
+    for (int tg = 0; tg < ngroups; ++tg) {
+      __syncthreads();  // previous stage's fragment reads are done
+      if (tg == 0 && active) {
+        // stage this unit's activation rows for channel chunk `ch` (wave-private region)
+        for (int idx = lane; idx < R * LPR; idx += 64) {
+          const int r = idx / LPR, part = idx - r * LPR;
+          const int in_row = row0 + r;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (in_row >= 0 && in_row < p.Lin) {
+            const long off = (long)in_row * p.Cin + ch * CK + part * (16 / SZ);
+            v = *reinterpret_cast<const uint4*>(xg + off);
+            uint4 va = make_uint4(0, 0, 0, 0);
+            if (ag) va = *reinterpret_cast<const uint4*>(ag + off);
+            v = fuse_load16<T>(v, ag != nullptr, va, p.xact_kind, p.xact_slope, p.in_slope);
+          }
+          *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
+        }
+      }
+      // stage weights for taps [t0, t0+ntap) of chunk ch: TM rows of ntap*CK contiguous elements
+      const int t0 = tg * TG;
+      const int ntap = min(TG, p.KHp - t0);
+      const int ppr = ntap * CK * SZ / 16;  // 16-byte pieces per row
+      for (int idx = tid; idx < TM * ppr; idx += 256) {
+        const int r = idx / ppr, piece = idx - r * ppr;
+        const T* src = wg + ((long)(r * p.nchunk + ch) * p.KHp + t0) * CK + piece * (16 / SZ);
+        *reinterpret_cast<uint4*>(ws + r * WROW + piece * 16) = *reinterpret_cast<const uint4*>(src);
+      }
+      __syncthreads();
+      if (active) {
+        const int steps = ntap * CK / KS;
+        for (int st = 0; st < steps; ++st) {
+          const int kl = st * KS + g * EPL;  // K index inside this weight stage: [tap][ci]
+          const int tl = kl / CK, ci = kl - tl * CK;
+          const int tap = t0 + tl;
+          frag_t a[MT], b[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            a[i] = *reinterpret_cast<const frag_t*>(ws + (i * 16 + n) * WROW + kl * SZ);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            b[j] = *reinterpret_cast<const frag_t*>(xs + ((j * 16 + n) * p.s_in + tap * p.dil) * XROW + ci * SZ);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+
+  // epilogue: lane holds rows (channels) g*4..g*4+3, column (position) n of each 16x16 tile
+  T* yg = reinterpret_cast<T*>(p.y) + (long)seq * p.Lout * p.Cout;
+  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long)seq * p.Lout * p.Cout : nullptr;
+  const T* gg = p.gate ? reinterpret_cast<const T*>(p.gate) + (long)seq * p.Lout * p.Cout : nullptr;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int q = q0 + j * 16 + n;
+    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
+    if (q >= p.Q || orow < 0 || orow >= p.Lout) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int co = yi * TM + i * 16 + g * 4;
+      const long off = (long)orow * p.Cout + co;
+      T outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co + r];
+        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
+        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
+        if (gg) v *= (to_f<T>(gg[off + r]) > 0.f ? 1.f : p.gate_slope);
+        if (rg) v += to_f<T>(rg[off + r]);
+        outv[r] = from_f<T>(v);
+      }
+      if constexpr (SZ == 4) *reinterpret_cast<float4*>(yg + off) = *reinterpret_cast<float4*>(outv);
+      else *reinterpret_cast<uint2*>(yg + off) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[a][chunk(b)][tap][cc] += sum_{seq,q} A[seq][q][a] * B[seq][q*s + tap*dil + off][b]
+// GEMM view: M = A channels, N = B channels (one CK chunk), K = positions.  A block owns 64 A-channels
+// (16 per wave), one B chunk and up to KT taps; positions are split over blockIdx.y and the partial
+// tiles are accumulated with fp32 global atomics.  Fragments are gathered element-wise from
+// position-major LDS tiles (k = position is the strided index of a channels-last tensor).
+// ---------------------------------------------------------------------------------------------
+struct WgP {
+  const void* A;      // [nseq][LA][CA]   q-indexed operand
+  const void* Aact;   // optional activation output (A_eff = A * dact(Aact))
+  const void* B;      // [nseq][LB][CB]   tap-shifted operand
+  const void* Bact;
+  float* dw;          // [CA][nchunk][KHp][CK] fp32
+  int nseq, LA, LB, CA, CB;
+  int KH, KHp, s, dil, off, Q;
+  int nchunk;
+  float a_slope, b_slope;     // lrelu-on-load slopes (1 = identity)
+  int aact_kind, bact_kind;
+  float aact_slope, bact_slope;
+  int nsplit;
+  int ntapgrp;
+};
+
+template <typename T> union FragBuf;
+template <> union FragBuf<float> { float v; float e[1]; };
+template <> union FragBuf<bf16_t> { bf16x8 v; bf16_t e[8]; };
+
+template <typename T>
+__device__ __forceinline__ T fuse_elem(T v, bool has_act, T va, int kind, float aslope, float slope) {
+  if (!has_act && slope == 1.f) return v;
+  float t = to_f<T>(v);
+  if (has_act) t *= dact_from_out(kind, to_f<T>(va), aslope);
+  return from_f<T>(lrelu_f(t, slope));
+}
+
+template <typename T, int CK>
+__global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
+  constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
+  constexpr int KT = 4;    // taps per block
+  constexpr int PK = 64;   // positions staged per iteration
+  constexpr int NTB = CK / 16;
+  constexpr int AP = 64 + 2;  // A tile pitch (elements): [PK][64 ch]
+  constexpr int BP = CK + 2;  // B tile pitch (elements)
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+
+  // blockIdx.x = ((atile * nchunk) + chunk) * ntapgrp + tapgrp
+  int bx = blockIdx.x;
+  const int tgi = bx % p.ntapgrp; bx /= p.ntapgrp;
+  const int ch = bx % p.nchunk;
+  const int atile = bx / p.nchunk;
+  const int t0 = tgi * KT;
+  const int ntap = min(KT, p.KHp - t0);
+  const int a0 = atile * 64;
+
+  const int BR = (PK - 1) * p.s + (KT - 1) * p.dil + 1;  // staged B rows
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + PK * AP;
+
+  f32x4 acc[KT][NTB];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int UQ = (p.Q + PK - 1) / PK;
+  const long total = (long)p.nseq * UQ;
+  const T* Ag0 = reinterpret_cast<const T*>(p.A);
+  const T* Aa0 = reinterpret_cast<const T*>(p.Aact);
+  const T* Bg0 = reinterpret_cast<const T*>(p.B);
+  const T* Ba0 = reinterpret_cast<const T*>(p.Bact);
+
+  for (long it = blockIdx.y; it < total; it += p.nsplit) {
+    const int seq = (int)(it / UQ);
+    const int q0 = (int)(it % UQ) * PK;
+    __syncthreads();
+    // stage A tile: PK positions x 64 channels
+    for (int idx = tid; idx < PK * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const int q = q0 + r;
+      T v = from_f<T>(0.f);
+      if (q < p.Q && a0 + c < p.CA) {
+        const long off = ((long)seq * p.LA + q) * p.CA + a0 + c;
+        v = Ag0[off];
+        T va = Aa0 ? Aa0[off] : v;
+        v = fuse_elem<T>(v, Aa0 != nullptr, va, p.aact_kind, p.aact_slope, p.a_slope);
+      }
+      As[r * AP + c] = v;
+    }
+    // stage B tile: rows q0*s + t0*dil + off + [0, BR)
+    const int brow0 = q0 * p.s + t0 * p.dil + p.off;
+    for (int idx = tid; idx < BR * CK; idx += 256) {
+      const int r = idx / CK, c = idx - r * CK;
+      const int row = brow0 + r;
+      T v = from_f<T>(0.f);
+      if (row >= 0 && row < p.LB) {
+        const long off = ((long)seq * p.LB + row) * p.CB + ch * CK + c;
+        v = Bg0[off];
+        T va = Ba0 ? Ba0[off] : v;
+        v = fuse_elem<T>(v, Ba0 != nullptr, va, p.bact_kind, p.bact_slope, p.b_slope);
+      }
+      Bs[r * BP + c] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kk = 0; kk < PK / KS; ++kk) {
+      const int k0 = kk * KS + g * EPL;  // first of this lane's EPL positions
+      FragBuf<T> av;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) av.e[e] = As[(k0 + e) * AP + wave * 16 + n];
+      const frag_t a = av.v;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        if (t < ntap) {
+#pragma unroll
+          for (int j = 0; j < NTB; ++j) {
+            FragBuf<T> bv;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) bv.e[e] = Bs[((k0 + e) * p.s + t * p.dil) * BP + j * 16 + n];
+            acc[t][j] = Frag<T>::mma(a, bv.v, acc[t][j]);
+          }
+        }
+      }
+    }
+  }
+  // accumulate: lane holds A-channel rows g*4+r (of this wave's 16), B-channel column n
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (t >= ntap) continue;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wave * 16 + g * 4 + r;
+        if (a < p.CA) {
+          const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * CK + j * 16 + n;
+          atomicAdd(p.dw + off, acc[t][j][r]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-form kernels: any channel count, groups, any taps.  They read the REG weight image only.
+// Used for the degenerate shapes (Cin == 1, Cout == 1, grouped DiscriminatorS layers) and as the
+// independent second implementation the parity tests compare the MFMA path against.
+// ---------------------------------------------------------------------------------------------
+struct NvP {
+  const void* x; const void* w; const float* bias; const void* res; const void* y_in; const void* gate;
+  void* y; float* dw; float* dbias;
+  int nseq, lin, lout, cin, cout, k, stride, pad, dil, groups, transposed;
+  int ck, nchunk, kp;    // REG geometry of the weight image [d0][nchunk][kp][ck]
+  float in_slope; int out_act; float out_slope;
+  int nsplit;
+};
+
+__device__ __forceinline__ long reg_index(const NvP& p, int d0, int d1, int t) {
+  const int chunk = d1 / p.ck, cc = d1 - chunk * p.ck;
+  return (((long)d0 * p.nchunk + chunk) * p.kp + t) * p.ck + cc;
+}
+
+// forward: one thread per output element (seq, row, co)
+template <typename T>
+__global__ void conv_naive_fwd(NvP p) {
+  const long total = (long)p.nseq * p.lout * p.cout;
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* w = reinterpret_cast<const T*>(p.w);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % p.cout);
+    const long sr = i / p.cout;
+    const int row = (int)(sr % p.lout);
+    const int seq = (int)(sr / p.lout);
+    float acc = 0.f;
+    if (!p.transposed) {
+      const int cpg = p.cin / p.groups, opg = p.cout / p.groups;
+      const int grp = co / opg;
+      for (int t = 0; t < p.k; ++t) {
+        const int ir = row * p.stride + t * p.dil - p.pad;
+        if (ir < 0 || ir >= p.lin) continue;
+        const T* xr = x + ((long)seq * p.lin + ir) * p.cin + grp * cpg;
+        for (int c = 0; c < cpg; ++c)
+          acc += lrelu_f(to_f<T>(xr[c]), p.in_slope) * to_f<T>(w[reg_index(p, co, c, t)]);
+      }
+    } else {
+      // out[n][co] = sum_{t,ci} x[(n + pad - t)/s][ci] * W[ci][co][t]
+      for (int t = 0; t < p.k; ++t) {
+        const int num = row + p.pad - t * p.dil;
+        if (num < 0 || num % p.stride) continue;
+        const int ir = num / p.stride;
+        if (ir >= p.lin) continue;
+        const T* xr = x + ((long)seq * p.lin + ir) * p.cin;
+        for (int c = 0; c < p.cin; ++c)
+          acc += lrelu_f(to_f<T>(xr[c]), p.in_slope) * to_f<T>(w[reg_index(p, c, co, t)]);
+      }
+    }
+    if (p.bias) acc += p.bias[co];
+    if (p.out_act == EVT_ACT_LRELU) acc = lrelu_f(acc, p.out_slope);
+    else if (p.out_act == EVT_ACT_TANH) acc = tanhf(acc);
+    if (p.res) acc += to_f<T>(reinterpret_cast<const T*>(p.res)[i]);
+    reinterpret_cast<T*>(p.y)[i] = from_f<T>(acc);
+  }
+}
+
+// backward-data: one thread per dx element (seq, row, ci); here p.x = dy, p.y_in = saved y, p.gate = saved x,
+// p.res = dx_add, p.y = dx.
+template <typename T>
+__global__ void conv_naive_bwd_data(NvP p) {
+  const long total = (long)p.nseq * p.lin * p.cin;
+  const T* dy = reinterpret_cast<const T*>(p.x);
+  const T* ys = reinterpret_cast<const T*>(p.y_in);
+  const T* w = reinterpret_cast<const T*>(p.w);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % p.cin);
+    const long sr = i / p.cin;
+    const int row = (int)(sr % p.lin);
+    const int seq = (int)(sr / p.lin);
+    float acc = 0.f;
+    if (!p.transposed) {
+      const int cpg = p.cin / p.groups, opg = p.cout / p.groups;
+      const int grp = ci / cpg, cl = ci - grp * cpg;
+      for (int t = 0; t < p.k; ++t) {
+        const int num = row + p.pad - t * p.dil;
+        if (num < 0 || num % p.stride) continue;
+        const int q = num / p.stride;
+        if (q >= p.lout) continue;
+        const long base = ((long)seq * p.lout + q) * p.cout + grp * opg;
+        for (int o = 0; o < opg; ++o) {
+          float d = to_f<T>(dy[base + o]);
+          if (ys) d *= dact_from_out(p.out_act, to_f<T>(ys[base + o]), p.out_slope);
+          acc += d * to_f<T>(w[reg_index(p, grp * opg + o, cl, t)]);
+        }
+      }
+    } else {
+      // dx[i][ci] = sum_{t,co} dy[i*s + t - pad][co] * W[ci][co][t]
+      for (int t = 0; t < p.k; ++t) {
+        const int orow = row * p.stride + t * p.dil - p.pad;
+        if (orow < 0 || orow >= p.lout) continue;
+        const long base = ((long)seq * p.lout + orow) * p.cout;
+        for (int o = 0; o < p.cout; ++o) {
+          float d = to_f<T>(dy[base + o]);
+          if (ys) d *= dact_from_out(p.out_act, to_f<T>(ys[base + o]), p.out_slope);
+          acc += d * to_f<T>(w[reg_index(p, ci, o, t)]);
+        }
+      }
+    }
+    if (p.gate) acc *= (to_f<T>(reinterpret_cast<const T*>(p.gate)[i]) > 0.f ? 1.f : p.in_slope);
+    if (p.res) acc += to_f<T>(reinterpret_cast<const T*>(p.res)[i]);
+    reinterpret_cast<T*>(p.y)[i] = from_f<T>(acc);
+  }
+}
+
+// backward-weight: one block per REG weight element (d0, d1, t), positions strided over threads and
+// blockIdx.y splits; p.x = saved x, p.res = dy, p.y_in = saved y.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_naive_bwd_weight(NvP p) {
+  __shared__ float red[4];
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* dy = reinterpret_cast<const T*>(p.res);
+  const T* ys = reinterpret_cast<const T*>(p.y_in);
+  int e = blockIdx.x;
+  const int t = e % p.k; e /= p.k;
+  const int d1n = p.transposed ? p.cout : p.cin / p.groups;
+  const int d1 = e % d1n;
+  const int d0 = e / d1n;
+  int co, ci;
+  if (!p.transposed) {
+    const int cpg = p.cin / p.groups, opg = p.cout / p.groups;
+    co = d0; ci = (co / opg) * cpg + d1;
+  } else { ci = d0; co = d1; }
+  // positions enumerated on the side that is NOT strided: conv -> output rows q, convT -> input rows i
+  const int nq = p.transposed ? p.lin : p.lout;
+  const long total = (long)p.nseq * nq;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)p.nsplit * 256) {
+    const int q = (int)(i % nq);
+    const int seq = (int)(i / nq);
+    const int other = q * p.stride + t * p.dil - p.pad;
+    int xr, yr;
+    if (!p.transposed) { xr = other; yr = q; if (xr < 0 || xr >= p.lin) continue; }
+    else { xr = q; yr = other; if (yr < 0 || yr >= p.lout) continue; }
+    const long yo = ((long)seq * p.lout + yr) * p.cout + co;
+    float d = to_f<T>(dy[yo]);
+    if (ys) d *= dact_from_out(p.out_act, to_f<T>(ys[yo]), p.out_slope);
+    acc += d * lrelu_f(to_f<T>(x[((long)seq * p.lin + xr) * p.cin + ci]), p.in_slope);
+  }
+  acc = block_reduce_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(p.dw + reg_index(p, d0, d1, t), acc);
+}
+
+// dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_act(const T* dy, const T* ys, float* out, long rows, int C, int kind,
+                                                  float slope, int rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      float d = to_f<T>(dy[r * C + c]);
+      if (ys) d *= dact_from_out(kind, to_f<T>(ys[r * C + c]), slope);
+      acc += d;
+    }
+    atomicAdd(out + c, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+inline void pick_ck(int dtype, int b, int k, int stride_unused, int* ck, int* nchunk, int* kp) {
+  (void)stride_unused;
+  if (b % 32 == 0) { *ck = 32; *nchunk = b / 32; *kp = k; }
+  else if (b % 16 == 0) { *ck = 16; *nchunk = b / 16; *kp = (dtype == EVT_DT_BF16) ? ((k + 1) & ~1) : k; }
+  else { *ck = b; *nchunk = 1; *kp = k; }
+}
+
+template <typename T, int CK, int MT, int NT>
+int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
+  constexpr int SZ = sizeof(T);
+  constexpr int XROW = CK * SZ + 16;
+  constexpr int WK = (SZ == 2 ? 256 : 128);
+  constexpr int WROW = WK * SZ + 16;
+  const int R = (16 * NT - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
+  const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * R * XROW;
+  if (lds > 160 * 1024) return EVT_ENOTSUP;
+  static size_t max_set = 0;
+  if (lds > 48 * 1024 && lds > max_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return EVT_ELAUNCH;
+    max_set = 160 * 1024;
+  }
+  const int gx = 8 * ceil_div(p.P, 8) * p.Y;
+  hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT>), dim3(gx, nphase), dim3(256), lds, st, p);
+  return evt_check_launch();
+}
+
+template <typename T, int CK, int MT>
+int launch_igemm_nt(const ConvP& p, int NT, int nphase, hipStream_t st) {
+  switch (NT) {
+    case 1: return launch_igemm_inst<T, CK, MT, 1>(p, nphase, st);
+    case 2: return launch_igemm_inst<T, CK, MT, 2>(p, nphase, st);
+    default: return launch_igemm_inst<T, CK, MT, 4>(p, nphase, st);
+  }
+}
+
+template <typename T, int CK>
+int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, hipStream_t st) {
+  switch (MT) {
+    case 1: return launch_igemm_nt<T, CK, 1>(p, NT, nphase, st);
+    case 2: return launch_igemm_nt<T, CK, 2>(p, NT, nphase, st);
+    default: return launch_igemm_nt<T, CK, 4>(p, NT, nphase, st);
+  }
+}
+
+// Generic igemm launch.  A = output channels, B = K-side channels.
+int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st) {
+  if (A % 16 || B % 16) return EVT_ENOTSUP;
+  const int CK = (B % 32 == 0) ? 32 : 16;
+  const int MT = (A % 64 == 0) ? 4 : (A % 32 == 0 ? 2 : 1);
+  p.Y = A / (16 * MT);
+  // positions per wave: largest NT that still gives the chip >= ~2 blocks per CU, without
+  // padding short sequences by more than a tile
+  int NT = 4;
+  while (NT > 1) {
+    const long units = (long)p.nseq * ceil_div(p.Q, 16 * NT);
+    const long blocks = ((units + 3) / 4) * p.Y * nphase;
+    const int waste = ceil_div(p.Q, 16 * NT) * 16 * NT - p.Q;
+    if (blocks >= 512 && waste * 4 <= p.Q) break;
+    NT >>= 1;
+  }
+  for (;; NT >>= 1) {
+    p.U = ceil_div(p.Q, 16 * NT);
+    const long units = (long)p.nseq * p.U;
+    p.P = (int)((units + 3) / 4);
+    int rc;
+    if (dtype == EVT_DT_BF16)
+      rc = (CK == 32) ? launch_igemm_mt<bf16_t, 32>(p, MT, NT, nphase, st) : launch_igemm_mt<bf16_t, 16>(p, MT, NT, nphase, st);
+    else
+      rc = (CK == 32) ? launch_igemm_mt<float, 32>(p, MT, NT, nphase, st) : launch_igemm_mt<float, 16>(p, MT, NT, nphase, st);
+    if (rc != EVT_ENOTSUP || NT == 1) return rc;  // ENOTSUP here = LDS too large: shrink the unit
+  }
+}
+
+template <typename T, int CK>
+int launch_wgrad_inst(const WgP& p, hipStream_t st) {
+  const int BR = 63 * p.s + 3 * p.dil + 1;
+  const size_t lds = (size_t)(64 * 66 + (size_t)BR * (CK + 2)) * sizeof(T);
+  if (lds > 160 * 1024) return EVT_ENOTSUP;
+  static bool attr = false;
+  if (lds > 48 * 1024 && !attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad<T, CK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  const int gx = ceil_div(p.CA, 64) * p.nchunk * p.ntapgrp;
+  hipLaunchKernelGGL((conv_wgrad<T, CK>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
+  return evt_check_launch();
+}
+
+int launch_wgrad(int dtype, WgP p, hipStream_t st) {
+  if (p.CB % 16) return EVT_ENOTSUP;
+  const int CK = (p.CB % 32 == 0) ? 32 : 16;
+  p.nchunk = p.CB / CK;
+  p.ntapgrp = ceil_div(p.KHp, 4);
+  const long iters = (long)p.nseq * ceil_div(p.Q, 64);
+  const long tiles = (long)ceil_div(p.CA, 64) * p.nchunk * p.ntapgrp;
+  long split = (2048 + tiles - 1) / tiles;  // aim for >= ~2048 blocks
+  if (split > iters) split = iters;
+  if (split < 1) split = 1;
+  if (split > 65535) split = 65535;
+  p.nsplit = (int)split;
+  if (dtype == EVT_DT_BF16) return CK == 32 ? launch_wgrad_inst<bf16_t, 32>(p, st) : launch_wgrad_inst<bf16_t, 16>(p, st);
+  return CK == 32 ? launch_wgrad_inst<float, 32>(p, st) : launch_wgrad_inst<float, 16>(p, st);
+}
+
+NvP make_nvp(const evt_conv1d_params* c) {
+  NvP p{};
+  p.nseq = c->nseq; p.lin = c->lin; p.lout = evt_conv1d_lout(c); p.cin = c->cin; p.cout = c->cout;
+  p.k = c->k; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.groups = c->groups;
+  p.transposed = c->transposed; p.in_slope = c->in_slope; p.out_act = c->out_act; p.out_slope = c->out_slope;
+  evt_wlayout l; evt_conv1d_layout(c, &l);
+  p.ck = l.reg_ck; p.nchunk = l.reg_nchunk; p.kp = l.reg_kp;
+  p.nsplit = 1;
+  return p;
+}
+
+bool igemm_ok(const evt_conv1d_params* c) {
+  if (c->groups != 1) return false;
+  if (c->cin % 16 || c->cout % 16) return false;
+  if (c->stride > 1 && c->dil != 1) return false;
+  return true;
+}
+
+int valid(const evt_conv1d_params* c) {
+  if (!c || c->nseq <= 0 || c->lin <= 0 || c->cin <= 0 || c->cout <= 0 || c->k <= 0 || c->stride <= 0 ||
+      c->dil <= 0 || c->groups <= 0 || c->pad < 0)
+    return EVT_EINVAL;
+  if (c->dtype != EVT_DT_F32 && c->dtype != EVT_DT_BF16) return EVT_EINVAL;
+  if (c->cin % c->groups || c->cout % c->groups) return EVT_EINVAL;
+  if (c->transposed && (c->groups != 1 || c->dil != 1)) return EVT_ENOTSUP;
+  if (evt_conv1d_lout(c) <= 0) return EVT_EINVAL;
+  return EVT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t evt_conv1d_lout(const evt_conv1d_params* c) {
+  if (!c->transposed) return (c->lin + 2 * c->pad - c->dil * (c->k - 1) - 1) / c->stride + 1;
+  return (c->lin - 1) * c->stride - 2 * c->pad + c->dil * (c->k - 1) + 1;
+}
+
+int evt_conv1d_layout(const evt_conv1d_params* c, evt_wlayout* o) {
+  if (!c || !o) return EVT_EINVAL;
+  const int d0 = c->transposed ? c->cin : c->cout;
+  const int d1 = c->transposed ? c->cout : c->cin / c->groups;
+  o->d0 = d0; o->d1 = d1; o->k = c->k; o->stride = c->stride;
+  pick_ck(c->dtype, d1, c->k, 1, &o->reg_ck, &o->reg_nchunk, &o->reg_kp);
+  o->reg_elems = (int64_t)d0 * o->reg_nchunk * o->reg_kp * o->reg_ck;
+  if (c->stride == 1) {
+    pick_ck(c->dtype, d0, c->k, 1, &o->alt_ck, &o->alt_nchunk, &o->alt_kp);
+    o->alt_nphase = 1;
+  } else {
+    const int J = (c->k + c->stride - 1) / c->stride;
+    pick_ck(c->dtype, d0, J, 1, &o->alt_ck, &o->alt_nchunk, &o->alt_kp);
+    o->alt_nphase = c->stride;
+  }
+  o->alt_elems = (int64_t)o->alt_nphase * d1 * o->alt_nchunk * o->alt_kp * o->alt_ck;
+  return EVT_OK;
+}
+
+int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const void* w_alt,
+                   const float* bias, const void* res, void* y, void* stream) {
+  int rc = valid(c);
+  if (rc) return rc;
+  if (!x || !y) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_igemm = c->impl != EVT_IMPL_NAIVE && igemm_ok(c);
+  if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
+  const int lout = evt_conv1d_lout(c);
+  evt_wlayout l; evt_conv1d_layout(c, &l);
+  if (!use_igemm) {
+    if (!w_reg) return EVT_EINVAL;
+    NvP p = make_nvp(c);
+    p.x = x; p.w = w_reg; p.bias = bias; p.res = res; p.y = y;
+    const long total = (long)c->nseq * lout * c->cout;
+    const int blocks = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
+    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(conv_naive_fwd<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_naive_fwd<float>, dim3(blocks), dim3(256), 0, st, p);
+    return evt_check_launch();
+  }
+  const void* w = c->transposed ? w_alt : w_reg;
+  if (!w) return EVT_EINVAL;
+  ConvP p{};
+  p.x = x; p.xact = nullptr; p.w = w; p.bias = bias; p.res = res; p.gate = nullptr; p.y = y;
+  p.nseq = c->nseq; p.Lin = c->lin; p.Lout = lout; p.Cin = c->cin; p.Cout = c->cout;
+  p.in_slope = c->in_slope; p.xact_kind = 0; p.xact_slope = 1.f; p.out_act = c->out_act; p.out_slope = c->out_slope;
+  p.gate_slope = 1.f;
+  int nphase = 1;
+  if (!c->transposed) {
+    p.KHp = l.reg_kp; p.nchunk = l.reg_nchunk;
+    p.s_in = c->stride; p.dil = c->dil; p.off_in = -c->pad;
+    p.s_out = 1; p.off_out = 0; p.off_out_phase = 0; p.Q = lout; p.w_phase_stride = 0;
+  } else {
+    p.KHp = l.alt_kp; p.nchunk = l.alt_nchunk; p.dil = 1; p.s_in = 1;
+    if (c->stride == 1) {
+      p.off_in = c->pad - (c->k - 1); p.s_out = 1; p.off_out = 0; p.off_out_phase = 0; p.Q = lout;
+      p.w_phase_stride = 0;
+    } else {
+      const int J = (c->k + c->stride - 1) / c->stride;
+      nphase = c->stride;
+      p.off_in = -(J - 1); p.s_out = c->stride; p.off_out = -c->pad; p.off_out_phase = 1;
+      p.Q = (lout - 1 + c->pad) / c->stride + 1;
+      p.w_phase_stride = (long)c->cout * l.alt_nchunk * l.alt_kp * l.alt_ck;
+    }
+  }
+  return launch_igemm(c->dtype, p, c->cout, c->cin, nphase, st);
+}
+
+int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
+                        const void* w_alt, const void* x, const void* dx_add, void* dx, void* stream) {
+  int rc = valid(c);
+  if (rc) return rc;
+  if (!dy || !dx) return EVT_EINVAL;
+  if (c->out_act != EVT_ACT_NONE && !y) return EVT_EINVAL;
+  if (c->in_slope != 1.f && !x) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_igemm = c->impl != EVT_IMPL_NAIVE && igemm_ok(c);
+  if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
+  const int lout = evt_conv1d_lout(c);
+  evt_wlayout l; evt_conv1d_layout(c, &l);
+  const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
+  const void* gate = c->in_slope != 1.f ? x : nullptr;
+  if (!use_igemm) {
+    if (!w_reg) return EVT_EINVAL;
+    NvP p = make_nvp(c);
+    p.x = dy; p.y_in = ysv; p.w = w_reg; p.gate = gate; p.res = dx_add; p.y = dx;
+    const long total = (long)c->nseq * c->lin * c->cin;
+    const int blocks = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
+    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(conv_naive_bwd_data<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_naive_bwd_data<float>, dim3(blocks), dim3(256), 0, st, p);
+    return evt_check_launch();
+  }
+  const void* w = c->transposed ? w_reg : w_alt;
+  if (!w) return EVT_EINVAL;
+  ConvP p{};
+  p.x = dy; p.xact = ysv; p.w = w; p.bias = nullptr; p.res = dx_add; p.gate = gate; p.y = dx;
+  p.nseq = c->nseq; p.Lin = lout; p.Lout = c->lin; p.Cin = c->cout; p.Cout = c->cin;
+  p.in_slope = 1.f; p.xact_kind = c->out_act; p.xact_slope = c->out_slope; p.out_act = EVT_ACT_NONE;
+  p.out_slope = 1.f; p.gate_slope = c->in_slope;
+  int nphase = 1;
+  if (!c->transposed) {
+    p.KHp = l.alt_kp; p.nchunk = l.alt_nchunk;
+    if (c->stride == 1) {
+      p.s_in = 1; p.dil = c->dil; p.off_in = c->pad - (c->k - 1) * c->dil;
+      p.s_out = 1; p.off_out = 0; p.off_out_phase = 0; p.Q = c->lin; p.w_phase_stride = 0;
+    } else {
+      const int J = (c->k + c->stride - 1) / c->stride;
+      nphase = c->stride;
+      p.s_in = 1; p.dil = 1; p.off_in = -(J - 1);
+      p.s_out = c->stride; p.off_out = -c->pad; p.off_out_phase = 1;
+      p.Q = (c->lin - 1 + c->pad) / c->stride + 1;
+      p.w_phase_stride = (long)c->cin * l.alt_nchunk * l.alt_kp * l.alt_ck;
+    }
+  } else {
+    // dx[i][ci] = sum_t sum_co dy[i*s + t - pad][co] W[ci][co][t]  (REG image, rows = ci)
+    p.KHp = l.reg_kp; p.nchunk = l.reg_nchunk;
+    p.s_in = c->stride; p.dil = 1; p.off_in = -c->pad;
+    p.s_out = 1; p.off_out = 0; p.off_out_phase = 0; p.Q = c->lin; p.w_phase_stride = 0;
+  }
+  return launch_igemm(c->dtype, p, c->cin, c->cout, nphase, st);
+}
+
+int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
+                          float* dbias, void* stream) {
+  int rc = valid(c);
+  if (rc) return rc;
+  if (!x || !dy || !dw) return EVT_EINVAL;
+  if (c->out_act != EVT_ACT_NONE && !y) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int lout = evt_conv1d_lout(c);
+  const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
+  evt_wlayout l; evt_conv1d_layout(c, &l);
+  if (dbias) {
+    const long rows = (long)c->nseq * lout;
+    const int rpb = 64;
+    const int blocks = (int)((rows + rpb - 1) / rpb);
+    if (c->dtype == EVT_DT_BF16)
+      hipLaunchKernelGGL(colsum_act<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
+                         dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
+    else
+      hipLaunchKernelGGL(colsum_act<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv, dbias,
+                         rows, c->cout, c->out_act, c->out_slope, rpb);
+    rc = evt_check_launch();
+    if (rc) return rc;
+  }
+  const bool use_igemm = c->impl != EVT_IMPL_NAIVE && igemm_ok(c) && l.reg_kp <= 64;
+  if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
+  if (!use_igemm) {
+    NvP p = make_nvp(c);
+    p.x = x; p.res = dy; p.y_in = ysv; p.dw = dw;
+    const int d1n = c->transposed ? c->cout : c->cin / c->groups;
+    const int d0n = c->transposed ? c->cin : c->cout;
+    const long elems = (long)d0n * d1n * c->k;
+    const long pos = (long)c->nseq * (c->transposed ? c->lin : lout);
+    long split = (4096 + elems - 1) / elems;
+    const long maxsplit = (pos + 2047) / 2048;
+    if (split > maxsplit) split = maxsplit;
+    if (split < 1) split = 1;
+    p.nsplit = (int)split;
+    if (c->dtype == EVT_DT_BF16)
+      hipLaunchKernelGGL(conv_naive_bwd_weight<bf16_t>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(conv_naive_bwd_weight<float>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
+    return evt_check_launch();
+  }
+  WgP p{};
+  p.dw = dw; p.nseq = c->nseq; p.KH = c->k; p.KHp = l.reg_kp; p.s = c->stride; p.dil = c->dil; p.off = -c->pad;
+  if (!c->transposed) {
+    // dW[co][.][t][ci] += dy_eff[q][co] * lrelu(x)[q*s + t*dil - pad][ci]
+    p.A = dy; p.Aact = ysv; p.aact_kind = c->out_act; p.aact_slope = c->out_slope; p.a_slope = 1.f;
+    p.B = x; p.Bact = nullptr; p.bact_kind = 0; p.bact_slope = 1.f; p.b_slope = c->in_slope;
+    p.LA = lout; p.CA = c->cout; p.LB = c->lin; p.CB = c->cin; p.Q = lout;
+  } else {
+    // dW[ci][.][t][co] += lrelu(x)[i][ci] * dy_eff[i*s + t - pad][co]
+    p.A = x; p.Aact = nullptr; p.aact_kind = 0; p.aact_slope = 1.f; p.a_slope = c->in_slope;
+    p.B = dy; p.Bact = ysv; p.bact_kind = c->out_act; p.bact_slope = c->out_slope; p.b_slope = 1.f;
+    p.LA = c->lin; p.CA = c->cin; p.LB = lout; p.CB = c->cout; p.Q = c->lin;
+  }
+  return launch_wgrad(c->dtype, p, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,319 @@
+// Multi-tensor weight preparation (weight-norm fold + GEMM-ready layouts), fused losses, AdamW over a
+// flat arena and small element-wise fusions of the s2 path.  gfx950 only.
+//
+// Reference call sites (file:line under /root/reference):
+//   weight_norm            src/easevoice/module/modules.py:162,174,184,228-296; models.py:427-436,486-536,563-574
+//   stage mean             src/easevoice/module/models.py:457-466
+//   gated activation       src/easevoice/module/commons.py:94-101
+//   feature/LSGAN losses   src/easevoice/module/losses.py:7-43
+//   AdamW, grad norm       src/train/sovits.py:294-319,505,522; src/easevoice/module/commons.py:140-155
+#include "evt_common.h"
+#include "../../include/evt.h"
+
+namespace {
+
+__device__ __forceinline__ void store_w(void* base, long idx, float w, int dtype) {
+  if (dtype == EVT_DT_BF16) reinterpret_cast<bf16_t*>(base)[idx] = f2bf(w);
+  else reinterpret_cast<float*>(base)[idx] = w;
+}
+
+__device__ __forceinline__ long reg_idx(const evt_wlayout& L, int d0, int d1, int kk) {
+  const int chunk = d1 / L.reg_ck, cc = d1 - chunk * L.reg_ck;
+  return (((long)d0 * L.reg_nchunk + chunk) * L.reg_kp + kk) * L.reg_ck + cc;
+}
+
+__device__ __forceinline__ long alt_idx(const evt_wlayout& L, int d0, int d1, int kk) {
+  const int chunk = d0 / L.alt_ck, cc = d0 - chunk * L.alt_ck;
+  if (L.stride == 1) {
+    const int t = L.k - 1 - kk;
+    return (((long)d1 * L.alt_nchunk + chunk) * L.alt_kp + t) * L.alt_ck + cc;
+  }
+  const int J = (L.k + L.stride - 1) / L.stride;
+  const int ph = kk % L.stride, j = kk / L.stride;
+  const int jp = J - 1 - j;
+  return ((((long)ph * L.d1 + d1) * L.alt_nchunk + chunk) * L.alt_kp + jp) * L.alt_ck + cc;
+}
+
+__global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* items, const int32_t* rows) {
+  __shared__ float red[4];
+  const evt_wprep_item it = items[rows[2 * blockIdx.x]];
+  const int d0 = rows[2 * blockIdx.x + 1];
+  const evt_wlayout& L = it.lay;
+  const int n = L.d1 * L.k;
+  const float* v = it.v + (long)d0 * n;
+  float scale = 1.f;
+  if (it.g) {
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) ss += v[e] * v[e];
+    ss = block_reduce_sum_256(ss, red);
+    scale = it.g[d0] / sqrtf(ss);
+  }
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int d1 = e / L.k, kk = e - d1 * L.k;
+    const float w = v[e] * scale;
+    if (it.reg) store_w(it.reg, reg_idx(L, d0, d1, kk), w, it.dtype);
+    if (it.alt) store_w(it.alt, alt_idx(L, d0, d1, kk), w, it.dtype);
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_grad_kernel(const evt_wprep_item* items, const int32_t* rows) {
+  __shared__ float red[4];
+  const evt_wprep_item it = items[rows[2 * blockIdx.x]];
+  const int d0 = rows[2 * blockIdx.x + 1];
+  const evt_wlayout& L = it.lay;
+  const int n = L.d1 * L.k;
+  const float* v = it.v + (long)d0 * n;
+  float* dv = it.dv + (long)d0 * n;
+  if (!it.g) {
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int d1 = e / L.k, kk = e - d1 * L.k;
+      dv[e] += it.dw[reg_idx(L, d0, d1, kk)];
+    }
+    return;
+  }
+  float ss = 0.f, dot = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int d1 = e / L.k, kk = e - d1 * L.k;
+    const float x = v[e];
+    ss += x * x;
+    dot += x * it.dw[reg_idx(L, d0, d1, kk)];
+  }
+  ss = block_reduce_sum_256(ss, red);
+  dot = block_reduce_sum_256(dot, red);
+  const float norm = sqrtf(ss);
+  const float gval = it.g[d0];
+  // w = g * v / |v|  =>  dg = <dw, v>/|v| ;  dv = g/|v| * (dw - v <dw, v>/|v|^2)
+  if (threadIdx.x == 0) it.dg[d0] += dot / norm;
+  const float s1 = gval / norm, s2 = dot / ss;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int d1 = e / L.k, kk = e - d1 * L.k;
+    dv[e] += s1 * (it.dw[reg_idx(L, d0, d1, kk)] - v[e] * s2);
+  }
+}
+
+template <typename T>
+__global__ void add3_scale_kernel(const T* a, const T* b, const T* c, float scale, T* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = to_f<T>(a[i]);
+    if (b) v += to_f<T>(b[i]);
+    if (c) v += to_f<T>(c[i]);
+    out[i] = from_f<T>(v * scale);
+  }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ void gated_fwd_kernel(const T* xin, const T* g, T* acts, int nseq, int len, int H) {
+  const long total = (long)nseq * len * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const long nt = i / H;
+    const int s = (int)(nt / len);
+    float a = to_f<T>(xin[nt * 2 * H + h]), b = to_f<T>(xin[nt * 2 * H + H + h]);
+    if (g) { a += to_f<T>(g[(long)s * 2 * H + h]); b += to_f<T>(g[(long)s * 2 * H + H + h]); }
+    acts[i] = from_f<T>(tanhf(a) * sigmoid_f(b));
+  }
+}
+
+template <typename T>
+__global__ void gated_bwd_kernel(const T* xin, const T* g, const T* dacts, T* dxin, float* dg, int nseq, int len,
+                                 int H) {
+  const long total = (long)nseq * len * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const long nt = i / H;
+    const int s = (int)(nt / len);
+    float a = to_f<T>(xin[nt * 2 * H + h]), b = to_f<T>(xin[nt * 2 * H + H + h]);
+    if (g) { a += to_f<T>(g[(long)s * 2 * H + h]); b += to_f<T>(g[(long)s * 2 * H + H + h]); }
+    const float t = tanhf(a), sg = sigmoid_f(b), d = to_f<T>(dacts[i]);
+    const float da = d * sg * (1.f - t * t), db = d * t * sg * (1.f - sg);
+    dxin[nt * 2 * H + h] = from_f<T>(da);
+    dxin[nt * 2 * H + H + h] = from_f<T>(db);
+    if (dg) { atomicAdd(dg + (long)s * 2 * H + h, da); atomicAdd(dg + (long)s * 2 * H + H + h, db); }
+  }
+}
+
+// ---- fused loss reductions over a table of segments ------------------------------------------------
+template <typename T, int MODE>  // MODE 0: |a-b| ; 1: (target-a)^2
+__global__ __launch_bounds__(256) void seg_reduce_fwd(const evt_seg* segs, float target, float* out) {
+  __shared__ float red[4];
+  const evt_seg s = segs[blockIdx.y];
+  const T* a = reinterpret_cast<const T*>(s.a);
+  const T* b = reinterpret_cast<const T*>(s.b);
+  float acc = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < s.n; i += (long)gridDim.x * 256) {
+    if (MODE == 0) acc += fabsf(to_f<T>(a[i]) - to_f<T>(b[i]));
+    else { const float d = target - to_f<T>(a[i]); acc += d * d; }
+  }
+  acc = block_reduce_sum_256(acc, red);
+  if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc * s.scale);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void seg_reduce_bwd(const evt_seg* segs, float target, const float* dloss) {
+  const evt_seg s = segs[blockIdx.y];
+  if (!s.da) return;
+  const T* a = reinterpret_cast<const T*>(s.a);
+  const T* b = reinterpret_cast<const T*>(s.b);
+  T* da = reinterpret_cast<T*>(s.da);
+  const float dl = dloss[0] * s.scale;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < s.n; i += (long)gridDim.x * 256) {
+    float gv;
+    if (MODE == 0) { const float d = to_f<T>(a[i]) - to_f<T>(b[i]); gv = d > 0.f ? dl : (d < 0.f ? -dl : 0.f); }
+    else gv = -2.f * (target - to_f<T>(a[i])) * dl;
+    da[i] = from_f<T>(gv);
+  }
+}
+
+// ---- AdamW over a flat arena ---------------------------------------------------------------------------
+__global__ void adamw_flat_kernel(float* p, const float* g, float* m, float* v, const evt_adamw_seg* segs, int nseg,
+                                  float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale,
+                                  long lo, long hi) {
+  for (long i = lo + blockIdx.x * (long)blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
+    int si = -1;
+    for (int s = 0; s < nseg; ++s)
+      if (i >= segs[s].begin && i < segs[s].end) { si = s; break; }
+    if (si < 0) continue;
+    const float lr = segs[si].lr, wd = segs[si].weight_decay;
+    const float gr = g[i] * gscale;
+    float pv = p[i];
+    pv *= 1.f - lr * wd;
+    const float mv = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mv; v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += x[i] * x[i];
+  acc = block_reduce_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+inline int grid_for(long n, int cap = 8192) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* evt_version(void) { return "evt-hip 0.1 (gfx950)"; }
+
+int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream) {
+  if (!items || !row_index || nrows <= 0) return EVT_EINVAL;
+  hipLaunchKernelGGL(wn_fold_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, items, row_index);
+  return evt_check_launch();
+}
+
+int evt_wn_grad_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream) {
+  if (!items || !row_index || nrows <= 0) return EVT_EINVAL;
+  hipLaunchKernelGGL(wn_grad_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, items, row_index);
+  return evt_check_launch();
+}
+
+int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, float scale, void* out, int64_t n,
+                   void* stream) {
+  if (!a || !out || n <= 0) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(add3_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a,
+                       (const bf16_t*)b, (const bf16_t*)c, scale, (bf16_t*)out, (long)n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(add3_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b,
+                       (const float*)c, scale, (float*)out, (long)n);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_gated_act_fwd(int32_t dtype, const void* xin, const void* g, void* acts, int32_t nseq, int32_t len, int32_t H,
+                      void* stream) {
+  if (!xin || !acts || nseq <= 0 || len <= 0 || H <= 0) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)nseq * len * H;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(gated_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)xin,
+                       (const bf16_t*)g, (bf16_t*)acts, nseq, len, H);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(gated_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)xin,
+                       (const float*)g, (float*)acts, nseq, len, H);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void* dacts, void* dxin, float* dg,
+                      int32_t nseq, int32_t len, int32_t H, void* stream) {
+  if (!xin || !dacts || !dxin || nseq <= 0 || len <= 0 || H <= 0) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)nseq * len * H;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(gated_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)xin,
+                       (const bf16_t*)g, (const bf16_t*)dacts, (bf16_t*)dxin, dg, nseq, len, H);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(gated_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)xin,
+                       (const float*)g, (const float*)dacts, (float*)dxin, dg, nseq, len, H);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+#define SEG_LAUNCH(KERN, MODE, ...)                                                                              \
+  do {                                                                                                           \
+    if (dtype == EVT_DT_BF16) hipLaunchKernelGGL((KERN<bf16_t, MODE>), dim3(64, nseg), dim3(256), 0, st, __VA_ARGS__); \
+    else if (dtype == EVT_DT_F32) hipLaunchKernelGGL((KERN<float, MODE>), dim3(64, nseg), dim3(256), 0, st, __VA_ARGS__); \
+    else return EVT_EINVAL;                                                                                      \
+  } while (0)
+
+int evt_l1_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float* out, void* stream) {
+  if (!segs || nseg <= 0 || !out) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  SEG_LAUNCH(seg_reduce_fwd, 0, segs, 0.f, out);
+  return evt_check_launch();
+}
+int evt_l1_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, const float* dloss, void* stream) {
+  if (!segs || nseg <= 0 || !dloss) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  SEG_LAUNCH(seg_reduce_bwd, 0, segs, 0.f, dloss);
+  return evt_check_launch();
+}
+int evt_lsgan_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, float* out, void* stream) {
+  if (!segs || nseg <= 0 || !out) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  SEG_LAUNCH(seg_reduce_fwd, 1, segs, target, out);
+  return evt_check_launch();
+}
+int evt_lsgan_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, const float* dloss,
+                        void* stream) {
+  if (!segs || nseg <= 0 || !dloss) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  SEG_LAUNCH(seg_reduce_bwd, 1, segs, target, dloss);
+  return evt_check_launch();
+}
+
+int evt_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                   float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || step <= 0 || n <= 0)
+    return EVT_EINVAL;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, segs, nseg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, 0L, (long)n);
+  return evt_check_launch();
+}
+
+int evt_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n <= 0) return EVT_EINVAL;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+  return evt_check_launch();
+}
+
+}  // extern "C"

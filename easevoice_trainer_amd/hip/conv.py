@@ -1,0 +1,313 @@
+"""Host side of the fused Conv1d / ConvTranspose1d family: parameter modules with the reference's
+state_dict keys, the prepared-weight bank, and the autograd Functions that call the C ABI.
+
+Layout contract: activations are channels-last [nseq, L, C] (contiguous); the reference's [B, C, L]
+tensors are transposed once at the model boundary.  Reference modules mirrored:
+torch.nn.Conv1d / ConvTranspose1d / Conv2d((k,1)) with optional old-style weight_norm
+(`weight_g` / `weight_v` keys), src/easevoice/module/models.py:419-446,486-536,563-574,
+modules.py:154-185,226-296.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import lib as L
+
+
+class ConvSlot:
+    """Per-conv record inside a WeightBank: geometry + views into the prepared-weight arenas."""
+
+    __slots__ = ("module", "layout", "reg", "alt", "dw", "bank", "_pcache")
+
+    def __init__(self, module, layout, bank):
+        self.module, self.layout, self.bank = module, layout, bank
+        self.reg = self.alt = self.dw = None
+        self._pcache = {}
+
+    def params(self, nseq, lin, in_slope, out_act, out_slope):
+        key = (nseq, lin, in_slope, out_act, out_slope, self.bank.impl)
+        p = self._pcache.get(key)
+        if p is None:
+            m = self.module
+            p = L.ConvParams(self.bank.dt, nseq, lin, m.cin, m.cout, m.k, m.stride, m.pad, m.dil, m.groups,
+                             1 if m.transposed else 0, in_slope, out_act, out_slope, self.bank.impl)
+            self._pcache[key] = p
+        return p
+
+
+def conv_layout(dt, cin, cout, k, stride, pad, dil, groups, transposed) -> L.WLayout:
+    p = L.ConvParams(dt, 1, max(64, k * dil + 1), cin, cout, k, stride, pad, dil, groups, 1 if transposed else 0,
+                     1.0, 0, 1.0, 0)
+    lay = L.WLayout()
+    L.check(L.lib().evt_conv1d_layout(C.byref(p), C.byref(lay)), "evt_conv1d_layout")
+    return lay
+
+
+class EvtConv1d(nn.Module):
+    """Conv1d / ConvTranspose1d parameter holder.  Keys: `weight` (+`bias`) or `weight_g`/`weight_v`
+    (+`bias`) exactly as torch's (old-style weight-normed) modules expose them; `kdims=2` appends the
+    trailing size-1 kernel dim of DiscriminatorP's Conv2d((k,1)) weights."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, bias=True, transposed=False,
+                 weight_norm=False, kdims=1):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad, self.dil = cin, cout, k, stride, padding, dilation
+        self.groups, self.transposed, self.weight_norm, self.kdims = groups, transposed, weight_norm, kdims
+        d0 = cin if transposed else cout
+        d1 = cout if transposed else cin // groups
+        wshape = (d0, d1, k) + ((1,) if kdims == 2 else ())
+        w = torch.empty(wshape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        fan_in = d1 * k if not transposed else d0 * k  # torch: fan_in is computed from weight.size(1)*k
+        fan_in = w.size(1) * k
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.reshape(d0, -1).norm(dim=1).reshape((d0,) + (1,) * (w.dim() - 1)))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._slot = None
+
+    @property
+    def v(self):
+        return self.weight_v if self.weight_norm else self.weight
+
+    def lout(self, lin):
+        if not self.transposed:
+            return (lin + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
+        return (lin - 1) * self.stride - 2 * self.pad + self.dil * (self.k - 1) + 1
+
+    def forward(self, x, res=None, in_slope=1.0, out_act=L.ACT_NONE, out_slope=1.0):
+        if self._slot is None:
+            raise L.EvtError("EvtConv1d used before WeightBank.attach(); there is no eager fallback")
+        return ConvFn.apply(x, self._slot.bank.anchor, res, self._slot, float(in_slope), int(out_act),
+                            float(out_slope))
+
+
+class WeightBank:
+    """All prepared conv weights of one model: REG/ALT images in the compute dtype, fp32 dW images,
+    and the device tables for the two multi-tensor launches (fold before forward, grad after backward)."""
+
+    def __init__(self, model: nn.Module, dtype: torch.dtype, device, impl=L.IMPL_AUTO):
+        self.dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
+        self.dtype, self.device, self.impl = dtype, torch.device(device), impl
+        self.weight_grads = True
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.slots = []
+        reg_n = alt_n = 0
+        ALIGN = 128  # elements; keeps every image 256-byte aligned
+        offs = []
+        for m in model.modules():
+            if isinstance(m, EvtConv1d):
+                lay = conv_layout(self.dt, m.cin, m.cout, m.k, m.stride, m.pad, m.dil, m.groups, m.transposed)
+                s = ConvSlot(m, lay, self)
+                m._slot = s
+                self.slots.append(s)
+                offs.append((reg_n, alt_n))
+                reg_n += (lay.reg_elems + ALIGN - 1) // ALIGN * ALIGN
+                alt_n += (lay.alt_elems + ALIGN - 1) // ALIGN * ALIGN
+        self.reg_arena = torch.zeros(max(reg_n, 1), dtype=dtype, device=device)
+        self.alt_arena = torch.zeros(max(alt_n, 1), dtype=dtype, device=device)
+        self.dw_arena = torch.zeros(max(reg_n, 1), dtype=torch.float32, device=device)
+        for s, (ro, ao) in zip(self.slots, offs):
+            s.reg = self.reg_arena[ro: ro + s.layout.reg_elems]
+            s.alt = self.alt_arena[ao: ao + s.layout.alt_elems]
+            s.dw = self.dw_arena[ro: ro + s.layout.reg_elems]
+        self._items = self._rows = None
+        self._nrows = 0
+
+    def build_tables(self):
+        """(Re)build the device descriptor tables.  Must be called after parameters (and their .grad
+        buffers) have reached their final storage (ParamArena.flatten)."""
+        items, rows = [], []
+        for i, s in enumerate(self.slots):
+            m = s.module
+            v = m.v
+            if v.grad is None:
+                v.grad = torch.zeros_like(v)
+            g = m.weight_g if m.weight_norm else None
+            if g is not None and g.grad is None:
+                g.grad = torch.zeros_like(g)
+            it = L.WPrepItem()
+            it.v = v.data_ptr()
+            it.g = g.data_ptr() if g is not None else None
+            it.reg, it.alt, it.dw = s.reg.data_ptr(), s.alt.data_ptr(), s.dw.data_ptr()
+            it.dv = v.grad.data_ptr()
+            it.dg = g.grad.data_ptr() if g is not None else None
+            it.lay = s.layout
+            it.dtype = self.dt
+            items.append(it)
+            rows.extend((i, r) for r in range(s.layout.d0))
+        self._items = L.struct_to_device(items, self.device)
+        self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+        self._nrows = len(rows)
+
+    def fold(self):
+        """w = g*v/|v| -> REG/ALT images for every conv of the model: ONE launch."""
+        if self._items is None:
+            self.build_tables()
+        L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
+                "evt_wn_fold_multi")
+
+    def zero_dw(self):
+        self.dw_arena.zero_()
+
+    def grads(self):
+        """dW images -> weight_v.grad / weight_g.grad (or weight.grad): ONE launch."""
+        L.check(L.lib().evt_wn_grad_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
+                "evt_wn_grad_multi")
+
+
+def _fwd(slot, x, res, in_slope, out_act, out_slope):
+    m = slot.module
+    if x.dim() != 3 or x.size(2) != m.cin or x.dtype != slot.bank.dtype or not x.is_contiguous():
+        raise L.EvtError(f"conv input must be contiguous [nseq, L, {m.cin}] {slot.bank.dtype}, got "
+                         f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
+    nseq, lin = x.size(0), x.size(1)
+    y = torch.empty((nseq, m.lout(lin), m.cout), dtype=x.dtype, device=x.device)
+    if res is not None and (res.shape != y.shape or not res.is_contiguous() or res.dtype != x.dtype):
+        raise L.EvtError("residual must match the output")
+    p = slot.params(nseq, lin, in_slope, out_act, out_slope)
+    bias = m.bias
+    L.check(L.lib().evt_conv1d_fwd(C.byref(p), L.ptr(x), L.ptr(slot.reg), L.ptr(slot.alt),
+                                   L.ptr(bias.data if bias is not None else None), L.ptr(res), L.ptr(y),
+                                   L.stream_ptr()), "evt_conv1d_fwd")
+    return y
+
+
+def _bwd_data(slot, dy, y, x, dx_add, nseq, lin, in_slope, out_act, out_slope):
+    m = slot.module
+    dx = torch.empty((nseq, lin, m.cin), dtype=dy.dtype, device=dy.device)
+    p = slot.params(nseq, lin, in_slope, out_act, out_slope)
+    L.check(L.lib().evt_conv1d_bwd_data(C.byref(p), L.ptr(dy), L.ptr(y if out_act != L.ACT_NONE else None),
+                                        L.ptr(slot.reg), L.ptr(slot.alt), L.ptr(x if in_slope != 1.0 else None),
+                                        L.ptr(dx_add), L.ptr(dx), L.stream_ptr()), "evt_conv1d_bwd_data")
+    return dx
+
+
+def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
+    m = slot.module
+    p = slot.params(nseq, lin, in_slope, out_act, out_slope)
+    dbias = None
+    if m.bias is not None:
+        if m.bias.grad is None:
+            m.bias.grad = torch.zeros_like(m.bias)
+        dbias = m.bias.grad
+    L.check(L.lib().evt_conv1d_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(y if out_act != L.ACT_NONE else None),
+                                          L.ptr(slot.dw), L.ptr(dbias), L.stream_ptr()), "evt_conv1d_bwd_weight")
+
+
+class ConvFn(torch.autograd.Function):
+    """y = act_out(conv(lrelu(x, in_slope)) + bias) + res, one HIP launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, res, slot, in_slope, out_act, out_slope):
+        y = _fwd(slot, x, res, in_slope, out_act, out_slope)
+        ctx.slot, ctx.cfg = slot, (in_slope, out_act, out_slope)
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, y if out_act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        slot = ctx.slot
+        in_slope, out_act, out_slope = ctx.cfg
+        dy = dy.contiguous()
+        nseq, lin = x.size(0), x.size(1)
+        if slot.bank.weight_grads:
+            _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _bwd_data(slot, dy, y, x, None, nseq, lin, in_slope, out_act, out_slope)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[2]) else None
+        if dres is not None and out_act != L.ACT_NONE:
+            raise L.EvtError("residual + output activation: residual is added after the activation, "
+                             "its gradient is dy (supported), but was not expected here")
+        return dx, None, dres, None, None, None, None
+
+
+class ResUnitFn(torch.autograd.Function):
+    """HiFi-GAN ResBlock1 inner step  y = x + c2(lrelu(c1(lrelu(x))))  (modules.py:299-308) as
+    2 launches forward and 4 backward, with the residual add and both leaky-relu derivatives fused
+    into the conv epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, s1, s2, slope):
+        mid = _fwd(s1, x, None, slope, L.ACT_NONE, 1.0)
+        y = _fwd(s2, mid, x, slope, L.ACT_NONE, 1.0)
+        ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
+        ctx.save_for_backward(x, mid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mid = ctx.saved_tensors
+        s1, s2, slope = ctx.s1, ctx.s2, ctx.slope
+        dy = dy.contiguous()
+        nseq, lin = x.size(0), x.size(1)
+        if s2.bank.weight_grads:
+            _bwd_weight(s2, mid, dy, None, nseq, lin, slope, L.ACT_NONE, 1.0)
+        dmid = _bwd_data(s2, dy, None, mid, None, nseq, lin, slope, L.ACT_NONE, 1.0)
+        if s1.bank.weight_grads:
+            _bwd_weight(s1, x, dmid, None, nseq, lin, slope, L.ACT_NONE, 1.0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _bwd_data(s1, dmid, None, x, dy, nseq, lin, slope, L.ACT_NONE, 1.0)
+        return dx, None, None, None, None
+
+
+def res_unit(x, c1: EvtConv1d, c2: EvtConv1d, slope: float):
+    return ResUnitFn.apply(x, c1._slot.bank.anchor, c1._slot, c2._slot, float(slope))
+
+
+class Add3ScaleFn(torch.autograd.Function):
+    """(a + b + c) * scale — HiFi-GAN stage mean (models.py:457-466)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, scale):
+        out = torch.empty_like(a)
+        L.check(L.lib().evt_add3_scale(L.dt_of(a), L.ptr(a), L.ptr(b), L.ptr(c), C.c_float(scale), L.ptr(out),
+                                       C.c_int64(a.numel()), L.stream_ptr()), "evt_add3_scale")
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        g = torch.empty_like(d)
+        L.check(L.lib().evt_add3_scale(L.dt_of(d), L.ptr(d), None, None, C.c_float(ctx.scale), L.ptr(g),
+                                       C.c_int64(d.numel()), L.stream_ptr()), "evt_add3_scale")
+        return g, g, g, None
+
+
+class GatedActFn(torch.autograd.Function):
+    """tanh(a+ga) * sigmoid(b+gb) on channels-last [n, t, 2H] (+ g [n, 2H]) — commons.py:94-101."""
+
+    @staticmethod
+    def forward(ctx, xin, g):
+        n, t, h2 = xin.shape
+        acts = torch.empty((n, t, h2 // 2), dtype=xin.dtype, device=xin.device)
+        L.check(L.lib().evt_gated_act_fwd(L.dt_of(xin), L.ptr(xin), L.ptr(g), L.ptr(acts), n, t, h2 // 2,
+                                          L.stream_ptr()), "evt_gated_act_fwd")
+        ctx.save_for_backward(xin, g)
+        return acts
+
+    @staticmethod
+    def backward(ctx, dacts):
+        xin, g = ctx.saved_tensors
+        n, t, h2 = xin.shape
+        dacts = dacts.contiguous()
+        dxin = torch.empty_like(xin)
+        dg32 = None
+        if g is not None and ctx.needs_input_grad[1]:
+            dg32 = torch.zeros((n, h2), dtype=torch.float32, device=xin.device)
+        L.check(L.lib().evt_gated_act_bwd(L.dt_of(xin), L.ptr(xin), L.ptr(g), L.ptr(dacts), L.ptr(dxin), L.ptr(dg32),
+                                          n, t, h2 // 2, L.stream_ptr()), "evt_gated_act_bwd")
+        return dxin, (dg32.to(g.dtype) if dg32 is not None else None)

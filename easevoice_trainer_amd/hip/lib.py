@@ -1,0 +1,133 @@
+"""ctypes binding of libevt_hip.so (the C ABI declared in include/evt.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns non-zero, an
+exception is raised.  torch is used only to own device memory and streams; every pointer crossing
+this boundary is a raw `data_ptr()`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libevt_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+IMPL_AUTO, IMPL_NAIVE, IMPL_IGEMM = 0, 1, 2
+
+
+class EvtError(RuntimeError):
+    pass
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("nseq", C.c_int32), ("lin", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("groups", C.c_int32),
+        ("transposed", C.c_int32), ("in_slope", C.c_float), ("out_act", C.c_int32), ("out_slope", C.c_float),
+        ("impl", C.c_int32),
+    ]
+
+
+class WLayout(C.Structure):
+    _fields_ = [
+        ("d0", C.c_int32), ("d1", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32),
+        ("reg_ck", C.c_int32), ("reg_nchunk", C.c_int32), ("reg_kp", C.c_int32),
+        ("alt_ck", C.c_int32), ("alt_nchunk", C.c_int32), ("alt_kp", C.c_int32), ("alt_nphase", C.c_int32),
+        ("reg_elems", C.c_int64), ("alt_elems", C.c_int64),
+    ]
+
+
+class WPrepItem(C.Structure):
+    _fields_ = [
+        ("v", C.c_void_p), ("g", C.c_void_p), ("reg", C.c_void_p), ("alt", C.c_void_p),
+        ("dw", C.c_void_p), ("dv", C.c_void_p), ("dg", C.c_void_p),
+        ("lay", WLayout), ("dtype", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
+class Seg(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("da", C.c_void_p), ("n", C.c_int64),
+                ("scale", C.c_float), ("pad_", C.c_int32)]
+
+
+class AdamWSeg(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
+        ("x_len", C.c_int32),
+        ("q_stride_b", C.c_int64), ("q_stride_l", C.c_int64), ("q_stride_h", C.c_int64),
+        ("o_stride_b", C.c_int64), ("o_stride_l", C.c_int64), ("o_stride_h", C.c_int64),
+    ]
+
+
+class ScaledAdamHP(C.Structure):
+    _fields_ = [
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("scalar_lr_scale", C.c_float), ("param_min_rms", C.c_float), ("param_max_rms", C.c_float),
+        ("clipping_scale", C.c_float),
+        ("step", C.c_int32), ("size_update_period", C.c_int32), ("pad0_", C.c_int32), ("pad1_", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly if it is missing (no CPU / eager fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EvtError(
+                f"{LIB_PATH} not found: build it with `python -m easevoice_trainer_amd.build` "
+                "(or __graft_entry__.build()). There is no fallback path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.evt_version.restype = C.c_char_p
+        _lib.evt_conv1d_lout.restype = C.c_int32
+        if hasattr(_lib, "evt_mel_workspace_floats"):
+            _lib.evt_mel_workspace_floats.restype = C.c_int64
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise EvtError(f"{what} failed with code {rc}")
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise EvtError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt: int) -> torch.dtype:
+    return torch.float32 if dt == DT_F32 else torch.bfloat16
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL); the tensor must be contiguous"""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_contiguous():
+        raise EvtError("non-contiguous tensor passed to the C ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def struct_to_device(items, device) -> torch.Tensor:
+    """copy a python list of ctypes structures to a device uint8 tensor"""
+    if not items:
+        raise EvtError("empty table")
+    arr = (type(items[0]) * len(items))(*items)
+    buf = bytes(arr)
+    host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+    return host.to(device)

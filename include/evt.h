@@ -1,0 +1,221 @@
+/*
+ * evt.h — C ABI of libevt_hip.so, the MI355X (gfx950) compute library behind the
+ * GPT-SoVITS training hot path of megaease/easevoice-trainer.
+ *
+ * The reference has NO native code: every entry point below replaces a vendor kernel that
+ * the reference reaches through torch (ATen / cuDNN / cuBLAS / cuFFT) at the cited call
+ * site.  Citations are file:line under /root/reference.
+ *
+ * Conventions
+ *   - plain C, raw device pointers, sizes as int32/int64, `stream` is a hipStream_t passed
+ *     as void*; no torch types, no hidden allocation, no global mutable state; every call
+ *     only enqueues work on `stream` and returns 0 or a positive errno-style code.
+ *   - activations are CHANNELS-LAST: a "sequence tensor" is [nseq][len][channels] with the
+ *     channel index contiguous (the reference's [B, C, L] transposed); bf16 tensors are raw
+ *     uint16 storage.  dtype: 0 = float32, 1 = bfloat16 (fp32 accumulation everywhere).
+ *   - weight gradients / bias gradients are fp32 and are ACCUMULATED (+=) into the caller's
+ *     buffers (atomics), so the caller zeroes them once per optimiser step.
+ */
+#ifndef EVT_H
+#define EVT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVT_DT_F32 0
+#define EVT_DT_BF16 1
+#define EVT_ACT_NONE 0
+#define EVT_ACT_LRELU 1
+#define EVT_ACT_TANH 2
+#define EVT_IMPL_AUTO 0
+#define EVT_IMPL_NAIVE 1 /* direct-form reference kernels (any shape, groups) */
+#define EVT_IMPL_IGEMM 2 /* LDS-tiled implicit-GEMM on MFMA */
+
+const char* evt_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Conv1d / ConvTranspose1d family.
+ * Replaces F.conv1d / F.conv_transpose1d / F.conv2d((k,1)) reached from
+ *   HiFi-GAN Generator + ResBlock1   src/easevoice/module/models.py:452-471, modules.py:298-311
+ *   WN (enc_q, flow)                 src/easevoice/module/modules.py:187-212
+ *   FFN convs                        src/easevoice/module/attentions.py:408-416
+ *   DiscriminatorS / DiscriminatorP  src/easevoice/module/models.py:538-587
+ * One fused op computes, per output position:
+ *     y = act_out( conv( lrelu(x, in_slope) ) + bias ) * 1 + res
+ * DiscriminatorP's Conv2d (k,1)/(s,1) over [B,1,T/p,p] is the same op on B*p sequences
+ * (the caller lays the period axis out as the sequence axis).
+ * ------------------------------------------------------------------------------------- */
+typedef struct evt_conv1d_params {
+  int32_t dtype;      /* EVT_DT_*: activations and prepared weights */
+  int32_t nseq;       /* sequences (batch, or batch*period) */
+  int32_t lin;        /* input length per sequence */
+  int32_t cin, cout;  /* module in/out channels (ConvTranspose: in = weight dim 0) */
+  int32_t k, stride, pad, dil, groups;
+  int32_t transposed; /* 0 Conv1d (weight [cout][cin/g][k]); 1 ConvTranspose1d (weight [cin][cout][k]) */
+  float in_slope;     /* leaky-relu slope applied to x on load; 1.0f = identity */
+  int32_t out_act;    /* EVT_ACT_* applied to conv+bias */
+  float out_slope;    /* slope when out_act == EVT_ACT_LRELU */
+  int32_t impl;       /* EVT_IMPL_* */
+} evt_conv1d_params;
+
+/* output length for these hyper-parameters (torch semantics) */
+int32_t evt_conv1d_lout(const evt_conv1d_params* p);
+
+/* Prepared-weight layouts.  The parameter tensor is W[d0][d1][k] (Conv1d: d0=cout, d1=cin/g;
+ * ConvTranspose1d: d0=cin, d1=cout).  Two GEMM-ready images are derived from it:
+ *   REG: [d0][chunk(d1)][k'][ck]                — "rows = d0"; Conv1d forward, ConvT backward-data, all dW
+ *   ALT: stride==1: [d1][chunk(d0)][k' flipped][ck]; stride>1: polyphase [phase][d1][chunk(d0)][j][ck]
+ *                                                — Conv1d backward-data, ConvT forward
+ * evt_conv1d_layout fills the geometry; element counts are in elements of the compute dtype
+ * (REG/ALT) or fp32 (dW, same geometry as REG). */
+typedef struct evt_wlayout {
+  int32_t d0, d1, k, stride;
+  int32_t reg_ck, reg_nchunk, reg_kp;          /* REG image */
+  int32_t alt_ck, alt_nchunk, alt_kp, alt_nphase; /* ALT image (alt_kp = taps per phase) */
+  int64_t reg_elems, alt_elems;
+} evt_wlayout;
+int evt_conv1d_layout(const evt_conv1d_params* p, evt_wlayout* out);
+
+/* Multi-tensor weight preparation: one launch for a whole model.
+ * Replaces torch.nn.utils.weight_norm's per-forward w = g * v / ||v|| (dims 1,2 per d0 row;
+ * modules.py:162,174,184,228-296, models.py:427-436,486-536,563-574) plus the cast/layout
+ * change into REG and ALT images.  `g` may be NULL for plain (non weight-normed) convs. */
+typedef struct evt_wprep_item {
+  const float* v;   /* [d0][d1][k] fp32 master (weight_v, or weight when g == NULL) */
+  const float* g;   /* [d0] fp32 weight_g or NULL */
+  void* reg;        /* REG image (compute dtype) or NULL */
+  void* alt;        /* ALT image (compute dtype) or NULL */
+  /* backward side (evt_wn_grad_multi): */
+  const float* dw;  /* fp32 REG-geometry gradient, accumulated by evt_conv1d_bwd_weight */
+  float* dv;        /* [d0][d1][k] fp32, += */
+  float* dg;        /* [d0] fp32, += (NULL when g == NULL) */
+  evt_wlayout lay;
+  int32_t dtype;
+  int32_t pad_;
+} evt_wprep_item;
+/* items is a DEVICE pointer to n items; row_index is a DEVICE int32 [nrows][2] table of
+ * (item, d0-row) pairs, one workgroup each. */
+int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream);
+int evt_wn_grad_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream);
+
+/* y[nseq][lout][cout] = act_out(conv(lrelu(x)) + bias) + res ; bias/res may be NULL.
+ * The MFMA path reads REG for Conv1d and ALT for ConvTranspose1d; the direct path reads REG.
+ * Pass both images (either may be NULL if the path that needs it cannot be selected). */
+int evt_conv1d_fwd(const evt_conv1d_params* p, const void* x, const void* w_reg, const void* w_alt,
+                   const float* bias, const void* res, void* y, void* stream);
+
+/* dx[nseq][lin][cin] = convT( dy * act_out'(y) ) * lrelu'(x) + dx_add
+ * y may be NULL when out_act == NONE; x may be NULL when in_slope == 1; dx_add may be NULL.
+ * The MFMA path reads ALT for Conv1d and REG for ConvTranspose1d; the direct path reads REG. */
+int evt_conv1d_bwd_data(const evt_conv1d_params* p, const void* dy, const void* y, const void* w_reg,
+                        const void* w_alt, const void* x, const void* dx_add, void* dx, void* stream);
+
+/* dW(REG geometry, fp32) += ..., dbias[cout] += sum(dy * act_out'(y)); dbias may be NULL. */
+int evt_conv1d_bwd_weight(const evt_conv1d_params* p, const void* x, const void* dy, const void* y,
+                          float* dw, float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Element-wise / reduction helpers of the s2 path.
+ * ------------------------------------------------------------------------------------- */
+/* out = (a + b + c) * scale ; b, c may be NULL.  (Generator stage mean, models.py:457-466) */
+int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, float scale, void* out,
+                   int64_t n, void* stream);
+
+/* WN gated activation, commons.py:94-101 (fused_add_tanh_sigmoid_multiply), channels-last:
+ *   acts[n][t][h] = tanh(xin[n][t][h] + g[n][h]) * sigmoid(xin[n][t][H+h] + g[n][H+h])
+ * g is [nseq][2H] (broadcast over t) or NULL. */
+int evt_gated_act_fwd(int32_t dtype, const void* xin, const void* g, void* acts, int32_t nseq, int32_t len,
+                      int32_t H, void* stream);
+/* dxin = d(acts)/d(xin) * dacts ; dg[nseq][2H] (fp32, +=) may be NULL */
+int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void* dacts, void* dxin, float* dg,
+                      int32_t nseq, int32_t len, int32_t H, void* stream);
+
+/* STFT magnitude + mel + log of the generated waveform, src/easevoice/module/mel_processing.py:93-142:
+ * reflect-pad (n_fft-hop)/2, hann window, n_fft-point real DFT per frame (radix-2 in LDS, wavefront
+ * shuffles for the short butterflies), sqrt(re^2+im^2+1e-6), mel basis [n_mels][n_fft/2+1] matmul,
+ * log(clamp(.,1e-5)).  wav is fp32 [nseq][wav_len]; outputs fp32 channels-FIRST [nseq][n_mels][frames]
+ * (the layout the mel-L1 at sovits.py:513 consumes).  spec_out ([nseq][n_fft/2+1][frames]) may be NULL. */
+int evt_mel_fwd(const float* wav, const float* window, const float* mel_basis, float* spec_out, float* mel_out,
+                float* ws_spec_re_im, int32_t nseq, int32_t wav_len, int32_t n_fft, int32_t hop, int32_t n_mels,
+                void* stream);
+/* dwav[nseq][wav_len] = d(sum(dmel * mel))/d(wav); ws is the (re,im,mag,melpre) workspace written by fwd. */
+int evt_mel_bwd(const float* dmel, const float* window, const float* mel_basis, const float* ws_spec_re_im,
+                float* dwav, int32_t nseq, int32_t wav_len, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream);
+/* workspace floats needed by evt_mel_fwd/bwd */
+int64_t evt_mel_workspace_floats(int32_t nseq, int32_t wav_len, int32_t n_fft, int32_t hop, int32_t n_mels);
+
+/* Fused loss reductions (src/easevoice/module/losses.py:7-61).  Pointer tables are DEVICE arrays.
+ * feature_loss: out[0] += 2 * sum_i mean|r_i - g_i| ; optional dg_i = 2*sign(g_i-r_i)/n_i * dloss. */
+typedef struct evt_seg { const void* a; const void* b; void* da; int64_t n; float scale; int32_t pad_; } evt_seg;
+int evt_l1_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float* out, void* stream);
+int evt_l1_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, const float* dloss, void* stream);
+/* LSGAN: out[0] += sum_i scale_i * mean((target - a_i)^2) ; da_i = -2*scale_i*(target - a_i)/n_i * dloss */
+int evt_lsgan_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, float* out, void* stream);
+int evt_lsgan_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, const float* dloss,
+                        void* stream);
+
+/* Multi-segment AdamW over a flat fp32 arena (torch.optim.AdamW at sovits.py:294-319: decoupled
+ * weight decay, bias correction, eps outside the sqrt).  seg table is a DEVICE array (<= 64 segments);
+ * elements of [0, n) outside every segment are left untouched (frozen parameters, alignment padding). */
+typedef struct evt_adamw_seg { int64_t begin, end; float lr; float weight_decay; } evt_adamw_seg;
+int evt_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
+                   float grad_scale, void* stream);
+/* out[0] = sum(x^2) over n floats (grad-norm at commons.py:140-155 without the per-parameter .item()) */
+int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * s1 (text -> semantic GPT) kernels.
+ * ------------------------------------------------------------------------------------- */
+/* Flash attention with the ANALYTIC prefix-LM + key-padding mask of
+ * src/easevoice/soundstorm/auto_reg/models/t2s_model.py:456-479 (no [B*H,L,L] mask tensor):
+ *   key j visible from query i  <=>  j is not padding  AND  ( j < x_len  if i < x_len  else  j <= i )
+ * where padding keys are x-part columns j >= x_lens[b] and y-part columns j - x_len >= y_lens[b].
+ * q,k,v,o: [B][L][H][D] (the packed in_proj output viewed per head), D = 32 or 64, bf16 or fp32 storage;
+ * softmax scale = 1/sqrt(D); lse: fp32 [B][H][L] (log-sum-exp, saved for backward).
+ * Replaces F.scaled_dot_product_attention at patched_mha_with_cache.py:452-454. */
+typedef struct evt_attn_params {
+  int32_t dtype, B, L, H, D;
+  int32_t x_len;             /* padded text length (prefix width) */
+  int64_t q_stride_b, q_stride_l, q_stride_h; /* element strides (q, k, v share them) */
+  int64_t o_stride_b, o_stride_l, o_stride_h;
+} evt_attn_params;
+int evt_attn_prefixlm_fwd(const evt_attn_params* p, const void* q, const void* k, const void* v,
+                          const int32_t* x_lens, const int32_t* y_lens, void* o, float* lse, void* stream);
+int evt_attn_prefixlm_bwd(const evt_attn_params* p, const void* q, const void* k, const void* v, const void* o,
+                          const void* d_o, const float* lse, const int32_t* x_lens, const int32_t* y_lens,
+                          void* dq, void* dk, void* dv, float* delta_ws, void* stream);
+
+/* y = LayerNorm(x + r) * gamma + beta over the last dim C (post-LN block, transformer.py:311-315);
+ * r may be NULL.  mean/rstd fp32 [rows] are saved for backward. */
+int evt_add_layernorm_fwd(int32_t dtype, const void* x, const void* r, const float* gamma, const float* beta,
+                          void* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream);
+/* dxr = d/d(x+r); dgamma/dbeta fp32 [C] are accumulated (+=) */
+int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const float* gamma, const void* dy,
+                          const float* mean, const float* rstd, void* dxr, float* dgamma, float* dbeta,
+                          int64_t rows, int32_t C, void* stream);
+
+/* Cross-entropy, reduction="sum" (t2s_model.py:486-489): logits [rows][V] (any dtype), targets int64.
+ * loss[0] += sum_r (lse_r - logit[r][t_r]); dlogits = (softmax - onehot) * dloss[0]; top-k hit counts for
+ * the accuracy metric are written to hits[0] (+=, rows with target == ignore_index skipped, count in hits[1]). */
+int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
+                       int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, float dloss,
+                       void* stream);
+
+/* ScaledAdam batched update (src/easevoice/soundstorm/auto_reg/modules/optim.py:448-598) over a stack of
+ * `nb` same-shaped tensors laid out contiguously [nb][numel]. */
+typedef struct evt_scaled_adam_hp {
+  float lr, beta1, beta2, eps, scalar_lr_scale, param_min_rms, param_max_rms, clipping_scale;
+  int32_t step, size_update_period, pad0_, pad1_;
+} evt_scaled_adam_hp;
+int evt_scaled_adam_batch(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* param_rms,
+                          float* scale_grads, float* scale_exp_avg_sq, float* delta, int32_t nb, int64_t numel,
+                          const evt_scaled_adam_hp* hp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVT_H */

@@ -1,0 +1,121 @@
+"""GPU parity: fused Conv1d / ConvTranspose1d HIP kernels (through the C ABI) vs the CPU oracle.
+
+fp32 tolerance 1e-3 relative to the tensor's max-abs (north_star: 1e-3 relative fp32); bf16 runs are
+checked at 3e-2 against the fp32 oracle evaluated on bf16-rounded inputs.
+"""
+import pytest
+import torch
+from torch import nn
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+# (cin, cout, k, stride, pad, dil, groups, transposed, wn, L, nseq)  — shapes of the real model, short L
+CASES = [
+    # HiFi-GAN ResBlock convs (modules.py:226-296): C in {256,128,64,32,16}, k in {3,7,11}, d in {1,3,5}
+    (32, 32, 3, 1, 1, 1, 1, False, True, 100, 3),
+    (32, 32, 11, 1, 25, 5, 1, False, True, 150, 2),
+    (16, 16, 7, 1, 9, 3, 1, False, True, 130, 2),
+    (16, 16, 11, 1, 5, 1, 1, False, True, 70, 2),
+    (64, 64, 7, 1, 3, 1, 1, False, True, 96, 2),
+    (128, 128, 3, 1, 3, 3, 1, False, True, 80, 2),
+    (256, 256, 11, 1, 5, 1, 1, False, True, 40, 2),
+    # conv_pre 192->512 k7, WN in_layer 192->384 k5, FFN 192->768 k3, 1x1 res_skip
+    (192, 512, 7, 1, 3, 1, 1, False, False, 32, 2),
+    (192, 384, 5, 1, 2, 1, 1, False, True, 50, 2),
+    (192, 768, 3, 1, 1, 1, 1, False, False, 37, 2),
+    (192, 384, 1, 1, 0, 1, 1, False, True, 45, 2),
+    (96, 192, 1, 1, 0, 1, 1, False, False, 45, 2),
+    # ups (models.py:424-436): (k,u,p) = (16,10,3) (16,8,4) (8,2,3) (2,2,0)
+    (64, 32, 16, 10, 3, 1, 1, True, True, 12, 2),
+    (64, 32, 16, 8, 4, 1, 1, True, True, 12, 2),
+    (32, 16, 8, 2, 3, 1, 1, True, True, 33, 2),
+    (32, 16, 2, 2, 0, 1, 1, True, True, 33, 2),
+    # DiscriminatorP (k5,s3) and (k5,s1), DiscriminatorS dense k5 (models.py:487-536,571)
+    (32, 128, 5, 3, 2, 1, 1, False, True, 100, 4),
+    (128, 64, 5, 3, 2, 1, 1, False, True, 23, 6),
+    (64, 64, 5, 1, 2, 1, 1, False, True, 23, 6),
+    # degenerate / grouped shapes -> direct kernels: conv_post 16->1 k7 no bias, D first layers, D post,
+    # DiscriminatorS grouped k41 s4
+    (16, 1, 7, 1, 3, 1, 1, False, False, 90, 2),
+    (1, 32, 5, 3, 2, 1, 1, False, True, 200, 4),
+    (1, 16, 15, 1, 7, 1, 1, False, True, 120, 2),
+    (64, 1, 3, 1, 1, 1, 1, False, True, 40, 3),
+    (16, 64, 41, 4, 20, 1, 4, False, True, 300, 2),
+]
+FUSIONS = [
+    dict(in_slope=1.0, out_act=0, out_slope=1.0, res=False),
+    dict(in_slope=0.1, out_act=0, out_slope=1.0, res=True),
+    dict(in_slope=1.0, out_act=1, out_slope=0.1, res=False),
+    dict(in_slope=0.01, out_act=2, out_slope=1.0, res=False),
+]
+
+
+def _run_case(gpu, case, fusion, dtype, impl):
+    from easevoice_trainer_amd.hip import conv as HC, lib as HL
+
+    cin, cout, k, stride, pad, dil, groups, transposed, wn, Lin, nseq = case
+    torch.manual_seed(hash(case) % 100000)
+    m = HC.EvtConv1d(cin, cout, k, stride, pad, dil, groups, bias=(cout != 1 or wn), transposed=transposed,
+                     weight_norm=wn)
+    if wn:
+        with torch.no_grad():
+            m.weight_g.mul_(torch.rand_like(m.weight_g) + 0.5)
+    x = torch.randn(nseq, cin, Lin)  # reference layout
+    lout = m.lout(Lin)
+    res = torch.randn(nseq, cout, lout) if fusion["res"] else None
+    dy = torch.randn(nseq, cout, lout)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+
+    # ---- oracle (CPU fp32, [B,C,L]) ----
+    xo = x.clone().requires_grad_(True)
+    ro = res.clone().requires_grad_(True) if res is not None else None
+    po = {n_: p.detach().clone().requires_grad_(True) for n_, p in m.named_parameters()}
+    w = O.weight_norm_fold(po["weight_v"], po["weight_g"]) if wn else po["weight"]
+    if dtype == torch.bfloat16:
+        w = w + (w.detach().bfloat16().float() - w.detach())  # straight-through bf16 rounding of weights
+    yo = O.conv_block(xo, w, po.get("bias"), ro, stride=stride, pad=pad, dil=dil, groups=groups,
+                      transposed=transposed, in_slope=fusion["in_slope"], out_act=fusion["out_act"],
+                      out_slope=fusion["out_slope"])
+    yo.backward(dy)
+
+    # ---- HIP path (channels-last) ----
+    m = m.to(gpu)
+    bank = HC.WeightBank(m, dtype, gpu, impl=impl)
+    bank.build_tables()
+    bank.fold()
+    xg = x.transpose(1, 2).contiguous().to(gpu, dtype).requires_grad_(True)
+    rg = res.transpose(1, 2).contiguous().to(gpu, dtype).requires_grad_(True) if res is not None else None
+    yg = m(xg, rg, fusion["in_slope"], fusion["out_act"], fusion["out_slope"])
+    yg.backward(dy.transpose(1, 2).contiguous().to(gpu, dtype))
+    bank.grads()
+    torch.cuda.synchronize()
+
+    tol = 1e-3 if dtype == torch.float32 else 3e-2
+
+    def close(a, b, name):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        scale = b.abs().max().item() + 1e-6
+        err = (a - b).abs().max().item() / scale
+        assert err < tol, f"{name}: rel err {err:.3e} (tol {tol}) case={case} fusion={fusion} dtype={dtype} impl={impl}"
+
+    close(yg.transpose(1, 2), yo, "y")
+    close(xg.grad.transpose(1, 2), xo.grad, "dx")
+    if rg is not None:
+        close(rg.grad.transpose(1, 2), ro.grad, "dres")
+    for n_, p in m.named_parameters():
+        close(p.grad, po[n_].grad, f"d{n_}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("impl", [1, 0], ids=["naive", "auto"])
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_conv_parity(gpu, ci, impl, dtype):
+    case = CASES[ci]
+    for fusion in FUSIONS:
+        if fusion["res"] and case[7]:
+            continue
+        _run_case(gpu, case, fusion, dtype, impl)
