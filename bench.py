@@ -1,0 +1,141 @@
+"""bench.py — the s2 SoVITS GAN training step (generator + discriminators, both AdamW updates) on synthetic
+fixed-shape batches, one process per GPU.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+Workload (BASELINE.json configs[1]): batch 16 per GPU, 4 s clips (T = 200 frames, 128000
+samples, text 60), bf16 compute, random-init weights of configs/s2.json, synthetic data.  Weak scaling: the per-GPU
+batch is fixed, gradients are all-reduced over RCCL.
+metric: audio-seconds/sec trained (s2) = N * B * clip_seconds / step_time.  The s1 tokens/s figure of the combined
+BASELINE metric is reported by `--workload s1` (secondary line, same contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def init_dist(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def synth_s2_batch(B, T, t_text, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    wav = (torch.rand(B, 1, T * 640, generator=g) - 0.5).to(device)
+    ssl = torch.randn(B, 768, T, generator=g).to(device)
+    text = torch.randint(0, 732, (B, t_text), generator=g).to(device)
+    lengths = torch.full((B,), T, dtype=torch.long, device=device)
+    tl = torch.full((B,), t_text, dtype=torch.long, device=device)
+    return wav, ssl, text, lengths, tl
+
+
+def run_s2(args, world, rank, local):
+    from easevoice_trainer_amd.module.mel_processing import spectrogram_torch
+    from easevoice_trainer_amd.train.s2_engine import S2Engine
+
+    dev = torch.device("cuda", local)
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(hps["train"]["seed"])
+    reducer = None
+    if world > 1:
+        from easevoice_trainer_amd.dist import GradReducer
+
+        reducer = GradReducer(world)
+    eng = S2Engine(hps, dev, dtype, reducer=reducer)
+    # frozen quantizer codebook: synthetic N(0,1) codes; marks it initialised
+    cb = eng.net_g.quantizer.vq.layers[0]._codebook
+    cb.embed.normal_(generator=None)
+    cb.inited.fill_(1.0)
+    if world > 1:
+        reducer.broadcast_params(eng.rt_g.arena.param)
+        reducer.broadcast_params(eng.rt_d.arena.param)
+    eng.build_optimizers()
+    B, T, t_text = args.batch, args.clip_seconds * 50, 60
+    wav, ssl, text, lengths, tl = synth_s2_batch(B, T, t_text, dev, 1234 + rank)
+    spec = spectrogram_torch(wav.squeeze(1), 2048, 32000, 640, 2048)
+
+    def step():
+        return eng.step(ssl, spec, lengths, wav, text, tl)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    losses = dict(disc=float(out.disc), gen=float(out.gen), fm=float(out.fm), mel=float(out.mel), kl=float(out.kl))
+    finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+    res = {
+        "metric": "audio-seconds/sec trained (s2)", "value": world * B * args.clip_seconds / (dt / args.steps),
+        "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"s2 SoVITS generator+discriminator GAN step, batch={B}/GPU, {args.clip_seconds} s 32 kHz "
+                               f"clips (T={T} frames), configs/s2.json, random-init weights",
+                   "global_batch": world * B, "parallelism": f"dp{world}"},
+        "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
+        "losses_last_step": losses, "losses_finite": finite,
+    }
+    return res, eng
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="s2", choices=["s2", "s1"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--clip-seconds", type=int, default=4)
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
+    args = ap.parse_args()
+    world, rank, local = init_dist(args.gpus)
+    if args.workload == "s2":
+        res, eng = run_s2(args, world, rank, local)
+        if not args.no_extras:
+            try:
+                from tools import bench_extras
+
+                res.update(bench_extras.s2_extras(args, eng, world, rank))
+            except Exception as e:  # the headline number must still be printed
+                res["extras_error"] = repr(e)
+    else:
+        from tools import bench_s1
+
+        res = bench_s1.run(args, world, rank, local)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

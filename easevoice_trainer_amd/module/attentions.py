@@ -1,0 +1,156 @@
+"""Relative-position transformer encoder of the s2 text/ssl encoders, channels-last.
+
+Mirrors (names, parameter keys and arithmetic) src/easevoice/module/attentions.py:12-90 (Encoder),
+:179-292 (MultiHeadAttention with window-4 relative position embeddings), :379-435 (FFN) of the
+reference.  Tensors are [B, T, C] here ([B, C, T] in the reference); masks are [B, T, 1].
+
+T <= a few hundred frames, so the attention itself stays on rocBLAS GEMMs through torch; the two
+k=3 FFN convolutions (most of this block's MACs) run on the fused HIP conv kernel.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..hip import lib as L
+from ..hip.conv import EvtConv1d
+
+
+class LayerNorm(nn.Module):
+    """modules.py:19-31 — LayerNorm over the channel axis (keys gamma/beta)."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x):
+        return F.layer_norm(x, (self.channels,), self.gamma, self.beta, self.eps)
+
+
+class PointwiseConv(nn.Module):
+    """nn.Conv1d(cin, cout, 1) parameters ([cout, cin, 1] weight) applied as a GEMM on [B, T, C]."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        c = nn.Conv1d(cin, cout, 1, bias=bias)
+        self.weight = c.weight
+        self.bias = c.bias
+
+    def forward(self, x):
+        return F.linear(x, self.weight.squeeze(-1), self.bias)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, channels, out_channels, n_heads, p_dropout=0.0, window_size=None, heads_share=True):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.channels, self.out_channels, self.n_heads = channels, out_channels, n_heads
+        self.p_dropout, self.window_size = p_dropout, window_size
+        self.k_channels = channels // n_heads
+        self.conv_q = PointwiseConv(channels, channels)
+        self.conv_k = PointwiseConv(channels, channels)
+        self.conv_v = PointwiseConv(channels, channels)
+        self.conv_o = PointwiseConv(channels, out_channels)
+        self.drop = nn.Dropout(p_dropout)
+        if window_size is not None:
+            n_heads_rel = 1 if heads_share else n_heads
+            std = self.k_channels ** -0.5
+            self.emb_rel_k = nn.Parameter(torch.randn(n_heads_rel, window_size * 2 + 1, self.k_channels) * std)
+            self.emb_rel_v = nn.Parameter(torch.randn(n_heads_rel, window_size * 2 + 1, self.k_channels) * std)
+        nn.init.xavier_uniform_(self.conv_q.weight)
+        nn.init.xavier_uniform_(self.conv_k.weight)
+        nn.init.xavier_uniform_(self.conv_v.weight)
+        self._band_cache = {}
+
+    def _band(self, length, device):
+        """index maps between absolute (i, j) and windowed-relative (i, r) positions, r = j - i + w"""
+        key = (length, str(device))
+        if key not in self._band_cache:
+            w = self.window_size
+            i = torch.arange(length, device=device)
+            rel = i[None, :] - i[:, None] + w                    # [l, l]  r for (i, j)
+            valid = (rel >= 0) & (rel <= 2 * w)
+            abs_idx = torch.where(valid, rel, torch.full_like(rel, 2 * w + 1))  # slot 2w+1 = zero column
+            r = torch.arange(2 * w + 1, device=device)
+            j = i[:, None] + r[None, :] - w                      # [l, 2w+1]  j for (i, r)
+            jvalid = (j >= 0) & (j < length)
+            self._band_cache[key] = (abs_idx, j.clamp(0, length - 1), jvalid)
+        return self._band_cache[key]
+
+    def forward(self, x, c, attn_mask=None):
+        """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend)"""
+        b, t_t, _ = x.shape
+        t_s = c.size(1)
+        h, d = self.n_heads, self.k_channels
+        q = self.conv_q(x).view(b, t_t, h, d).transpose(1, 2)    # [b, h, t, d]
+        k = self.conv_k(c).view(b, t_s, h, d).transpose(1, 2)
+        v = self.conv_v(c).view(b, t_s, h, d).transpose(1, 2)
+        qs = q / math.sqrt(d)
+        scores = torch.matmul(qs, k.transpose(-2, -1))
+        if self.window_size is not None:
+            assert t_s == t_t, "relative attention is only available for self-attention"
+            abs_idx, j_idx, jvalid = self._band(t_s, x.device)
+            # logits against the 2w+1 relative key embeddings, scattered onto the |i-j| <= w band
+            qe = torch.matmul(qs, self.emb_rel_k.unsqueeze(0).transpose(-2, -1))       # [b, h, l, 2w+1]
+            qe = F.pad(qe, (0, 1))
+            scores = scores + qe.gather(-1, abs_idx.expand(b, h, t_s, t_s))
+        if attn_mask is not None:
+            scores = scores.masked_fill(attn_mask == 0, -1e4)
+        p_attn = self.drop(F.softmax(scores, dim=-1))
+        out = torch.matmul(p_attn, v)
+        if self.window_size is not None:
+            relw = p_attn.gather(-1, j_idx.expand(b, h, t_s, -1)) * jvalid.to(p_attn.dtype)   # [b, h, l, 2w+1]
+            out = out + torch.matmul(relw, self.emb_rel_v.unsqueeze(0))
+        out = out.transpose(1, 2).reshape(b, t_t, h * d)
+        return self.conv_o(out)
+
+
+class FFN(nn.Module):
+    """conv(k) -> relu -> dropout -> conv(k), 'same' padding, masked (attentions.py:408-416); both convs
+    run on the fused HIP kernel, the relu is the first conv's epilogue."""
+
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0.0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.conv_1 = EvtConv1d(in_channels, filter_channels, kernel_size, padding=(kernel_size - 1) // 2)
+        self.conv_2 = EvtConv1d(filter_channels, out_channels, kernel_size, padding=(kernel_size - 1) // 2)
+        self.drop = nn.Dropout(p_dropout)
+
+    def forward(self, x, x_mask, cd):
+        x = self.conv_1((x * x_mask).to(cd).contiguous(), out_act=L.ACT_LRELU, out_slope=0.0)
+        x = self.drop(x)
+        x = self.conv_2((x * x_mask).to(cd).contiguous())
+        return x * x_mask
+
+
+class Encoder(nn.Module):
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0.0,
+                 window_size=4):
+        super().__init__()
+        self.hidden_channels, self.n_layers = hidden_channels, n_layers
+        self.drop = nn.Dropout(p_dropout)
+        self.attn_layers = nn.ModuleList()
+        self.norm_layers_1 = nn.ModuleList()
+        self.ffn_layers = nn.ModuleList()
+        self.norm_layers_2 = nn.ModuleList()
+        for _ in range(n_layers):
+            self.attn_layers.append(MultiHeadAttention(hidden_channels, hidden_channels, n_heads, p_dropout=p_dropout,
+                                                       window_size=window_size))
+            self.norm_layers_1.append(LayerNorm(hidden_channels))
+            self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size,
+                                       p_dropout=p_dropout))
+            self.norm_layers_2.append(LayerNorm(hidden_channels))
+
+    def forward(self, x, x_mask, cd):
+        """x [B, T, C], x_mask [B, T, 1]"""
+        attn_mask = (x_mask.transpose(1, 2).unsqueeze(2) * x_mask.unsqueeze(1))   # [B, 1, T, T]
+        x = x * x_mask
+        for i in range(self.n_layers):
+            y = self.drop(self.attn_layers[i](x, x, attn_mask))
+            x = self.norm_layers_1[i](x + y)
+            y = self.drop(self.ffn_layers[i](x, x_mask, cd))
+            x = self.norm_layers_2[i](x + y)
+        return x * x_mask

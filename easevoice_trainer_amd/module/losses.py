@@ -1,0 +1,90 @@
+"""GAN / feature / KL losses of the s2 step (src/easevoice/module/losses.py:7-61) as fused HIP
+reductions: one launch over a table of all (real, fake) feature-map pairs instead of 37 mean-abs
+kernels, one launch for the 6 LSGAN terms, and no `.item()` host syncs inside the step (the
+reference does 12 per step at losses.py:28-29)."""
+import ctypes as C
+
+import torch
+
+from ..hip import lib as L
+
+
+def _table(pairs, scales, grads, device):
+    segs = []
+    for (a, b), sc, da in zip(pairs, scales, grads):
+        segs.append(L.Seg(a.data_ptr(), b.data_ptr() if b is not None else None,
+                          da.data_ptr() if da is not None else None, a.numel(), sc, 0))
+    return L.struct_to_device(segs, device)
+
+
+class _SegLossFn(torch.autograd.Function):
+    """sum_i scale_i * reduce_i(a_i, b_i); mode 0 = sum|a-b| (b detached), mode 1 = sum (target-a)^2."""
+
+    @staticmethod
+    def forward(ctx, mode, target, scales, n_a, *tensors):
+        a_list, b_list = tensors[:n_a], tensors[n_a:]
+        a_list = [t.contiguous() for t in a_list]
+        b_list = [t.contiguous() for t in b_list] if mode == 0 else [None] * n_a
+        dev = a_list[0].device
+        dt = L.dt_of(a_list[0])
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        tab = _table(list(zip(a_list, b_list)), scales, [None] * n_a, dev)
+        fn = L.lib().evt_l1_multi_fwd if mode == 0 else L.lib().evt_lsgan_multi_fwd
+        if mode == 0:
+            L.check(fn(dt, L.ptr(tab), n_a, L.ptr(out), L.stream_ptr()), "evt_l1_multi_fwd")
+        else:
+            L.check(fn(dt, L.ptr(tab), n_a, C.c_float(target), L.ptr(out), L.stream_ptr()), "evt_lsgan_multi_fwd")
+        ctx.mode, ctx.target, ctx.scales, ctx.n_a, ctx.dt = mode, target, scales, n_a, dt
+        ctx.save_for_backward(*a_list, *[b for b in b_list if b is not None])
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        saved = ctx.saved_tensors
+        n_a = ctx.n_a
+        a_list = saved[:n_a]
+        b_list = saved[n_a:] if ctx.mode == 0 else [None] * n_a
+        dev = a_list[0].device
+        grads = [torch.empty_like(a) if ctx.needs_input_grad[4 + i] else None for i, a in enumerate(a_list)]
+        tab = _table(list(zip(a_list, b_list)), ctx.scales, grads, dev)
+        dl = dloss.reshape(1).float().contiguous()
+        if ctx.mode == 0:
+            L.check(L.lib().evt_l1_multi_bwd(ctx.dt, L.ptr(tab), n_a, L.ptr(dl), L.stream_ptr()), "evt_l1_multi_bwd")
+        else:
+            L.check(L.lib().evt_lsgan_multi_bwd(ctx.dt, L.ptr(tab), n_a, C.c_float(ctx.target), L.ptr(dl),
+                                                L.stream_ptr()), "evt_lsgan_multi_bwd")
+        return (None, None, None, None, *grads, *([None] * (len(saved) - n_a)))
+
+
+def feature_loss(fmap_r, fmap_g):
+    """losses.py:7-15: 2 * sum over all feature maps of mean|r - g| (r detached)."""
+    a, b, sc = [], [], []
+    for dr, dg in zip(fmap_r, fmap_g):
+        for rl, gl in zip(dr, dg):
+            a.append(gl)
+            b.append(rl.detach())
+            sc.append(2.0 / gl.numel())
+    return _SegLossFn.apply(0, 0.0, sc, len(a), *a, *b)
+
+
+def discriminator_loss(disc_real_outputs, disc_generated_outputs):
+    """losses.py:18-32: sum_i mean((1-dr_i)^2) + mean(dg_i^2).  Returns the scalar only (the per-term
+    python lists of the reference exist to be `.item()`-ed for logging, which this path avoids)."""
+    r = _SegLossFn.apply(1, 1.0, [1.0 / t.numel() for t in disc_real_outputs], len(disc_real_outputs),
+                         *disc_real_outputs)
+    g = _SegLossFn.apply(1, 0.0, [1.0 / t.numel() for t in disc_generated_outputs], len(disc_generated_outputs),
+                         *disc_generated_outputs)
+    return r + g
+
+
+def generator_loss(disc_outputs):
+    """losses.py:35-43: sum_i mean((1-dg_i)^2)."""
+    return _SegLossFn.apply(1, 1.0, [1.0 / t.numel() for t in disc_outputs], len(disc_outputs), *disc_outputs)
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
+    """losses.py:46-61 (layout-agnostic: any matching shapes, mask broadcastable)."""
+    z_p, logs_q, m_p, logs_p, z_mask = z_p.float(), logs_q.float(), m_p.float(), logs_p.float(), z_mask.float()
+    kl = logs_p - logs_q - 0.5
+    kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+    return torch.sum(kl * z_mask) / torch.sum(z_mask)

@@ -1,0 +1,611 @@
+"""s2 SoVITS generator (SynthesizerTrn) and discriminators (MultiPeriodDiscriminator), MI355X-native.
+
+Same class names, constructor arguments, parameter/buffer keys and arithmetic as the reference's
+src/easevoice/module/models.py:174-471,481-614,803-946 (+ modules.py:135-317,404-458,685-763,
+mrte_model.py:9-61, core_vq.py:172-228), re-laid-out for the hardware:
+
+  * every activation is channels-last [B, T, C] so the conv stacks are implicit GEMMs whose K index
+    (tap, channel) is contiguous in HBM/LDS; the reference's [B, C, T] only exists at the module boundary;
+  * every Conv1d / ConvTranspose1d / Conv2d((k,1)) is one fused HIP launch (hip/conv.py): leaky-relu
+    prologue, bias / activation / residual epilogues, weight-norm folded once per step for the whole model;
+  * 1x1 convolutions on [B, T, C] are plain GEMMs (hipBLASLt through F.linear);
+  * DiscriminatorP's period axis is laid out as extra sequences ([B*p, T/p, C]) instead of a 2-D image.
+
+There is no CPU / eager fallback: the modules need a WeightBank (hip/conv.py) and a GPU.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..hip import lib as L
+from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
+from . import commons
+from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv
+
+LRELU_SLOPE = 0.1
+N_SYMBOLS = 732  # len(SYMBOLS), src/easevoice/text/symbols.py:410-412 (pinned by tests/easevoice/text_test.py)
+
+
+def get_padding(kernel_size, dilation=1):
+    return (kernel_size * dilation - dilation) // 2
+
+
+class _ComputeDtype:
+    """mix-in: `self.cd` is the compute dtype of the fused conv kernels (set by runtime.attach)"""
+    cd = torch.float32
+
+
+# --------------------------------------------------------------------------------------------------
+# WN / posterior encoder / flow
+# --------------------------------------------------------------------------------------------------
+class WeightNormPointwise(nn.Module):
+    """weight-normed nn.Conv1d(cin, cout, 1) applied to a [B, C] vector (the WN cond_layer on ge)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        c = nn.Conv1d(cin, cout, 1)
+        self.bias = c.bias
+        self.weight_g = nn.Parameter(c.weight.detach().reshape(cout, -1).norm(dim=1).reshape(cout, 1, 1))
+        self.weight_v = nn.Parameter(c.weight.detach().clone())
+
+    def forward(self, g):
+        v = self.weight_v.squeeze(-1)
+        w = v * (self.weight_g.view(-1, 1) / v.norm(dim=1, keepdim=True))
+        return F.linear(g, w, self.bias)
+
+
+class WN(nn.Module, _ComputeDtype):
+    """modules.py:135-212.  in_layers (k=5) and res_skip_layers (1x1) are fused HIP convs, the gated
+    tanh*sigmoid with the conditioning add is one HIP element-wise launch."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.hidden_channels, self.n_layers, self.gin_channels = hidden_channels, n_layers, gin_channels
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        self.drop = nn.Dropout(p_dropout)
+        if gin_channels != 0:
+            self.cond_layer = WeightNormPointwise(gin_channels, 2 * hidden_channels * n_layers)
+        for i in range(n_layers):
+            dilation = dilation_rate ** i
+            self.in_layers.append(EvtConv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=dilation,
+                                            padding=(kernel_size * dilation - dilation) // 2, weight_norm=True))
+            rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(EvtConv1d(hidden_channels, rs, 1, weight_norm=True))
+
+    def forward(self, x, x_mask, g=None):
+        """x [B, T, H] (compute dtype), x_mask [B, T, 1], g [B, gin] or None"""
+        H = self.hidden_channels
+        output = None
+        if g is not None:
+            g = self.cond_layer(g).to(x.dtype)     # [B, 2*H*n_layers]
+        for i in range(self.n_layers):
+            x_in = self.in_layers[i](x)
+            g_l = g[:, i * 2 * H:(i + 1) * 2 * H].contiguous() if g is not None else None
+            acts = self.drop(GatedActFn.apply(x_in, g_l))
+            rs = self.res_skip_layers[i](acts)
+            if i < self.n_layers - 1:
+                x = ((x + rs[..., :H]) * x_mask).to(x.dtype).contiguous()
+                skip = rs[..., H:]
+            else:
+                skip = rs
+            output = skip if output is None else output + skip
+        return output * x_mask
+
+
+class PosteriorEncoder(nn.Module, _ComputeDtype):
+    """models.py:318-359."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                 gin_channels=0):
+        super().__init__()
+        self.out_channels = out_channels
+        self.pre = PointwiseConv(in_channels, hidden_channels)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.proj = PointwiseConv(hidden_channels, out_channels * 2)
+
+    def forward(self, x, x_mask, g=None, eps=None):
+        """x [B, T, spec] -> z, m, logs [B, T, out]; eps (the randn_like draw of models.py:358) may be injected"""
+        if g is not None:
+            g = g.detach()
+        h = (self.pre(x) * x_mask).to(self.cd).contiguous()
+        h = self.enc(h, x_mask, g=g)
+        stats = self.proj(h) * x_mask
+        m, logs = torch.split(stats.float(), self.out_channels, dim=-1)
+        if eps is None:
+            eps = torch.randn_like(m)
+        z = (m + eps * torch.exp(logs)) * x_mask
+        return z, m, logs
+
+
+class ResidualCouplingLayer(nn.Module, _ComputeDtype):
+    """modules.py:404-458 (mean_only coupling)."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0, gin_channels=0,
+                 mean_only=False):
+        super().__init__()
+        assert channels % 2 == 0
+        self.half_channels, self.mean_only = channels // 2, mean_only
+        self.pre = PointwiseConv(self.half_channels, hidden_channels)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=p_dropout,
+                      gin_channels=gin_channels)
+        self.post = PointwiseConv(hidden_channels, self.half_channels * (2 - mean_only))
+        self.post.weight.data.zero_()
+        self.post.bias.data.zero_()
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        x0, x1 = torch.split(x, [self.half_channels] * 2, dim=-1)
+        h = (self.pre(x0) * x_mask).to(self.cd).contiguous()
+        h = self.enc(h, x_mask, g=g)
+        stats = (self.post(h) * x_mask).float()
+        if not self.mean_only:
+            m, logs = torch.split(stats, [self.half_channels] * 2, dim=-1)
+        else:
+            m, logs = stats, torch.zeros_like(stats)
+        if not reverse:
+            x1 = m + x1 * torch.exp(logs) * x_mask
+        else:
+            x1 = (x1 - m) * torch.exp(-logs) * x_mask
+        return torch.cat([x0, x1], dim=-1)
+
+
+class Flip(nn.Module):
+    def forward(self, x, *args, **kwargs):
+        return torch.flip(x, [-1])
+
+
+class ResidualCouplingBlock(nn.Module):
+    """models.py:273-315."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0):
+        super().__init__()
+        self.flows = nn.ModuleList()
+        for _ in range(n_flows):
+            self.flows.append(ResidualCouplingLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                                                    gin_channels=gin_channels, mean_only=True))
+            self.flows.append(Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        flows = self.flows if not reverse else reversed(self.flows)
+        for flow in flows:
+            x = flow(x, x_mask, g=g, reverse=reverse)
+        return x
+
+
+# --------------------------------------------------------------------------------------------------
+# text / ssl encoder
+# --------------------------------------------------------------------------------------------------
+class MRTE(nn.Module):
+    """mrte_model.py:9-61."""
+
+    def __init__(self, content_enc_channels=192, hidden_size=512, out_channels=192, n_heads=4):
+        super().__init__()
+        self.cross_attention = MultiHeadAttention(hidden_size, hidden_size, n_heads)
+        self.c_pre = PointwiseConv(content_enc_channels, hidden_size)
+        self.text_pre = PointwiseConv(content_enc_channels, hidden_size)
+        self.c_post = PointwiseConv(hidden_size, out_channels)
+
+    def forward(self, ssl_enc, ssl_mask, text, text_mask, ge):
+        """ssl_enc [B, T, C], text [B, Tt, C], ge [B, 512] or None"""
+        attn_mask = text_mask.transpose(1, 2).unsqueeze(2) * ssl_mask.unsqueeze(1)   # [B, 1, T, Tt]
+        ssl_enc = self.c_pre(ssl_enc * ssl_mask)
+        text_enc = self.text_pre(text * text_mask)
+        x = self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, attn_mask) + ssl_enc
+        if ge is not None:
+            x = x + ge.unsqueeze(1)
+        return self.c_post(x * ssl_mask)
+
+
+class TextEncoder(nn.Module, _ComputeDtype):
+    """models.py:174-251."""
+
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                 latent_channels=192, version="v2"):
+        super().__init__()
+        self.out_channels = out_channels
+        self.ssl_proj = PointwiseConv(768, hidden_channels)
+        self.encoder_ssl = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
+        self.encoder_text = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.text_embedding = nn.Embedding(N_SYMBOLS, hidden_channels)
+        self.mrte = MRTE()
+        self.encoder2 = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
+        self.proj = PointwiseConv(hidden_channels, out_channels * 2)
+
+    def forward(self, y, y_mask, text, text_mask, ge):
+        """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]"""
+        y = self.ssl_proj(y * y_mask) * y_mask
+        y = self.encoder_ssl(y * y_mask, y_mask, self.cd)
+        t = self.text_embedding(text)
+        t = self.encoder_text(t * text_mask, text_mask, self.cd)
+        y = self.mrte(y, y_mask, t, text_mask, ge)
+        y = self.encoder2(y * y_mask, y_mask, self.cd)
+        stats = (self.proj(y) * y_mask).float()
+        m, logs = torch.split(stats, self.out_channels, dim=-1)
+        return y, m, logs
+
+
+# --------------------------------------------------------------------------------------------------
+# style encoder
+# --------------------------------------------------------------------------------------------------
+class LinearNorm(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.fc = nn.Linear(cin, cout, bias)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class Mish(nn.Module):
+    def forward(self, x):
+        return x * torch.tanh(F.softplus(x))
+
+
+class ConvNorm(nn.Module):
+    def __init__(self, cin, cout, kernel_size):
+        super().__init__()
+        self.conv = EvtConv1d(cin, cout, kernel_size, padding=(kernel_size - 1) // 2)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Conv1dGLU(nn.Module, _ComputeDtype):
+    """modules.py:548-566."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dropout):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv1 = ConvNorm(in_channels, 2 * out_channels, kernel_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        residual = x
+        h = self.conv1(x.to(self.cd).contiguous())
+        x1, x2 = torch.split(h, self.out_channels, dim=-1)
+        return residual + self.dropout(x1 * torch.sigmoid(x2))
+
+
+class StyleAttention(nn.Module):
+    """modules.py:605-682 (MultiHeadAttention + ScaledDotProductAttention of the style encoder)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.0):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        self.temperature = float(d_model) ** 0.5
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.attn_dropout = nn.Dropout(dropout)
+
+    def forward(self, x, mask=None):
+        """x [B, T, d_model]; mask [B, T, T] bool, True = masked"""
+        b, t, _ = x.shape
+        h = self.n_head
+        q = self.w_qs(x).view(b, t, h, self.d_k).transpose(1, 2)
+        k = self.w_ks(x).view(b, t, h, self.d_k).transpose(1, 2)
+        v = self.w_vs(x).view(b, t, h, self.d_v).transpose(1, 2)
+        attn = torch.matmul(q, k.transpose(-2, -1)) / self.temperature
+        if mask is not None:
+            attn = attn.masked_fill(mask.unsqueeze(1), float("-inf"))
+        attn = self.attn_dropout(F.softmax(attn, dim=-1))
+        out = torch.matmul(attn, v).transpose(1, 2).reshape(b, t, h * self.d_v)
+        return self.dropout(self.fc(out)) + x
+
+
+class MelStyleEncoder(nn.Module):
+    """modules.py:685-763."""
+
+    def __init__(self, n_mel_channels=80, style_hidden=128, style_vector_dim=256, style_kernel_size=5, style_head=2,
+                 dropout=0.1):
+        super().__init__()
+        self.spectral = nn.Sequential(LinearNorm(n_mel_channels, style_hidden), Mish(), nn.Dropout(dropout),
+                                      LinearNorm(style_hidden, style_hidden), Mish(), nn.Dropout(dropout))
+        self.temporal = nn.Sequential(Conv1dGLU(style_hidden, style_hidden, style_kernel_size, dropout),
+                                      Conv1dGLU(style_hidden, style_hidden, style_kernel_size, dropout))
+        self.slf_attn = StyleAttention(style_head, style_hidden, style_hidden // style_head,
+                                       style_hidden // style_head, dropout)
+        self.fc = LinearNorm(style_hidden, style_vector_dim)
+
+    def forward(self, x, x_mask):
+        """x [B, T, n_mel], x_mask [B, T, 1] -> [B, style_vector_dim]"""
+        pad = x_mask.squeeze(-1) == 0                     # [B, T] True = padding
+        attn_mask = pad.unsqueeze(1).expand(-1, x.size(1), -1)
+        x = self.spectral(x)
+        x = self.temporal(x)
+        x = x.masked_fill(pad.unsqueeze(-1), 0)
+        x = self.slf_attn(x, mask=attn_mask)
+        x = self.fc(x)
+        n = (~pad).sum(dim=1, keepdim=True)
+        return x.masked_fill(pad.unsqueeze(-1), 0).sum(dim=1) / n
+
+
+# --------------------------------------------------------------------------------------------------
+# frozen residual vector quantizer (n_q = 1), eval semantics only (models.py:912-926)
+# --------------------------------------------------------------------------------------------------
+class _Codebook(nn.Module):
+    def __init__(self, dim, codebook_size):
+        super().__init__()
+        self.register_buffer("inited", torch.Tensor([False]))   # kmeans_init=True in the reference
+        self.register_buffer("cluster_size", torch.zeros(codebook_size))
+        self.register_buffer("embed", torch.zeros(codebook_size, dim))
+        self.register_buffer("embed_avg", torch.zeros(codebook_size, dim))
+
+    def nearest(self, x):
+        """core_vq.py:172-180: argmax of -(|x|^2 - 2 x.e + |e|^2); x [N, D] fp32"""
+        e = self.embed.t()
+        dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
+        return dist.max(dim=-1).indices
+
+
+class _VQLayer(nn.Module):
+    def __init__(self, dim, codebook_size):
+        super().__init__()
+        self._codebook = _Codebook(dim, codebook_size)
+
+
+class _RVQ(nn.Module):
+    def __init__(self, dim, codebook_size, n_q):
+        super().__init__()
+        self.layers = nn.ModuleList([_VQLayer(dim, codebook_size) for _ in range(n_q)])
+
+
+class ResidualVectorQuantizer(nn.Module):
+    """quantize.py:29-94 / core_vq.py:95-357, inference path of the frozen quantizer: look-up only.
+    (The reference runs it in eval mode inside the training forward, so there is no EMA update, no
+    commitment loss and no gradient: models.py:912-921.)"""
+
+    def __init__(self, dimension=256, n_q=8, bins=1024):
+        super().__init__()
+        self.n_q, self.dimension, self.bins = n_q, dimension, bins
+        self.vq = _RVQ(dimension, bins, n_q)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x [B, T, D] fp32 -> (quantized [B, T, D], codes [1, B, T])"""
+        cb = self.vq.layers[0]._codebook
+        if not bool(cb.inited.item() if cb.inited.device.type == "cpu" else cb.inited.cpu().item()):
+            raise L.EvtError("quantizer codebook is not initialised: load pretrained weights "
+                             "(the reference would run k-means on the first batch, core_vq.py:140-149)")
+        b, t, d = x.shape
+        ind = cb.nearest(x.reshape(b * t, d).float())
+        q = F.embedding(ind, cb.embed).view(b, t, d)
+        return q, ind.view(1, b, t)
+
+
+# --------------------------------------------------------------------------------------------------
+# HiFi-GAN generator
+# --------------------------------------------------------------------------------------------------
+class ResBlock1(nn.Module):
+    """modules.py:223-317: three (dilated conv, conv) pairs with residuals, each pair = one ResUnitFn."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.convs1 = nn.ModuleList([
+            EvtConv1d(channels, channels, kernel_size, dilation=d, padding=get_padding(kernel_size, d), weight_norm=True)
+            for d in dilation])
+        self.convs2 = nn.ModuleList([
+            EvtConv1d(channels, channels, kernel_size, dilation=1, padding=get_padding(kernel_size, 1), weight_norm=True)
+            for _ in dilation])
+
+    def forward(self, x):
+        for c1, c2 in zip(self.convs1, self.convs2):
+            x = res_unit(x, c1, c2, LRELU_SLOPE)
+        return x
+
+
+class Generator(nn.Module, _ComputeDtype):
+    """models.py:404-471."""
+
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+        super().__init__()
+        if str(resblock) != "1":
+            raise L.EvtError("only ResBlock1 (configs/s2.json resblock='1') is implemented")
+        self.num_kernels, self.num_upsamples = len(resblock_kernel_sizes), len(upsample_rates)
+        self.conv_pre = EvtConv1d(initial_channel, upsample_initial_channel, 7, padding=3)
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            self.ups.append(EvtConv1d(upsample_initial_channel // (2 ** i), upsample_initial_channel // (2 ** (i + 1)),
+                                      k, stride=u, padding=(k - u) // 2, transposed=True, weight_norm=True))
+        self.resblocks = nn.ModuleList()
+        ch = upsample_initial_channel
+        for i in range(len(self.ups)):
+            ch = upsample_initial_channel // (2 ** (i + 1))
+            for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+                self.resblocks.append(ResBlock1(ch, k, tuple(d)))
+        self.conv_post = EvtConv1d(ch, 1, 7, padding=3, bias=False)
+        if gin_channels != 0:
+            self.cond = PointwiseConv(gin_channels, upsample_initial_channel)
+
+    def forward(self, x, g=None):
+        """x [B, T, inter] -> waveform [B, T*prod(up), 1]"""
+        x = self.conv_pre(x.to(self.cd).contiguous())
+        if g is not None:
+            x = (x + self.cond(g).unsqueeze(1)).to(self.cd)
+        for i in range(self.num_upsamples):
+            x = self.ups[i](x, in_slope=LRELU_SLOPE)          # leaky_relu(0.1) fused on load
+            rs = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
+            while len(rs) < 3:
+                rs.append(None)
+            x = Add3ScaleFn.apply(rs[0], rs[1], rs[2], 1.0 / self.num_kernels)
+        # F.leaky_relu(x) at models.py:467 uses the DEFAULT slope 0.01, then conv_post, then tanh
+        return self.conv_post(x, in_slope=0.01, out_act=L.ACT_TANH)
+
+
+# --------------------------------------------------------------------------------------------------
+# discriminators
+# --------------------------------------------------------------------------------------------------
+class DiscriminatorP(nn.Module, _ComputeDtype):
+    """models.py:481-557.  [B, T] -> reflect-pad to a multiple of p -> p interleaved sequences of
+    length T/p each; Conv2d((k,1),(s,1)) == Conv1d over each of the B*p sequences."""
+
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise L.EvtError("spectral_norm discriminators are not used by configs/s2.json")
+        self.period = period
+        chans = [1, 32, 128, 512, 1024, 1024]
+        self.convs = nn.ModuleList([
+            EvtConv1d(chans[i], chans[i + 1], kernel_size, stride=(stride if i < 4 else 1),
+                      padding=get_padding(kernel_size, 1), weight_norm=True, kdims=2) for i in range(5)])
+        self.conv_post = EvtConv1d(1024, 1, 3, padding=1, weight_norm=True, kdims=2)
+
+    def forward(self, x):
+        """x [N, T] fp32 waveform -> (logits [N, p*H'] , fmaps list of [N*p, H_i, C_i])"""
+        n, t = x.shape
+        p = self.period
+        if t % p != 0:
+            x = F.pad(x.unsqueeze(1), (0, p - (t % p)), "reflect").squeeze(1)
+            t = x.size(1)
+        x = x.view(n, t // p, p).transpose(1, 2).reshape(n * p, t // p, 1).to(self.cd).contiguous()
+        fmap = []
+        for l in self.convs:
+            x = l(x, out_act=L.ACT_LRELU, out_slope=LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return x.view(n, -1), fmap
+
+
+class DiscriminatorS(nn.Module, _ComputeDtype):
+    """models.py:560-587."""
+
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise L.EvtError("spectral_norm discriminators are not used by configs/s2.json")
+        spec = [(1, 16, 15, 1, 1, 7), (16, 64, 41, 4, 4, 20), (64, 256, 41, 4, 16, 20), (256, 1024, 41, 4, 64, 20),
+                (1024, 1024, 41, 4, 256, 20), (1024, 1024, 5, 1, 1, 2)]
+        self.convs = nn.ModuleList([EvtConv1d(ci, co, k, stride=s, groups=g, padding=p, weight_norm=True)
+                                    for ci, co, k, s, g, p in spec])
+        self.conv_post = EvtConv1d(1024, 1, 3, padding=1, weight_norm=True)
+
+    def forward(self, x):
+        x = x.unsqueeze(-1).to(self.cd).contiguous()
+        fmap = []
+        for l in self.convs:
+            x = l(x, out_act=L.ACT_LRELU, out_slope=LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return x.view(x.size(0), -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    """models.py:590-614.  `forward(y, y_hat)` keeps the reference's return structure
+    (y_d_rs, y_d_gs, fmap_rs, fmap_gs); real and generated audio are batched through each
+    sub-discriminator in ONE pass (same weights, twice the sequences)."""
+
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        periods = [2, 3, 5, 7, 11]
+        self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm)] +
+                                            [DiscriminatorP(p, use_spectral_norm=use_spectral_norm) for p in periods])
+
+    def forward_single(self, y):
+        """y [N, 1, T] or [N, T] -> (logits list, fmaps list-of-lists)"""
+        y = y.reshape(y.size(0), -1).float()
+        outs, fmaps = [], []
+        for d in self.discriminators:
+            o, f = d(y)
+            outs.append(o)
+            fmaps.append(f)
+        return outs, fmaps
+
+    def forward(self, y, y_hat):
+        n = y.size(0)
+        both = torch.cat([y.reshape(n, -1).float(), y_hat.reshape(n, -1).float()], dim=0)
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            o, f = d(both)
+            y_d_rs.append(o[:n])
+            y_d_gs.append(o[n:])
+            # sequences are ordered (item, period-phase): the first half of every fmap is the real audio
+            fmap_rs.append([t[: t.size(0) // 2] for t in f])
+            fmap_gs.append([t[t.size(0) // 2:] for t in f])
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+# --------------------------------------------------------------------------------------------------
+# SynthesizerTrn
+# --------------------------------------------------------------------------------------------------
+class SynthesizerTrn(nn.Module, _ComputeDtype):
+    """Synthesizer for training, models.py:803-946.  Inputs/outputs use the reference's [B, C, T]
+    layout; everything in between is channels-last."""
+
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0,
+                 use_sdp=True, semantic_frame_rate=None, freeze_quantizer=None, version="v2", **kwargs):
+        super().__init__()
+        self.spec_channels, self.segment_size, self.inter_channels = spec_channels, segment_size, inter_channels
+        self.gin_channels, self.version = gin_channels, version
+        self.enc_p = TextEncoder(inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
+                                 p_dropout, version=version)
+        self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                             upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.enc_q = PosteriorEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16,
+                                      gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 4, gin_channels=gin_channels)
+        self.ref_enc = MelStyleEncoder(spec_channels if version == "v1" else 704, style_vector_dim=gin_channels)
+        ssl_dim = 768
+        assert semantic_frame_rate in ["25hz", "50hz"]
+        self.semantic_frame_rate = semantic_frame_rate
+        if semantic_frame_rate == "25hz":
+            self.ssl_proj = nn.Conv1d(ssl_dim, ssl_dim, 2, stride=2)
+        else:
+            self.ssl_proj = nn.Conv1d(ssl_dim, ssl_dim, 1, stride=1)
+        self.quantizer = ResidualVectorQuantizer(dimension=ssl_dim, n_q=1, bins=1024)
+        self.freeze_quantizer = freeze_quantizer
+
+    def _quantize(self, ssl_cl):
+        """ssl_proj (fp32, no grad reaches it: models.py:912-921) + code look-up + x2 nearest upsample"""
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            b, t, c = ssl_cl.shape
+            w = self.ssl_proj.weight.float()
+            if self.semantic_frame_rate == "25hz":
+                t2 = t // 2
+                xr = ssl_cl[:, : 2 * t2].float().reshape(b, t2, 2 * c)
+                h = F.linear(xr, w.permute(0, 2, 1).reshape(w.size(0), 2 * c), self.ssl_proj.bias.float())
+            else:
+                h = F.linear(ssl_cl.float(), w.squeeze(-1), self.ssl_proj.bias.float())
+            q, codes = self.quantizer(h)
+            if self.semantic_frame_rate == "25hz":
+                q = q.repeat_interleave(2, dim=1)
+        return q, codes
+
+    def forward(self, ssl, y, y_lengths, text, text_lengths, eps=None, ids_slice=None):
+        """ssl [B, 768, T], y [B, spec, T] linear spectrogram, text [B, Tt] -> same tuple as the reference:
+        (o [B,1,seg*hop], commit_loss, ids_slice, y_mask, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized).
+        `eps` ([B, inter, T]) and `ids_slice` ([B]) inject the two random draws (models.py:358, commons.py:55)
+        for deterministic parity runs."""
+        dev = y.device
+        T = y.size(2)
+        y_mask = commons.sequence_mask(y_lengths, T).unsqueeze(-1).to(torch.float32)        # [B, T, 1]
+        text_mask = commons.sequence_mask(text_lengths, text.size(1)).unsqueeze(-1).to(torch.float32)
+        y_cl = y.transpose(1, 2)                                                               # [B, T, spec]
+        amp = self.cd == torch.bfloat16
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            ref_in = y_cl if self.version == "v1" else y_cl[..., :704]
+            ge = self.ref_enc(ref_in * y_mask, y_mask)                                         # [B, gin]
+            quantized, _codes = self._quantize(ssl.transpose(1, 2))
+            x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge)
+            eps_cl = eps.transpose(1, 2) if eps is not None else None
+            z, m_q, logs_q = self.enc_q(y_cl, y_mask, g=ge, eps=eps_cl)
+            z_p = self.flow(z, y_mask, g=ge)
+            if ids_slice is None:
+                z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
+            else:
+                z_slice = commons.slice_segments(z, ids_slice, self.segment_size)
+            o = self.dec(z_slice, g=ge)                                                        # [B, seg*hop, 1]
+        commit_loss = torch.zeros((), device=dev)   # quantizer in eval mode: core_vq.py:311-316 adds nothing
+        tr = lambda t: t.transpose(1, 2)
+        y_mask_ncl = y_mask.transpose(1, 2)
+        return (o.transpose(1, 2), commit_loss, ids_slice, y_mask_ncl, y_mask_ncl,
+                (tr(z), tr(z_p), tr(m_p), tr(logs_p), tr(m_q), tr(logs_q)), tr(quantized))

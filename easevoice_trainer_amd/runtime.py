@@ -1,0 +1,170 @@
+"""Device-side runtime of a model: flat fp32 parameter / gradient / optimiser-state arenas sized for one
+288 GB HBM3E device, the prepared-weight bank, and the flat AdamW step.
+
+Why flat arenas (MI355X-first, not how the reference does it): the reference holds ~900 separate tensors per
+model and runs torch.optim.AdamW's per-tensor loops plus a python grad-norm with one `.item()` host sync per
+parameter (commons.py:140-155).  Here one launch updates the whole model, one launch computes the grad norm,
+one memset zeroes the gradients, and the data-parallel all-reduce (dist.py) works on a few large contiguous
+buckets that keep the 7 xGMI links busy instead of hundreds of small messages.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .hip import lib as L
+from .hip.conv import WeightBank
+
+_ALIGN = 64  # floats: every parameter starts on a 256-byte boundary
+
+
+class ParamArena:
+    """Moves every parameter of `model` into one contiguous fp32 buffer (views keep their names/shapes, so
+    state_dict()/load_state_dict() are unchanged) and gives each a `.grad` view into a matching grad buffer."""
+
+    def __init__(self, model: nn.Module, device):
+        self.device = torch.device(device)
+        params = [(n, p) for n, p in model.named_parameters()]
+        offs, total = {}, 0
+        for n, p in params:
+            offs[n] = total
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.param = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.offsets = offs
+        self.names = [n for n, _ in params]
+        for n, p in params:
+            o = offs[n]
+            view = self.param[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data.to(self.device, torch.float32))
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.model = model
+
+    def range_of(self, name, numel):
+        o = self.offsets[name]
+        return o, o + numel
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (src/train/sovits.py:294-319: lr, betas, eps, weight_decay=0.01 default,
+    per-group learning rates) over a ParamArena: ONE launch per step.  Parameters listed in `frozen` (no
+    gradient in the reference, e.g. ssl_proj: models.py:912-921) are skipped exactly as AdamW skips
+    `grad is None` parameters."""
+
+    def __init__(self, arena: ParamArena, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        """groups: list of dict(names=[param names], lr=float)"""
+        self.arena, self.betas, self.eps, self.weight_decay = arena, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(arena.param)
+        self.exp_avg_sq = torch.zeros_like(arena.param)
+        self.step_count = 0
+        self.groups = []
+        named = dict(arena.model.named_parameters())
+        for g in groups:
+            ranges = sorted(arena.range_of(n, named[n].numel()) for n in g["names"])
+            merged = []
+            for b, e in ranges:
+                e_al = (e + _ALIGN - 1) // _ALIGN * _ALIGN
+                if merged and merged[-1][1] == b:
+                    merged[-1][1] = e_al
+                else:
+                    merged.append([b, e_al])
+            self.groups.append(dict(lr=g["lr"], initial_lr=g["lr"], ranges=merged, names=list(g["names"])))
+        self._table = None
+        self._table_lrs = None
+
+    @property
+    def param_groups(self):
+        return self.groups
+
+    def _segments(self):
+        lrs = tuple(g["lr"] for g in self.groups)
+        if self._table is None or lrs != self._table_lrs:
+            segs = []
+            for g in self.groups:
+                for b, e in g["ranges"]:
+                    segs.append(L.AdamWSeg(b, e, g["lr"], self.weight_decay))
+            if len(segs) > 64:
+                raise L.EvtError(f"{len(segs)} AdamW segments (max 64): register parameters group-contiguously")
+            self._table = L.struct_to_device(segs, self.arena.device)
+            self._nseg = len(segs)
+            self._table_lrs = lrs
+        return self._table, self._nseg
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        tab, nseg = self._segments()
+        a = self.arena
+        L.check(L.lib().evt_adamw_flat(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                       C.c_int64(a.numel), L.ptr(tab), nseg, C.c_float(self.betas[0]),
+                                       C.c_float(self.betas[1]), C.c_float(self.eps), self.step_count,
+                                       C.c_float(grad_scale), L.stream_ptr()), "evt_adamw_flat")
+
+    # ---- torch.optim-compatible checkpoint surface (src/utils/path/ckpt.py:78-93 stores optimizer.state_dict()) ----
+    def state_dict(self):
+        named = dict(self.arena.model.named_parameters())
+        state, idx, pgroups = {}, 0, []
+        for g in self.groups:
+            ids = []
+            for n in g["names"]:
+                b, e = self.arena.range_of(n, named[n].numel())
+                state[idx] = dict(step=torch.tensor(float(self.step_count)),
+                                  exp_avg=self.exp_avg[b:e].view(named[n].shape).clone(),
+                                  exp_avg_sq=self.exp_avg_sq[b:e].view(named[n].shape).clone())
+                ids.append(idx)
+                idx += 1
+            pgroups.append(dict(lr=g["lr"], initial_lr=g["initial_lr"], betas=self.betas, eps=self.eps,
+                                weight_decay=self.weight_decay, amsgrad=False, params=ids))
+        return dict(state=state, param_groups=pgroups)
+
+    def load_state_dict(self, sd):
+        named = dict(self.arena.model.named_parameters())
+        idx = 0
+        for g, pg in zip(self.groups, sd["param_groups"]):
+            g["lr"] = pg["lr"]
+            g["initial_lr"] = pg.get("initial_lr", pg["lr"])
+            for n in g["names"]:
+                st = sd["state"].get(idx)
+                if st is not None:
+                    b, e = self.arena.range_of(n, named[n].numel())
+                    self.exp_avg[b:e].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[b:e].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.step_count = max(self.step_count, int(float(st["step"])))
+                idx += 1
+
+
+class ModelRuntime:
+    """arena + weight bank for one nn.Module; `prepare()` before a forward, `finish_grads()` after backward."""
+
+    def __init__(self, model: nn.Module, dtype=torch.float32, device="cuda:0", impl=L.IMPL_AUTO):
+        L.lib()  # fail loudly before touching the device if the extension is missing
+        self.model, self.dtype, self.device = model, dtype, torch.device(device)
+        model.to(self.device)
+        self.arena = ParamArena(model, self.device)
+        self.bank = WeightBank(model, dtype, self.device, impl=impl)
+        self.bank.build_tables()
+        for m in model.modules():
+            if hasattr(m, "cd"):
+                m.cd = dtype
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+        self.bank.zero_dw()
+
+    def prepare(self):
+        self.bank.fold()
+
+    def finish_grads(self):
+        self.bank.grads()
+
+    def grad_sumsq(self):
+        """sum of squares of all gradients, as a device scalar (no host sync)"""
+        self._sumsq.zero_()
+        L.check(L.lib().evt_sumsq(L.ptr(self.arena.grad), C.c_int64(self.arena.numel), L.ptr(self._sumsq),
+                                  L.stream_ptr()), "evt_sumsq")
+        return self._sumsq
