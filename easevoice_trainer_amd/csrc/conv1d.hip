@@ -20,6 +20,14 @@
 #include "evt_common.h"
 #include "../../include/evt.h"
 
+extern "C" int evt_grouped_supported(const evt_conv1d_params* c);
+extern "C" int evt_grouped_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
+                               void* stream);
+extern "C" int evt_grouped_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
+                                    void* dx, void* stream);
+extern "C" int evt_grouped_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y,
+                                      float* dw, void* stream);
+
 namespace {
 
 struct ConvP {
@@ -707,6 +715,10 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   const int lout = evt_conv1d_lout(c);
   evt_wlayout l; evt_conv1d_layout(c, &l);
+  if (c->impl != EVT_IMPL_NAIVE && !res && evt_grouped_supported(c)) {
+    if (!w_reg) return EVT_EINVAL;
+    return evt_grouped_fwd(c, x, w_reg, bias, y, stream);
+  }
   if (!use_igemm) {
     if (!w_reg) return EVT_EINVAL;
     NvP p = make_nvp(c);
@@ -759,6 +771,10 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
   evt_wlayout l; evt_conv1d_layout(c, &l);
   const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
   const void* gate = c->in_slope != 1.f ? x : nullptr;
+  if (c->impl != EVT_IMPL_NAIVE && !gate && !dx_add && evt_grouped_supported(c)) {
+    if (!w_reg) return EVT_EINVAL;
+    return evt_grouped_bwd_data(c, dy, y, w_reg, dx, stream);
+  }
   if (!use_igemm) {
     if (!w_reg) return EVT_EINVAL;
     NvP p = make_nvp(c);
@@ -822,6 +838,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     rc = evt_check_launch();
     if (rc) return rc;
   }
+  if (c->impl != EVT_IMPL_NAIVE && evt_grouped_supported(c)) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
   const bool use_igemm = c->impl != EVT_IMPL_NAIVE && igemm_ok(c) && l.reg_kp <= 64;
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   if (!use_igemm) {

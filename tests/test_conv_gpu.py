@@ -43,6 +43,9 @@ CASES = [
     (1, 16, 15, 1, 7, 1, 1, False, True, 120, 2),
     (64, 1, 3, 1, 1, 1, 1, False, True, 40, 3),
     (16, 64, 41, 4, 20, 1, 4, False, True, 300, 2),
+    (64, 256, 41, 4, 20, 1, 16, False, True, 1000, 3),
+    (256, 1024, 41, 4, 20, 1, 64, False, True, 130, 2),
+    (1024, 1024, 41, 4, 20, 1, 256, False, True, 90, 2),
 ]
 FUSIONS = [
     dict(in_slope=1.0, out_act=0, out_slope=1.0, res=False),
