@@ -247,6 +247,7 @@ struct WgP {
   float aact_slope, bact_slope;
   int nsplit;
   int ntapgrp;
+  float* dbias;       // optional: += column sums of A_eff (only valid when A is dy)
 };
 
 template <typename T> union FragBuf;
@@ -369,6 +370,168 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient, v2.  Same GEMM view as conv_wgrad (M = A channels, N = B channels, K = positions) but
+//   * tiles are staged with 16-byte loads and kept position-major ([pos][channel]) in LDS;
+//   * MFMA fragments (8 consecutive positions of one channel) come from ds_read_b64_tr_b16, the gfx950 LDS
+//     transpose read: inside a 16-lane group lane j supplies the address of 4 contiguous elements of row (j>>2),
+//     columns 4*(j&3).., and lane i receives column i of that 4x16 block (semantics checked on hardware with
+//     tools/probe_tr.hip).  The row address is per lane, so strided / tap-shifted rows cost nothing;
+//   * for TA < 64 output-channel tiles the spare waves split the positions instead of idling;
+//   * dbias (column sums of dy_eff) is accumulated from the staged A tile by the (chunk 0, tap group 0) blocks.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 lds_tr2(const bf16_t* p0, const bf16_t* p1) {
+  const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1;
+  uint2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(a0), "v"(a1)
+               : "memory");
+  union { uint4 u; bf16x8 v; } r;
+  r.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return r.v;
+}
+
+template <int CK, int TA>
+__global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
+  typedef bf16_t T;
+  constexpr int KT = 4;
+  constexpr int NCT = TA / 16;   // waves along the A channels
+  constexpr int NPS = 4 / NCT;   // waves along the positions
+  constexpr int PK = 64 * NPS;   // positions staged per iteration (each wave: 64 = 2 MFMA k-steps)
+  constexpr int NTB = CK / 16;
+  constexpr int PA = TA + 8, PB = CK + 8;  // LDS pitches in elements (16-byte aligned rows)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j16 = lane & 15, g8 = lane >> 4;
+  const int ct = wave % NCT, ps = wave / NCT;
+
+  int bx = blockIdx.x;
+  const int tgi = bx % p.ntapgrp; bx /= p.ntapgrp;
+  const int ch = bx % p.nchunk;
+  const int atile = bx / p.nchunk;
+  const int t0 = tgi * KT;
+  const int ntap = min(KT, p.KHp - t0);
+  const int a0 = atile * TA;
+  const int BR = (PK - 1) * p.s + (KT - 1) * p.dil + 1;
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + PK * PA;
+
+  f32x4 acc[KT][NTB];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0;
+  const int bcol = tid % TA, brow = tid / TA;   // dbias: thread sums column bcol over rows brow, brow + 256/TA, ...
+  float bsum = 0.f;
+
+  const int UQ = (p.Q + PK - 1) / PK;
+  const long total = (long)p.nseq * UQ;
+  const T* Ag0 = reinterpret_cast<const T*>(p.A);
+  const T* Aa0 = reinterpret_cast<const T*>(p.Aact);
+  const T* Bg0 = reinterpret_cast<const T*>(p.B);
+  const T* Ba0 = reinterpret_cast<const T*>(p.Bact);
+
+  for (long it = blockIdx.y; it < total; it += p.nsplit) {
+    const int seq = (int)(it / UQ);
+    const int q0 = (int)(it % UQ) * PK;
+    __syncthreads();
+    for (int idx = tid; idx < PK * (TA / 8); idx += 256) {
+      const int r = idx / (TA / 8), c8 = idx - r * (TA / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q0 + r < p.Q) {
+        const long off = ((long)seq * p.LA + q0 + r) * p.CA + a0 + c8 * 8;
+        v = *reinterpret_cast<const uint4*>(Ag0 + off);
+        uint4 va = make_uint4(0, 0, 0, 0);
+        if (Aa0) va = *reinterpret_cast<const uint4*>(Aa0 + off);
+        v = fuse_load16<T>(v, Aa0 != nullptr, va, p.aact_kind, p.aact_slope, p.a_slope);
+      }
+      *reinterpret_cast<uint4*>(As + r * PA + c8 * 8) = v;
+    }
+    const int brow0 = q0 * p.s + t0 * p.dil + p.off;
+    for (int idx = tid; idx < BR * (CK / 8); idx += 256) {
+      const int r = idx / (CK / 8), c8 = idx - r * (CK / 8);
+      const int row = brow0 + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row >= 0 && row < p.LB) {
+        const long off = ((long)seq * p.LB + row) * p.CB + ch * CK + c8 * 8;
+        v = *reinterpret_cast<const uint4*>(Bg0 + off);
+        uint4 va = make_uint4(0, 0, 0, 0);
+        if (Ba0) va = *reinterpret_cast<const uint4*>(Ba0 + off);
+        v = fuse_load16<T>(v, Ba0 != nullptr, va, p.bact_kind, p.bact_slope, p.b_slope);
+      }
+      *reinterpret_cast<uint4*>(Bs + r * PB + c8 * 8) = v;
+    }
+    __syncthreads();
+    if (do_bias)
+      for (int r = brow; r < PK; r += 256 / TA) bsum += bf2f(As[r * PA + bcol]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kb = ps * 64 + ks * 32 + g8 * 8;  // first of this lane group's 8 positions
+      const T* pa = As + (kb + (j16 >> 2)) * PA + ct * 16 + 4 * (j16 & 3);
+      const bf16x8 a = lds_tr2(pa, pa + 4 * PA);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        if (t < ntap) {
+          const T* pb = Bs + ((kb + (j16 >> 2)) * p.s + t * p.dil) * PB + 4 * (j16 & 3);
+#pragma unroll
+          for (int j = 0; j < NTB; ++j) {
+            const bf16x8 b = lds_tr2(pb + j * 16, pb + j * 16 + 4 * p.s * PB);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (t >= ntap) continue;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + ct * 16 + g8 * 4 + r;
+        const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * CK + j * 16 + j16;
+        atomicAdd(p.dw + off, acc[t][j][r]);
+      }
+    }
+  }
+  if (do_bias) atomicAdd(p.dbias + a0 + bcol, bsum);
+}
+
+// dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last; per-block LDS accumulation, 16-byte loads
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_act2(const T* dy, const T* ys, float* out, long rows, int C, int kind,
+                                                   float slope, int rows_per_block) {
+  __shared__ float acc[1024];
+  constexpr int V = 16 / sizeof(T);
+  for (int c = threadIdx.x; c < C; c += 256) acc[c] = 0.f;
+  __syncthreads();
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  const long n = (r1 - r0) * C / V;   // C % V == 0 guaranteed by the launcher
+  const T* base = dy + r0 * C;
+  const T* ybase = ys ? ys + r0 * C : nullptr;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + i * V);
+    uint4 va = make_uint4(0, 0, 0, 0);
+    if (ybase) va = *reinterpret_cast<const uint4*>(ybase + i * V);
+    const T* pv = reinterpret_cast<const T*>(&v);
+    const T* pa = reinterpret_cast<const T*>(&va);
+    const int c0 = (int)((i * V) % C);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float d = to_f<T>(pv[e]);
+      if (ybase) d *= dact_from_out(kind, to_f<T>(pa[e]), slope);
+      atomicAdd(&acc[c0 + e], d);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(out + c, acc[c]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,6 +795,49 @@ int launch_wgrad_inst(const WgP& p, hipStream_t st) {
   return evt_check_launch();
 }
 
+template <int CK, int TA>
+int launch_wgrad_tr_inst(const WgP& p, hipStream_t st) {
+  constexpr int PK = 64 * (4 / (TA / 16));
+  const int BR = (PK - 1) * p.s + 3 * p.dil + 1;
+  const size_t lds = ((size_t)PK * (TA + 8) + (size_t)BR * (CK + 8)) * 2;
+  if (lds > 150 * 1024) return EVT_ENOTSUP;
+  static bool attr = false;
+  if (lds > 48 * 1024 && !attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr<CK, TA>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  const int gx = (p.CA / TA) * p.nchunk * p.ntapgrp;
+  hipLaunchKernelGGL((conv_wgrad_tr<CK, TA>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
+  return evt_check_launch();
+}
+
+// bf16 only; returns ENOTSUP when the tile does not fit so the caller can use the gather kernel
+int launch_wgrad_tr(WgP p, hipStream_t st) {
+  if (p.CB % 16 || p.CA % 16) return EVT_ENOTSUP;
+  const int CK = (p.CB % 32 == 0) ? 32 : 16;
+  const int TA = (p.CA % 64 == 0) ? 64 : (p.CA % 32 == 0 ? 32 : 16);
+  const int PK = 64 * (4 / (TA / 16));
+  p.nchunk = p.CB / CK;
+  p.ntapgrp = ceil_div(p.KHp, 4);
+  const long iters = (long)p.nseq * ceil_div(p.Q, PK);
+  const long tiles = (long)(p.CA / TA) * p.nchunk * p.ntapgrp;
+  long split = (1024 + tiles - 1) / tiles;
+  if (split > iters) split = iters;
+  if (split < 1) split = 1;
+  if (split > 65535) split = 65535;
+  p.nsplit = (int)split;
+  if (CK == 32) {
+    if (TA == 64) return launch_wgrad_tr_inst<32, 64>(p, st);
+    if (TA == 32) return launch_wgrad_tr_inst<32, 32>(p, st);
+    return launch_wgrad_tr_inst<32, 16>(p, st);
+  }
+  if (TA == 64) return launch_wgrad_tr_inst<16, 64>(p, st);
+  if (TA == 32) return launch_wgrad_tr_inst<16, 32>(p, st);
+  return launch_wgrad_tr_inst<16, 16>(p, st);
+}
+
 int launch_wgrad(int dtype, WgP p, hipStream_t st) {
   if (p.CB % 16) return EVT_ENOTSUP;
   const int CK = (p.CB % 32 == 0) ? 32 : 16;
@@ -825,21 +1031,38 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   const int lout = evt_conv1d_lout(c);
   const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
   evt_wlayout l; evt_conv1d_layout(c, &l);
-  if (dbias) {
+  const bool grouped = c->impl != EVT_IMPL_NAIVE && evt_grouped_supported(c);
+  const bool igemm_path = !grouped && c->impl != EVT_IMPL_NAIVE && igemm_ok(c) && l.reg_kp <= 64;
+  // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
+  const bool fuse_bias = dbias && igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed;
+  if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
-    const int rpb = 64;
-    const int blocks = (int)((rows + rpb - 1) / rpb);
-    if (c->dtype == EVT_DT_BF16)
-      hipLaunchKernelGGL(colsum_act<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
-                         dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
-    else
-      hipLaunchKernelGGL(colsum_act<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv, dbias,
-                         rows, c->cout, c->out_act, c->out_slope, rpb);
+    const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+    if (c->cout % V == 0 && c->cout <= 1024) {
+      long rpb = (rows + 1023) / 1024;
+      if (rpb < 16) rpb = 16;
+      const int blocks = (int)((rows + rpb - 1) / rpb);
+      if (c->dtype == EVT_DT_BF16)
+        hipLaunchKernelGGL(colsum_act2<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
+                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb);
+      else
+        hipLaunchKernelGGL(colsum_act2<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
+                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb);
+    } else {
+      const int rpb = 64;
+      const int blocks = (int)((rows + rpb - 1) / rpb);
+      if (c->dtype == EVT_DT_BF16)
+        hipLaunchKernelGGL(colsum_act<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
+                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
+      else
+        hipLaunchKernelGGL(colsum_act<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
+                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
+    }
     rc = evt_check_launch();
     if (rc) return rc;
   }
-  if (c->impl != EVT_IMPL_NAIVE && evt_grouped_supported(c)) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
-  const bool use_igemm = c->impl != EVT_IMPL_NAIVE && igemm_ok(c) && l.reg_kp <= 64;
+  if (grouped) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
+  const bool use_igemm = igemm_path;
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   if (!use_igemm) {
     NvP p = make_nvp(c);
@@ -872,6 +1095,19 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     p.B = dy; p.Bact = ysv; p.bact_kind = c->out_act; p.bact_slope = c->out_slope; p.b_slope = 1.f;
     p.LA = c->lin; p.CA = c->cin; p.LB = lout; p.CB = c->cout; p.Q = c->lin;
   }
+  if (c->dtype == EVT_DT_BF16) {
+    p.dbias = fuse_bias ? dbias : nullptr;
+    rc = launch_wgrad_tr(p, st);
+    if (rc != EVT_ENOTSUP) return rc;
+    if (fuse_bias) {  // tile did not fit: the gather kernel has no fused bias
+      const long rows = (long)c->nseq * lout;
+      hipLaunchKernelGGL(colsum_act<bf16_t>, dim3((int)((rows + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,
+                         (const bf16_t*)ysv, dbias, rows, c->cout, c->out_act, c->out_slope, 64);
+      rc = evt_check_launch();
+      if (rc) return rc;
+    }
+  }
+  p.dbias = nullptr;
   return launch_wgrad(c->dtype, p, st);
 }
 

@@ -63,22 +63,38 @@ class MultiHeadAttention(nn.Module):
         nn.init.xavier_uniform_(self.conv_q.weight)
         nn.init.xavier_uniform_(self.conv_k.weight)
         nn.init.xavier_uniform_(self.conv_v.weight)
-        self._band_cache = {}
 
-    def _band(self, length, device):
-        """index maps between absolute (i, j) and windowed-relative (i, r) positions, r = j - i + w"""
-        key = (length, str(device))
-        if key not in self._band_cache:
-            w = self.window_size
-            i = torch.arange(length, device=device)
-            rel = i[None, :] - i[:, None] + w                    # [l, l]  r for (i, j)
-            valid = (rel >= 0) & (rel <= 2 * w)
-            abs_idx = torch.where(valid, rel, torch.full_like(rel, 2 * w + 1))  # slot 2w+1 = zero column
-            r = torch.arange(2 * w + 1, device=device)
-            j = i[:, None] + r[None, :] - w                      # [l, 2w+1]  j for (i, r)
-            jvalid = (j >= 0) & (j < length)
-            self._band_cache[key] = (abs_idx, j.clamp(0, length - 1), jvalid)
-        return self._band_cache[key]
+    @staticmethod
+    def _rel_to_abs(x):
+        """[b, h, l, 2l-1] relative logits -> [b, h, l, l] (entry (i, j) = rel[i, j - i + l - 1]) by the
+        pad / reshape skew: pure copies forward and backward, no gather/scatter atomics."""
+        b, h, l, _ = x.shape
+        x = F.pad(x, (0, 1)).reshape(b, h, l * 2 * l)
+        x = F.pad(x, (0, l - 1)).reshape(b, h, l + 1, 2 * l - 1)
+        return x[:, :, :l, l - 1:]
+
+    @staticmethod
+    def _abs_to_rel(x):
+        """[b, h, l, l] -> [b, h, l, 2l-1] (entry (i, r) = abs[i, i + r - (l-1)], zero outside)"""
+        b, h, l, _ = x.shape
+        x = F.pad(x, (0, l - 1)).reshape(b, h, l * (2 * l - 1))
+        x = F.pad(x, (l, 0)).reshape(b, h, l, 2 * l)
+        return x[:, :, :, 1:]
+
+    def _band_to_full(self, band, length):
+        """[.., 2w+1] band around offset 0 -> [.., 2l-1] full relative axis (zeros outside the window)"""
+        w = self.window_size
+        extra = length - 1 - w
+        if extra >= 0:
+            return F.pad(band, (extra, extra))
+        return band[..., -extra: band.size(-1) + extra]
+
+    def _full_to_band(self, full, length):
+        w = self.window_size
+        extra = length - 1 - w
+        if extra >= 0:
+            return full[..., extra: extra + 2 * w + 1]
+        return F.pad(full, (-extra, -extra))
 
     def forward(self, x, c, attn_mask=None):
         """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend)"""
@@ -92,17 +108,15 @@ class MultiHeadAttention(nn.Module):
         scores = torch.matmul(qs, k.transpose(-2, -1))
         if self.window_size is not None:
             assert t_s == t_t, "relative attention is only available for self-attention"
-            abs_idx, j_idx, jvalid = self._band(t_s, x.device)
-            # logits against the 2w+1 relative key embeddings, scattered onto the |i-j| <= w band
+            # logits against the 2w+1 relative key embeddings, skewed onto the |i-j| <= w band
             qe = torch.matmul(qs, self.emb_rel_k.unsqueeze(0).transpose(-2, -1))       # [b, h, l, 2w+1]
-            qe = F.pad(qe, (0, 1))
-            scores = scores + qe.gather(-1, abs_idx.expand(b, h, t_s, t_s))
+            scores = scores + self._rel_to_abs(self._band_to_full(qe, t_s))
         if attn_mask is not None:
             scores = scores.masked_fill(attn_mask == 0, -1e4)
         p_attn = self.drop(F.softmax(scores, dim=-1))
         out = torch.matmul(p_attn, v)
         if self.window_size is not None:
-            relw = p_attn.gather(-1, j_idx.expand(b, h, t_s, -1)) * jvalid.to(p_attn.dtype)   # [b, h, l, 2w+1]
+            relw = self._full_to_band(self._abs_to_rel(p_attn), t_s)                    # [b, h, l, 2w+1]
             out = out + torch.matmul(relw, self.emb_rel_v.unsqueeze(0))
         out = out.transpose(1, 2).reshape(b, t_t, h * d)
         return self.conv_o(out)
