@@ -28,6 +28,14 @@ extern "C" int evt_grouped_bwd_data(const evt_conv1d_params* c, const void* dy, 
 extern "C" int evt_grouped_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y,
                                       float* dw, void* stream);
 
+extern "C" int evt_small_kind(const evt_conv1d_params* c);
+extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
+                             void* stream);
+extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
+                                    void* stream);
+extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
+                                   void* stream);
+
 namespace {
 
 struct ConvP {
@@ -487,6 +495,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       }
     }
   }
+  if (NPS > 1) {
+    // sum the position-slice waves inside the block first: 1/NPS of the global atomics
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((wave * KT + t) * NTB + j) * 4 + r) * 64 + lane] = acc[t][j][r];
+    __syncthreads();
+    if (ps != 0) {
+      if (do_bias) atomicAdd(p.dbias + a0 + bcol, bsum);
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[t][j][r];
+          for (int o = 1; o < NPS; ++o) v += red[((((o * NCT + ct) * KT + t) * NTB + j) * 4 + r) * 64 + lane];
+          acc[t][j][r] = v;
+        }
+  }
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     if (t >= ntap) continue;
@@ -799,7 +833,8 @@ template <int CK, int TA>
 int launch_wgrad_tr_inst(const WgP& p, hipStream_t st) {
   constexpr int PK = 64 * (4 / (TA / 16));
   const int BR = (PK - 1) * p.s + 3 * p.dil + 1;
-  const size_t lds = ((size_t)PK * (TA + 8) + (size_t)BR * (CK + 8)) * 2;
+  size_t lds = ((size_t)PK * (TA + 8) + (size_t)BR * (CK + 8)) * 2;
+  if (TA < 64 && lds < (size_t)16384 * (CK / 16)) lds = (size_t)16384 * (CK / 16);  // cross-wave reduction scratch
   if (lds > 150 * 1024) return EVT_ENOTSUP;
   static bool attr = false;
   if (lds > 48 * 1024 && !attr) {
@@ -823,10 +858,11 @@ int launch_wgrad_tr(WgP p, hipStream_t st) {
   p.ntapgrp = ceil_div(p.KHp, 4);
   const long iters = (long)p.nseq * ceil_div(p.Q, PK);
   const long tiles = (long)(p.CA / TA) * p.nchunk * p.ntapgrp;
-  long split = (1024 + tiles - 1) / tiles;
+  // enough blocks to fill the chip, but a bounded number of atomic partials per dW element
+  long split = (768 + tiles - 1) / tiles;
+  if (split > 256) split = 256;
   if (split > iters) split = iters;
   if (split < 1) split = 1;
-  if (split > 65535) split = 65535;
   p.nsplit = (int)split;
   if (CK == 32) {
     if (TA == 64) return launch_wgrad_tr_inst<32, 64>(p, st);
@@ -924,6 +960,10 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
   if (c->impl != EVT_IMPL_NAIVE && !res && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
     return evt_grouped_fwd(c, x, w_reg, bias, y, stream);
+  }
+  if (c->impl != EVT_IMPL_NAIVE && !res && evt_small_kind(c) == 1) {
+    if (!w_reg) return EVT_EINVAL;
+    return evt_cout1_fwd(c, x, w_reg, bias, y, stream);
   }
   if (!use_igemm) {
     if (!w_reg) return EVT_EINVAL;
@@ -1062,6 +1102,8 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     if (rc) return rc;
   }
   if (grouped) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
+  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, stream);
+  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2) return evt_cin1_bwd_weight(c, x, dy, y, dw, stream);
   const bool use_igemm = igemm_path;
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   if (!use_igemm) {

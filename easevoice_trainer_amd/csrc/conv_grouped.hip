@@ -49,6 +49,7 @@ struct GP {
   float out_slope;
   int tiles_per_seq;
   int nsplit;
+  int cog;           // output channels per group: 16, or 4 (MFMA rows 4..15 are zero padding)
 };
 
 // ---- forward: wave = (group, 64 output positions) --------------------------------------------------------
@@ -69,10 +70,10 @@ __global__ __launch_bounds__(256) void grouped_fwd(GP p) {
   const int K = p.k * 4;
   const T* xg = reinterpret_cast<const T*>(p.x) + (long)seq * p.lin * p.cin;
   // stage weights of this wave's group: [16 co][K] contiguous in the REG image, zero-padded to KPAD
-  const T* wg = reinterpret_cast<const T*>(p.w) + (long)grp * 16 * K;
+  const T* wg = reinterpret_cast<const T*>(p.w) + (long)grp * p.cog * K;
   for (int idx = lane; idx < 16 * KPAD; idx += 64) {
     const int co = idx / KPAD, kk = idx - co * KPAD;
-    wsA[co * WP + kk] = kk < K ? wg[co * K + kk] : from_f<T>(0.f);
+    wsA[co * WP + kk] = (kk < K && co < p.cog) ? wg[co * K + kk] : from_f<T>(0.f);
   }
   // stage rows 4*q0 - pad + [0, R) of the block's 4 groups (16 contiguous channels per row)
   T* xs_all = reinterpret_cast<T*>(smem) + 4 * (16 * WP);
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256) void grouped_fwd(GP p) {
 #pragma unroll
   for (int j = 0; j < PT / 16; ++j) {
     const int q = q0 + j * 16 + n;
-    if (q >= p.lout) continue;
-    const int co = grp * 16 + g8 * 4;
+    if (q >= p.lout || g8 * 4 >= p.cog) continue;
+    const int co = grp * p.cog + g8 * 4;
     T outv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(256) void grouped_bwd_data(GP p) {
   const int grp = blockIdx.y * 4 + wave;
   const int K = p.k * 4;
   // A[(phase, c)][(jj, co)] = w[grp*16+co][t = phase + 4*(JP-1-jj)][c], zero when t >= k
-  const T* wg = reinterpret_cast<const T*>(p.w) + (long)grp * 16 * K;
+  const T* wg = reinterpret_cast<const T*>(p.w) + (long)grp * p.cog * K;
   for (int idx = lane; idx < 16 * KPAD; idx += 64) {
     const int m = idx / KPAD, kk = idx - m * KPAD;
     const int ph = m >> 2, c = m & 3;
     const int jj = kk >> 4, co = kk & 15;
     const int t = ph + 4 * (JP - 1 - jj);
-    wsA[m * WP + kk] = t < p.k ? wg[co * K + t * 4 + c] : from_f<T>(0.f);
+    wsA[m * WP + kk] = (t < p.k && co < p.cog) ? wg[co * K + t * 4 + c] : from_f<T>(0.f);
   }
   // stage dy rows q0 - (JP-1) + [0, R) of this wave's group, times act'(y)
   const T* dyg = reinterpret_cast<const T*>(p.x) + (long)seq * p.lout * p.cout;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) void grouped_bwd_data(GP p) {
     const int r = idx >> 4, co = idx & 15;
     const int row = r0 + r;
     T v = from_f<T>(0.f);
-    if (row >= 0 && row < p.lout) {
-      const long off = (long)row * p.cout + grp * 16 + co;
+    if (row >= 0 && row < p.lout && co < p.cog) {
+      const long off = (long)row * p.cout + grp * p.cog + co;
       float f = to_f<T>(dyg[off]);
       if (yag) f *= dact_from_out(p.out_act, to_f<T>(yag[off]), p.out_slope);
       v = from_f<T>(f);
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(256) void grouped_bwd_weight(GP p) {
       const int r = idx >> 4, co = idx & 15;
       const int q = q0 + r;
       T v = from_f<T>(0.f);
-      if (q < p.lout) {
-        const long off = ((long)seq * p.lout + q) * p.cout + grp * 16 + co;
+      if (q < p.lout && co < p.cog) {
+        const long off = ((long)seq * p.lout + q) * p.cout + grp * p.cog + co;
         float f = to_f<T>(dy0[off]);
         if (ya0) f *= dact_from_out(p.out_act, to_f<T>(ya0[off]), p.out_slope);
         v = from_f<T>(f);
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) void grouped_bwd_weight(GP p) {
     if (kidx >= K) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = grp * 16 + g8 * 4 + r;
+      if (g8 * 4 + r >= p.cog) continue;
+      const int co = grp * p.cog + g8 * 4 + r;
       atomicAdd(p.dw + (long)co * K + kidx, acc[j][r]);
     }
   }
@@ -286,7 +288,7 @@ int set_lds(F f, size_t lds) {
 
 // Shape gate shared with conv1d.hip's dispatcher.
 extern "C" int evt_grouped_supported(const evt_conv1d_params* c) {
-  return !c->transposed && c->groups > 1 && c->groups % 4 == 0 && c->cin / c->groups == 4 && c->cout / c->groups == 16 &&
+  return !c->transposed && c->groups > 1 && c->groups % 4 == 0 && c->cin / c->groups == 4 && (c->cout / c->groups == 16 || c->cout / c->groups == 4) &&
          c->stride == 4 && c->dil == 1 && c->k * 4 <= 176 && c->k >= 4;
 }
 
@@ -296,6 +298,7 @@ extern "C" int evt_grouped_fwd(const evt_conv1d_params* c, const void* x, const 
   p.x = x; p.w = w_reg; p.bias = bias; p.y = y;
   p.nseq = c->nseq; p.lin = c->lin; p.lout = evt_conv1d_lout(c); p.cin = c->cin; p.cout = c->cout; p.k = c->k;
   p.pad = c->pad; p.groups = c->groups; p.in_slope = c->in_slope; p.out_act = c->out_act; p.out_slope = c->out_slope;
+  p.cog = c->cout / c->groups;
   p.tiles_per_seq = cdiv(p.lout, PT);
   const int sz = c->dtype == EVT_DT_BF16 ? 2 : 4;
   const size_t lds = (size_t)(4 * 16 * WP + 4 * ((4 * (PT - 1) + KPAD / 4) * 4 + 16)) * sz;
@@ -317,6 +320,7 @@ extern "C" int evt_grouped_bwd_data(const evt_conv1d_params* c, const void* dy, 
   p.x = dy; p.xact = c->out_act != EVT_ACT_NONE ? y : nullptr; p.w = w_reg; p.y = dx;
   p.nseq = c->nseq; p.lin = c->lin; p.lout = evt_conv1d_lout(c); p.cin = c->cin; p.cout = c->cout; p.k = c->k;
   p.pad = c->pad; p.groups = c->groups; p.in_slope = c->in_slope; p.out_act = c->out_act; p.out_slope = c->out_slope;
+  p.cog = c->cout / c->groups;
   const int nq = (c->lin - 1 + c->pad) / 4 + 1;   // q' in [0, nq)
   p.tiles_per_seq = cdiv(nq, PT);
   const int sz = c->dtype == EVT_DT_BF16 ? 2 : 4;
@@ -339,9 +343,12 @@ extern "C" int evt_grouped_bwd_weight(const evt_conv1d_params* c, const void* x,
   p.x = x; p.dy = dy; p.xact = c->out_act != EVT_ACT_NONE ? y : nullptr; p.dw = dw;
   p.nseq = c->nseq; p.lin = c->lin; p.lout = evt_conv1d_lout(c); p.cin = c->cin; p.cout = c->cout; p.k = c->k;
   p.pad = c->pad; p.groups = c->groups; p.in_slope = c->in_slope; p.out_act = c->out_act; p.out_slope = c->out_slope;
+  p.cog = c->cout / c->groups;
   p.tiles_per_seq = cdiv(p.lout, PT);
   const long total = (long)p.nseq * p.tiles_per_seq;
-  long split = 4096 / (c->groups / 4);
+  long split = 1024 / (c->groups / 4);
+  if (split > 256) split = 256;
+  if (split < 16) split = 16;
   if (split > total) split = total;
   if (split < 1) split = 1;
   p.nsplit = (int)split;
