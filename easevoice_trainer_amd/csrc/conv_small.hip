@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void cout1_fwd(SP p) {
 }
 
 // ---- Cout == 1 backward-weight: dW[t][c] += sum_pos dy_eff[pos] * lrelu(x)[row(pos,t)][c] --------------------
-// thread -> (position lane pl, piece pc); up to 2 pieces per thread; block covers pos_per_block positions
+// thread -> (position lane pl, piece pc); up to NA pieces per thread; block covers pos_per_block positions
 template <typename T>
 __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
   constexpr int V = 16 / sizeof(T);
@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
   const int pl = threadIdx.x / pp, pc0 = threadIdx.x % pp;
   for (int i = threadIdx.x; i < p.k * p.cin; i += 256) red[i] = 0.f;
   __syncthreads();
-  float acc[2][V];
+  constexpr int NA = 4;   // k*cin <= 4096 (evt_small_kind) -> at most 1024 pieces -> 4 per thread
+  float acc[NA][V];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[a][e] = 0.f;
   const T* x = reinterpret_cast<const T*>(p.x);
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
     float d = to_f<T>(dy[o]);
     if (ys) d *= dact_from_out(p.out_act, to_f<T>(ys[o]), p.out_slope);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NA; ++a) {
       const int pc = pc0 + a * pp;
-      if (pc >= pieces) break;
+      if (pc >= pieces) continue;
       const int t = pc / ppr, c0 = (pc - t * ppr) * V;
       const int row = q * p.stride + t * p.dil - p.pad;
       if (row < 0 || row >= p.lin) continue;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
     }
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < NA; ++a) {
     const int pc = pc0 + a * pp;
     if (pc < pieces) {
       const int t = pc / ppr, c0 = (pc - t * ppr) * V;
@@ -189,7 +190,7 @@ SP make_sp(const evt_conv1d_params* c) {
 extern "C" int evt_small_kind(const evt_conv1d_params* c) {
   if (c->transposed || c->groups != 1) return 0;
   const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
-  if (c->cout == 1 && c->cin % V == 0 && (long)c->k * c->cin <= 8192) return 1;   // dot-product conv
+  if (c->cout == 1 && c->cin % V == 0 && (long)c->k * c->cin <= 4096) return 1;   // dot-product conv
   if (c->cin == 1 && c->cout <= 64 && 256 % c->cout == 0 && c->k <= 16) return 2;  // single-channel input
   return 0;
 }

@@ -42,6 +42,7 @@ CASES = [
     (1, 32, 5, 3, 2, 1, 1, False, True, 200, 4),
     (1, 16, 15, 1, 7, 1, 1, False, True, 120, 2),
     (64, 1, 3, 1, 1, 1, 1, False, True, 40, 3),
+    (1024, 1, 3, 1, 1, 1, 1, False, True, 127, 4),
     (16, 64, 41, 4, 20, 1, 4, False, True, 300, 2),
     (64, 256, 41, 4, 20, 1, 16, False, True, 1000, 3),
     (256, 1024, 41, 4, 20, 1, 64, False, True, 130, 2),
