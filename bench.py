@@ -103,7 +103,7 @@ def run_s2(args, world, rank, local):
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
-    return res, eng
+    return res, eng, step
 
 
 def main():
@@ -119,12 +119,12 @@ def main():
     args = ap.parse_args()
     world, rank, local = init_dist(args.gpus)
     if args.workload == "s2":
-        res, eng = run_s2(args, world, rank, local)
+        res, eng, step_fn = run_s2(args, world, rank, local)
         if not args.no_extras:
             try:
                 from tools import bench_extras
 
-                res.update(bench_extras.s2_extras(args, eng, world, rank))
+                res.update(bench_extras.s2_extras(args, eng, world, rank, step_fn))
             except Exception as e:  # the headline number must still be printed
                 res["extras_error"] = repr(e)
     else:

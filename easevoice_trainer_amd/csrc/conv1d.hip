@@ -761,6 +761,7 @@ int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
     max_set = 160 * 1024;
   }
   const int gx = 8 * ceil_div(p.P, 8) * p.Y;
+  evt_set_last_tag("conv_igemm<%s, %d, %d, %d>", SZ == 2 ? "bf16" : "f32", CK, MT, NT);
   hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT>), dim3(gx, nphase), dim3(256), lds, st, p);
   return evt_check_launch();
 }
@@ -825,6 +826,7 @@ int launch_wgrad_inst(const WgP& p, hipStream_t st) {
     attr = true;
   }
   const int gx = ceil_div(p.CA, 64) * p.nchunk * p.ntapgrp;
+  evt_set_last_tag("conv_wgrad<%s, %d>", sizeof(T) == 2 ? "bf16" : "f32", CK);
   hipLaunchKernelGGL((conv_wgrad<T, CK>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
   return evt_check_launch();
 }
@@ -844,6 +846,7 @@ int launch_wgrad_tr_inst(const WgP& p, hipStream_t st) {
     attr = true;
   }
   const int gx = (p.CA / TA) * p.nchunk * p.ntapgrp;
+  evt_set_last_tag("conv_wgrad_tr<%d, %d>", CK, TA);
   hipLaunchKernelGGL((conv_wgrad_tr<CK, TA>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
   return evt_check_launch();
 }
@@ -957,8 +960,10 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   const int lout = evt_conv1d_lout(c);
   evt_wlayout l; evt_conv1d_layout(c, &l);
+  evt_set_last_tag("conv_other_fwd");
   if (c->impl != EVT_IMPL_NAIVE && !res && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
+    evt_set_last_tag("grouped_fwd");
     return evt_grouped_fwd(c, x, w_reg, bias, y, stream);
   }
   if (c->impl != EVT_IMPL_NAIVE && !res && evt_small_kind(c) == 1) {
@@ -1017,8 +1022,10 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
   evt_wlayout l; evt_conv1d_layout(c, &l);
   const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
   const void* gate = c->in_slope != 1.f ? x : nullptr;
+  evt_set_last_tag("conv_other_bwd_data");
   if (c->impl != EVT_IMPL_NAIVE && !gate && !dx_add && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
+    evt_set_last_tag("grouped_bwd_data");
     return evt_grouped_bwd_data(c, dy, y, w_reg, dx, stream);
   }
   if (!use_igemm) {
@@ -1101,6 +1108,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     rc = evt_check_launch();
     if (rc) return rc;
   }
+  evt_set_last_tag("conv_other_bwd_weight");
   if (grouped) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
   if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, stream);
   if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2) return evt_cin1_bwd_weight(c, x, dy, y, dw, stream);

@@ -205,7 +205,19 @@ inline int grid_for(long n, int cap = 8192) {
 
 }  // namespace
 
+#include <stdarg.h>
+#include <stdio.h>
+static thread_local char g_last_tag[128] = "";
+extern "C" void evt_set_last_tag(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_tag, sizeof(g_last_tag), fmt, ap);
+  va_end(ap);
+}
+
 extern "C" {
+
+const char* evt_last_kernel_tag(void) { return g_last_tag; }
 
 const char* evt_version(void) { return "evt-hip 0.1 (gfx950)"; }
 

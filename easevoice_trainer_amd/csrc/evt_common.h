@@ -69,6 +69,10 @@ __device__ __forceinline__ float block_reduce_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// name of the kernel instantiation the last entry point launched on this host thread (bench.py's roofline leg reads
+// it right after a call to attribute HIP-event timings to the same names rocprofv3 reports)
+extern "C" void evt_set_last_tag(const char* fmt, ...);
+
 static inline int evt_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? EVT_OK : EVT_ELAUNCH;

@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange over RCCL/xGMI for the flat gradient arenas (runtime.ParamArena).
+
+What the reference does (src/train/sovits.py:321-322, Lightning DDP in src/train/gpt.py:147-162): torch DDP with
+default 25 MiB buckets over several hundred gradient tensors; the discriminator's reducer fires a second, discarded
+time during the generator backward; s1 all-reduces on each of the 4 accumulation micro-batches.
+
+MI355X-first: gradients of a model are ONE contiguous fp32 buffer, so the exchange is a handful of large collectives
+issued on a side HIP stream as soon as the backward that produced them is done:
+  * D gradients are reduced while the generator's forward/backward through D runs, G gradients while the optimiser
+    of D and the loss bookkeeping run (GradReducer.all_reduce(async_op=True) + wait()); nothing is reduced twice;
+  * bucket size defaults to 64 MiB: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so per-collective latency
+    dominates small buckets; reduce-scatter + all-gather of a large bucket uses every link at once;
+  * averaging (1/world) is folded into the AdamW launch (grad_scale), not a separate pass over the buffer.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None):
+        self.world = world_size
+        self.group = group
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self._pending = []
+        self._stream = None
+
+    def _side_stream(self, device):
+        if self._stream is None and device.type == "cuda":
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def buckets(self, n):
+        b = self.bucket_elems
+        return [(i, min(n, i + b)) for i in range(0, n, b)]
+
+    def all_reduce(self, flat: torch.Tensor, async_op: bool = False, average: bool = False):
+        """sum `flat` (1-D contiguous) over the group, in place.  async_op=True: enqueue on a side stream and return;
+        call wait() before the optimiser reads the buffer."""
+        if self.world == 1:
+            return
+        assert flat.dim() == 1 and flat.is_contiguous()
+        if flat.device.type == "cuda" and async_op:
+            side = self._side_stream(flat.device)
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(side):
+                for b, e in self.buckets(flat.numel()):
+                    dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                if average:
+                    flat.mul_(1.0 / self.world)
+            self._pending.append(flat)
+            return
+        for b, e in self.buckets(flat.numel()):
+            dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+        if average:
+            flat.mul_(1.0 / self.world)
+
+    def wait(self):
+        if self._stream is not None and self._pending:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._pending.clear()
+
+    def broadcast_params(self, flat: torch.Tensor, src: int = 0):
+        """one-time parameter broadcast from rank `src` (DDP's wrap-time broadcast)"""
+        if self.world == 1:
+            return
+        for b, e in self.buckets(flat.numel()):
+            dist.broadcast(flat[b:e], src=src, group=self.group)
+
+    def all_reduce_scalars(self, t: torch.Tensor):
+        """batched metric reduction (the reference does three separate sync_dist scalar all-reduces per step)"""
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.div_(self.world)
+        return t
+
+
+def init_process_group_from_env(backend=None):
+    """one process per GPU; rendezvous over 127.0.0.1 (single node), RCCL when a GPU is present"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def split_subgroups(ranks_a, ranks_b):
+    """BASELINE config 5 (s1 on some ranks, s2 on the others): two sub-communicators from one world.  Every rank
+    must call this with the same arguments."""
+    ga = dist.new_group(ranks=list(ranks_a))
+    gb = dist.new_group(ranks=list(ranks_b))
+    return ga, gb

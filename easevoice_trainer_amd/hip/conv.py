@@ -164,6 +164,29 @@ class WeightBank:
                 "evt_wn_grad_multi")
 
 
+TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1) per launch
+
+
+def _t0():
+    if TRACE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _t1(e0, kind, m, nseq, lin, extra_elems):
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    lq = lin if m.transposed else m.lout(lin)
+    macs = nseq * lq * m.cin * m.cout * m.k // m.groups
+    sz = 2 if m._slot.bank.dtype == torch.bfloat16 else 4
+    act = nseq * (lin * m.cin + m.lout(lin) * m.cout) + extra_elems
+    wbytes = m.v.numel() * (4 if kind == "bwd_weight" else sz)
+    L.lib().evt_last_kernel_tag.restype = C.c_char_p
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1))
+
+
 def _fwd(slot, x, res, in_slope, out_act, out_slope):
     m = slot.module
     if x.dim() != 3 or x.size(2) != m.cin or x.dtype != slot.bank.dtype or not x.is_contiguous():
@@ -175,9 +198,12 @@ def _fwd(slot, x, res, in_slope, out_act, out_slope):
         raise L.EvtError("residual must match the output")
     p = slot.params(nseq, lin, in_slope, out_act, out_slope)
     bias = m.bias
+    e0 = _t0()
     L.check(L.lib().evt_conv1d_fwd(C.byref(p), L.ptr(x), L.ptr(slot.reg), L.ptr(slot.alt),
                                    L.ptr(bias.data if bias is not None else None), L.ptr(res), L.ptr(y),
                                    L.stream_ptr()), "evt_conv1d_fwd")
+    if e0 is not None:
+        _t1(e0, "fwd", m, nseq, lin, y.numel() if res is not None else 0)
     return y
 
 
@@ -185,9 +211,14 @@ def _bwd_data(slot, dy, y, x, dx_add, nseq, lin, in_slope, out_act, out_slope):
     m = slot.module
     dx = torch.empty((nseq, lin, m.cin), dtype=dy.dtype, device=dy.device)
     p = slot.params(nseq, lin, in_slope, out_act, out_slope)
+    e0 = _t0()
     L.check(L.lib().evt_conv1d_bwd_data(C.byref(p), L.ptr(dy), L.ptr(y if out_act != L.ACT_NONE else None),
                                         L.ptr(slot.reg), L.ptr(slot.alt), L.ptr(x if in_slope != 1.0 else None),
                                         L.ptr(dx_add), L.ptr(dx), L.stream_ptr()), "evt_conv1d_bwd_data")
+    if e0 is not None:
+        extra = (dy.numel() if out_act != L.ACT_NONE else 0) + (dx.numel() if in_slope != 1.0 else 0) + \
+                (dx.numel() if dx_add is not None else 0)
+        _t1(e0, "bwd_data", m, nseq, lin, extra)
     return dx
 
 
@@ -199,8 +230,11 @@ def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
         if m.bias.grad is None:
             m.bias.grad = torch.zeros_like(m.bias)
         dbias = m.bias.grad
+    e0 = _t0()
     L.check(L.lib().evt_conv1d_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(y if out_act != L.ACT_NONE else None),
                                           L.ptr(slot.dw), L.ptr(dbias), L.stream_ptr()), "evt_conv1d_bwd_weight")
+    if e0 is not None:
+        _t1(e0, "bwd_weight", m, nseq, lin, dy.numel() if out_act != L.ACT_NONE else 0)
 
 
 class ConvFn(torch.autograd.Function):

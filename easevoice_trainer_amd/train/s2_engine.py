@@ -95,13 +95,16 @@ class S2Engine:
         loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
         loss_disc.backward()
         rt_d.finish_grads()
+        inv_world = 1.0
         if self.reducer is not None:
+            # averaged inside the AdamW launch (grad_scale); the generator-side work below does not depend on it
             self.reducer.all_reduce(rt_d.arena.grad)
+            inv_world = 1.0 / self.reducer.world
         gss_d = rt_d.grad_sumsq().clone()
         if hook_after_d is not None:
             hook_after_d()
         if do_opt:
-            self.optim_d.step()
+            self.optim_d.step(grad_scale=inv_world)
             rt_d.prepare()   # D weights changed: refold before the generator's pass through D
 
         # ---- generator step (sovits.py:509-525) ----
@@ -121,7 +124,7 @@ class S2Engine:
             self.reducer.all_reduce(rt_g.arena.grad)
         gss_g = rt_g.grad_sumsq().clone()
         if do_opt:
-            self.optim_g.step()
+            self.optim_g.step(grad_scale=inv_world)
         return S2Losses(loss_disc.detach(), loss_gen.detach(), loss_fm.detach(), loss_mel.detach(), loss_kl.detach(),
                         kl_ssl.detach(), loss_gen_all.detach(), gss_d, gss_g,
                         extras=dict(y_hat=y_hat.detach(), y_hat_mel=y_hat_mel.detach(), y_mel=y_mel.detach(),

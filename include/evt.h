@@ -35,6 +35,8 @@ extern "C" {
 #define EVT_IMPL_IGEMM 2 /* LDS-tiled implicit-GEMM on MFMA */
 
 const char* evt_version(void);
+/* name of the kernel instantiation launched by the last conv entry point on this host thread (profiling aid) */
+const char* evt_last_kernel_tag(void);
 
 /* ---------------------------------------------------------------------------------------
  * Conv1d / ConvTranspose1d family.

@@ -1,0 +1,60 @@
+"""CPU: the oracle restatement (oracle/s2_step.py) is pinned against fixtures generated from the REFERENCE's own
+modules (tests/golden/s2_c1.pt).  This is what makes the oracle trustworthy as the checker for arbitrary sizes."""
+import json
+import os
+
+import torch
+
+from oracle import s2_step as O
+from util_fill import fill_tensor, s2_batch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def rel(a, b):
+    return ((a.detach().float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12)).item()
+
+
+def _filled(keys, seed):
+    return {k: fill_tensor(k, shape, seed) for k, shape in keys.items()}
+
+
+def test_oracle_s2_step_matches_reference_fixture():
+    torch.set_num_threads(8)
+    gold = torch.load(os.path.join(HERE, "golden", "s2_c1.pt"), weights_only=False)
+    keys = json.load(open(os.path.join(HERE, "golden", "state_dict_keys.json")))
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    sd_g, sd_d = _filled(keys["s2_g"], 1), _filled(keys["s2_d"], 2)
+    c = gold["config"]
+    b = s2_batch(c["B"], c["T"], c["t_text"])
+    out = O.s2_losses(sd_g, sd_d, hps, b["ssl"], b["wav"], b["text"], b["lengths"], b["text_lengths"], b["eps"],
+                      b["ids_slice"], with_grads=True)
+    assert rel(out["spec"][:, :, :4], gold["spec_head"]) < 1e-5
+    assert rel(out["y_hat"].squeeze(1), gold["y_hat"]) < 1e-4
+    assert rel(out["y_hat_mel"], gold["y_hat_mel"]) < 1e-4
+    for k in ("disc", "gen", "fm", "mel", "kl", "gen_all"):
+        assert abs(float(out[k]) - gold["losses"][k]) <= 2e-4 * abs(gold["losses"][k]), (k, float(out[k]))
+    for n, s in gold["g_grad_slices"].items():
+        assert rel(out["g_grads"][n].flatten()[:64], s) < max(2e-3, 3 * gold["g_grad_slice_noise"][n]), n
+    for n, s in gold["d_grad_slices"].items():
+        assert rel(out["d_grads"][n].flatten()[:64], s) < max(2e-3, 3 * gold["d_grad_slice_noise"][n]), n
+    assert out["g_grads"]["ssl_proj.weight"] is None    # no gradient reaches ssl_proj (models.py:912-921)
+
+
+def test_mel_filterbank_properties():
+    """librosa is absent: the slaney filterbank restatement is checked against its defining properties."""
+    import numpy as np
+    from oracle.melbank import slaney_mel
+
+    m = slaney_mel(32000, 2048, 128, 0.0, None)
+    assert m.shape == (128, 1025) and (m >= 0).all()
+    peaks = m.argmax(axis=1)
+    assert (np.diff(peaks) > 0).all()                      # centre frequencies increase
+    # slaney norm: each triangle has (approximately) unit area in Hz
+    hz_per_bin = 16000 / 1024
+    area = m.sum(axis=1) * hz_per_bin
+    assert np.allclose(area[8:], 1.0, atol=0.12)
+    # below 1 kHz the scale is linear: equal spacing of the first filters' peaks
+    lin = peaks[: 10]
+    assert np.abs(np.diff(lin, 2)).max() <= 1
