@@ -64,53 +64,24 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
     return r
 
 
-def cpu_baseline_s2(args, hps, budget_s=30.0):
-    from oracle import s2_step as O
+def cpu_baseline_s2(args, hps, hard_timeout_s=150.0):
+    """runs tools/cpu_baseline.py in a subprocess; whatever it printed before the hard timeout is reported"""
+    import subprocess
+    import sys
 
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
-    B, T, tt = 2, args.clip_seconds * 50, 60
-    from easevoice_trainer_amd.module.models import MultiPeriodDiscriminator, SynthesizerTrn
-
-    d, m, t = hps["data"], hps["model"], hps["train"]
-    torch.manual_seed(1234)
-    g = SynthesizerTrn(d["filter_length"] // 2 + 1, t["segment_size"] // d["hop_length"], n_speakers=d["n_speakers"], **m)
-    dd = MultiPeriodDiscriminator(False)
-    sd_g = {k: v.detach().clone() for k, v in g.state_dict().items()}
-    sd_d = {k: v.detach().clone() for k, v in dd.state_dict().items()}
-    sd_g["quantizer.vq.layers.0._codebook.embed"].normal_()
-    gen = torch.Generator().manual_seed(1234)
-    wav = torch.rand(B, 1, T * 640, generator=gen) - 0.5
-    ssl = torch.randn(B, 768, T, generator=gen)
-    text = torch.randint(0, 732, (B, tt), generator=gen)
-    eps = torch.randn(B, 192, T, generator=gen)
-    ids = torch.randint(0, T - 32 + 1, (B,), generator=gen)
-    lens, tl = torch.full((B,), T), torch.full((B,), tt)
-    state = {}
-
-    def one_step(step):
-        out = O.s2_losses(sd_g, sd_d, hps, ssl, wav, text, lens, tl, eps, ids, with_grads=True)
-        for sd, grads in ((sd_d, out["d_grads"]), (sd_g, out["g_grads"])):
-            for k, gr in grads.items():
-                if gr is None:
-                    continue
-                st = state.setdefault((id(sd), k), (torch.zeros_like(gr), torch.zeros_like(gr)))
-                O.adamw_step(sd[k], gr, st[0], st[1], step, t["learning_rate"], tuple(t["betas"]), t["eps"])
-        return out
-
-    one_step(1)   # warm-up
-    times, step = [], 2
-    t_start = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_start) < budget_s:
-        t0 = time.perf_counter()
-        one_step(step)
-        times.append(time.perf_counter() - t0)
-        step += 1
-    med = sorted(times)[len(times) // 2]
-    return dict(value=B * args.clip_seconds / med, unit="audio-s/s", cores=threads, kind="port",
-                sample=f"oracle s2 step (fwd + D/G backward + AdamW), batch {B} x {args.clip_seconds} s clips, fp32, "
-                       f"1 warm-up + {len(times)} timed steps, median {med:.2f} s/step",
-                seconds_per_step=med)
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_baseline.py"),
+           "--batch", "2", "--clip-seconds", str(args.clip_seconds), "--budget", "40"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env)
+        out = r.stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        return dict(value=None, unit="audio-s/s", cores=None, kind="port",
+                    sample=f"oracle s2 step did not finish one timed step within {hard_timeout_s:.0f} s on this host")
+    return json.loads(lines[-1])
 
 
 def s2_extras(args, eng, world, rank, step_fn=None):
