@@ -1,0 +1,180 @@
+"""s1 AR text->semantic GPT (training path), MI355X-native.
+
+Same constructor config, parameter keys (295 state_dict entries) and arithmetic as the reference's
+Text2SemanticDecoder.forward_old (src/easevoice/soundstorm/auto_reg/models/t2s_model.py:255-338,431-490,557-561),
+TransformerEncoder / TransformerEncoderLayer (modules/transformer.py:106-339), MultiheadAttention
+(modules/activation.py:17-428, patched_mha_with_cache.py:14-465), TokenEmbedding / SinePositionalEmbedding
+(modules/embedding.py:8-81).  Differences in HOW:
+  * the [B*16, L, L] float mask is never built: the flash-attention kernel evaluates the prefix-LM + padding rule from
+    (x_len, x_lens, y_lens);
+  * post-LN residuals, cross-entropy(sum) + top-3 accuracy are single fused HIP launches;
+  * Linear layers are plain GEMMs (hipBLASLt via F.linear) in the compute dtype.
+There is no inference path here and no DPO branch (N4).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..hip import lib as L
+from .ops import AddLayerNormFn, CrossEntropySumFn, PrefixLMAttentionFn
+
+
+class TokenEmbedding(nn.Module):
+    def __init__(self, embedding_dim, vocab_size, dropout=0.0):
+        super().__init__()
+        self.vocab_size, self.embedding_dim = vocab_size, embedding_dim
+        self.dropout = nn.Dropout(p=dropout)
+        self.word_embeddings = nn.Embedding(vocab_size, embedding_dim)
+
+    @property
+    def weight(self):
+        return self.word_embeddings.weight
+
+    def forward(self, x):
+        return self.dropout(self.word_embeddings(x))
+
+
+class SinePositionalEmbedding(nn.Module):
+    """x * x_scale + alpha * PE (embedding.py:36-81); `pe` is a plain attribute there, so it is not in the state_dict."""
+
+    def __init__(self, embedding_dim, dropout=0.0, scale=False, alpha=False):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.x_scale = math.sqrt(embedding_dim) if scale else 1.0
+        self.alpha = nn.Parameter(torch.ones(1), requires_grad=alpha)
+        self.dropout = nn.Dropout(p=dropout)
+        self._pe = None
+
+    def pe(self, length, device, dtype):
+        if self._pe is None or self._pe.size(0) < length or self._pe.device != device:
+            n = max(length, 4000)
+            position = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+            div_term = torch.exp(torch.arange(0, self.embedding_dim, 2, dtype=torch.float32)
+                                 * -(math.log(10000.0) / self.embedding_dim))
+            pe = torch.zeros(n, self.embedding_dim)
+            pe[:, 0::2] = torch.sin(position * div_term)
+            pe[:, 1::2] = torch.cos(position * div_term)
+            self._pe = pe.to(device)
+        return self._pe[:length].to(dtype)
+
+    def forward(self, x):
+        out = x * self.x_scale + self.alpha.to(x.dtype) * self.pe(x.size(1), x.device, x.dtype).unsqueeze(0)
+        return self.dropout(out)
+
+
+class MultiheadAttention(nn.Module):
+    """keys: in_proj_weight [3E, E], in_proj_bias [3E], out_proj.{weight,bias} (activation.py:112-150)"""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, x, x_lens, y_lens, x_len, seed):
+        qkv = F.linear(x, self.in_proj_weight.to(x.dtype), self.in_proj_bias.to(x.dtype))
+        p = self.dropout if self.training else 0.0
+        o = PrefixLMAttentionFn.apply(qkv.contiguous(), x_lens, y_lens, x_len, self.num_heads, p, seed)
+        return F.linear(o, self.out_proj.weight.to(x.dtype), self.out_proj.bias.to(x.dtype))
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, normalized_shape, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+
+
+class TransformerEncoderLayer(nn.Module):
+    """post-LN block, transformer.py:186-339 with norm_first=False, activation relu"""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+
+    def forward(self, x, x_lens, y_lens, x_len, seed):
+        sa = self.dropout1(self.self_attn(x, x_lens, y_lens, x_len, seed))
+        x = AddLayerNormFn.apply(x, sa, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        h = F.relu(F.linear(x, self.linear1.weight.to(x.dtype), self.linear1.bias.to(x.dtype)))
+        ff = self.dropout2(F.linear(self.dropout(h), self.linear2.weight.to(x.dtype), self.linear2.bias.to(x.dtype)))
+        return AddLayerNormFn.apply(x, ff, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
+                                     for _ in range(num_layers)])
+
+    def forward(self, x, x_lens, y_lens, x_len, seed):
+        for i, layer in enumerate(self.layers):
+            x = layer(x, x_lens, y_lens, x_len, seed + 7919 * i)
+        return x
+
+
+def make_pad_mask(lengths, max_len=None):
+    """True at padded positions (models/utils.py:16-41)"""
+    n = int(max_len if max_len is not None else lengths.max())
+    return torch.arange(n, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(1)
+
+
+class Text2SemanticDecoder(nn.Module):
+    def __init__(self, config, norm_first=False, top_k=3):
+        super().__init__()
+        m = config["model"]
+        self.model_dim, self.embedding_dim, self.num_head = m["hidden_dim"], m["embedding_dim"], m["head"]
+        self.num_layers, self.vocab_size, self.phoneme_vocab_size = m["n_layer"], m["vocab_size"], m["phoneme_vocab_size"]
+        self.p_dropout, self.EOS, self.top_k = m["dropout"], m["EOS"], top_k
+        if norm_first:
+            raise L.EvtError("norm_first=True is not used by configs/gpt.yaml")
+        assert self.EOS == self.vocab_size - 1
+        self.bert_proj = nn.Linear(1024, self.embedding_dim)
+        self.ar_text_embedding = TokenEmbedding(self.embedding_dim, self.phoneme_vocab_size, self.p_dropout)
+        self.ar_text_position = SinePositionalEmbedding(self.embedding_dim, dropout=0.1, scale=False, alpha=True)
+        self.ar_audio_embedding = TokenEmbedding(self.embedding_dim, self.vocab_size, self.p_dropout)
+        self.ar_audio_position = SinePositionalEmbedding(self.embedding_dim, dropout=0.1, scale=False, alpha=True)
+        # the reference hard-codes dropout=0.1 in the layers regardless of config model.dropout (t2s_model.py:290)
+        self.h = TransformerEncoder(self.model_dim, self.num_head, self.model_dim * 4, 0.1, self.num_layers)
+        self.ar_predict_layer = nn.Linear(self.model_dim, self.vocab_size, bias=False)
+        self.cd = torch.float32
+        self._seed = 0
+
+    def pad_y_eos(self, y, y_mask_int, eos_id):
+        targets = F.pad(y, (0, 1), value=0) + eos_id * F.pad(y_mask_int, (0, 1), value=1)
+        return targets[:, :-1], targets[:, 1:]
+
+    def forward_old(self, x, x_lens, y, y_lens, bert_feature):
+        """x phoneme ids [B, Tx], y semantic ids [B, Ty], bert_feature [B, 1024, Tx] -> (loss sum, top-3 acc)"""
+        cd = self.cd
+        xe = self.ar_text_embedding(x)
+        xe = xe + F.linear(bert_feature.transpose(1, 2).to(cd), self.bert_proj.weight.to(cd), self.bert_proj.bias.to(cd)
+                           ).to(xe.dtype)
+        xe = self.ar_text_position(xe)
+        y_mask_int = make_pad_mask(y_lens, y.size(1)).to(torch.int64)
+        codes = y.to(torch.int64) * (1 - y_mask_int)
+        y_in, targets = self.pad_y_eos(codes, y_mask_int, eos_id=self.EOS)
+        x_len, y_len = x.size(1), y.size(1)
+        y_pos = self.ar_audio_position(self.ar_audio_embedding(y_in))
+        xy = torch.cat([xe, y_pos], dim=1).to(cd).contiguous()
+        self._seed = (self._seed * 1664525 + 1013904223) & 0x7FFFFFFF
+        xy_dec = self.h(xy, x_lens.to(torch.int32).contiguous(), y_lens.to(torch.int32).contiguous(), x_len, self._seed)
+        logits = F.linear(xy_dec[:, x_len:], self.ar_predict_layer.weight.to(cd))        # [B, Ty, V]
+        loss, hits = CrossEntropySumFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k,
+                                             self.EOS)
+        acc = hits[0].float() / hits[1].clamp(min=1).float()
+        return loss, acc
+
+    forward = forward_old

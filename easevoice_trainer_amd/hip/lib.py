@@ -62,16 +62,17 @@ class AttnParams(C.Structure):
         ("x_len", C.c_int32),
         ("q_stride_b", C.c_int64), ("q_stride_l", C.c_int64), ("q_stride_h", C.c_int64),
         ("o_stride_b", C.c_int64), ("o_stride_l", C.c_int64), ("o_stride_h", C.c_int64),
+        ("dropout_p", C.c_float), ("seed", C.c_uint32),
     ]
+
+
+class SAChunk(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("tensor", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ScaledAdamHP(C.Structure):
-    _fields_ = [
-        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("scalar_lr_scale", C.c_float), ("param_min_rms", C.c_float), ("param_max_rms", C.c_float),
-        ("clipping_scale", C.c_float),
-        ("step", C.c_int32), ("size_update_period", C.c_int32), ("pad0_", C.c_int32), ("pad1_", C.c_int32),
-    ]
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("scalar_lr_scale", C.c_float), ("scalar_max", C.c_float), ("step", C.c_int32), ("pad_", C.c_int32)]
 
 
 _lib = None

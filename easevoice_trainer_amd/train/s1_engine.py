@@ -1,0 +1,43 @@
+"""The s1 training micro-step (Text2SemanticLightningModule.training_step,
+src/easevoice/soundstorm/auto_reg/models/t2s_lightning_module.py:41-89) without Lightning: manual optimisation,
+gradients accumulated in the flat arena, ScaledAdam + the pinned-LR schedule, optimiser step on
+`batch_idx > 0 and batch_idx % 4 == 0` exactly like the reference.  Data-parallel: ONE all-reduce of the flat gradient
+arena per optimiser step (the reference all-reduces on each of the accumulation micro-batches)."""
+import torch
+
+from ..auto_reg.optim import ScaledAdam, WarmupCosineLRSchedule
+from ..auto_reg.t2s_model import Text2SemanticDecoder
+from ..hip import lib as L
+from ..runtime import ParamArena
+
+
+class S1Engine:
+    def __init__(self, config: dict, device="cuda:0", dtype=torch.bfloat16, reducer=None):
+        L.lib()
+        self.config, self.device, self.dtype, self.reducer = config, torch.device(device), dtype, reducer
+        self.model = Text2SemanticDecoder(config=config, top_k=3).to(self.device)
+        self.model.cd = dtype
+        self.arena = ParamArena(self.model, self.device)
+        o = config["optimizer"]
+        self.optimizer = ScaledAdam(self.arena, lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0,
+                                    clipping_update_period=1000)
+        self.scheduler = WarmupCosineLRSchedule(self.optimizer, init_lr=o["lr_init"], peak_lr=o["lr"],
+                                                end_lr=o["lr_end"], warmup_steps=o["warmup_steps"],
+                                                total_steps=o["decay_steps"])
+        self.arena.zero_grad()
+
+    def micro_step(self, batch: dict, batch_idx: int):
+        """one micro-batch: forward_old + backward (+ optimiser step on the reference's schedule)"""
+        loss, acc = self.model.forward_old(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
+                                           batch["semantic_ids_len"], batch["bert_feature"])
+        loss.backward()
+        stepped = False
+        if batch_idx > 0 and batch_idx % 4 == 0:
+            if self.reducer is not None:
+                self.reducer.all_reduce(self.arena.grad)
+                self.arena.grad.mul_(1.0 / self.reducer.world)
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            self.scheduler.step()
+            stepped = True
+        return loss.detach(), acc.detach(), stepped

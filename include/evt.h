@@ -184,6 +184,8 @@ typedef struct evt_attn_params {
   int32_t x_len;             /* padded text length (prefix width) */
   int64_t q_stride_b, q_stride_l, q_stride_h; /* element strides (q, k, v share them) */
   int64_t o_stride_b, o_stride_l, o_stride_h;
+  float dropout_p;           /* attention dropout on the normalised probabilities (SDPA dropout_p); 0 = off */
+  uint32_t seed;             /* mask = hash(seed, b*H+h, query, key): identical in forward and backward */
 } evt_attn_params;
 int evt_attn_prefixlm_fwd(const evt_attn_params* p, const void* q, const void* k, const void* v,
                           const int32_t* x_lens, const int32_t* y_lens, void* o, float* lse, void* stream);
@@ -207,15 +209,24 @@ int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets
                        int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, float dloss,
                        void* stream);
 
-/* ScaledAdam batched update (src/easevoice/soundstorm/auto_reg/modules/optim.py:448-598) over a stack of
- * `nb` same-shaped tensors laid out contiguously [nb][numel]. */
+/* ScaledAdam (src/easevoice/soundstorm/auto_reg/modules/optim.py:206-251,300-390,448-622) over a flat fp32 arena.
+ * The reference stacks same-shaped tensors only to batch its torch ops; the arithmetic is per tensor, which is what
+ * these two launches implement for ALL tensors at once:
+ *   evt_scaled_adam_stats : stats[t] = (sum p*g, sum p*p, sum g*g) per tensor t  (+=, caller zeroes stats)
+ *   evt_scaled_adam_apply : delta = beta1*delta + p*coef[t][0] + g/(sqrt(v_hat)+eps)*coef[t][1] ; p += delta
+ *                           (coef[t][2] != 0 selects the numel==1 "scalar" branch, optim.py:600-622).  As in the
+ *                           reference, gradient clipping only enters through coef[t][0] (the size update).
+ * The per-tensor scalars between the two launches (size update, clipping scale) are a few vector ops on [ntensor]
+ * device arrays done by the host layer.  chunks: DEVICE table, one workgroup per chunk (a slice of one tensor). */
+typedef struct evt_sa_chunk { int64_t begin, end; int32_t tensor; int32_t pad_; } evt_sa_chunk;
 typedef struct evt_scaled_adam_hp {
-  float lr, beta1, beta2, eps, scalar_lr_scale, param_min_rms, param_max_rms, clipping_scale;
-  int32_t step, size_update_period, pad0_, pad1_;
+  float lr, beta1, beta2, eps, scalar_lr_scale, scalar_max;
+  int32_t step, pad_;
 } evt_scaled_adam_hp;
-int evt_scaled_adam_batch(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* param_rms,
-                          float* scale_grads, float* scale_exp_avg_sq, float* delta, int32_t nb, int64_t numel,
-                          const evt_scaled_adam_hp* hp, void* stream);
+int evt_scaled_adam_stats(const float* param, const float* grad, const evt_sa_chunk* chunks, int32_t nchunks,
+                          float* stats, void* stream);
+int evt_scaled_adam_apply(float* param, const float* grad, float* delta, float* exp_avg_sq, const evt_sa_chunk* chunks,
+                          int32_t nchunks, const float* coef, const evt_scaled_adam_hp* hp, void* stream);
 
 #ifdef __cplusplus
 }

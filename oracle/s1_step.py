@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE ONLY — CPU fp32 restatement of the reference's s1 (text->semantic GPT) micro-step.
+
+Follows Text2SemanticDecoder.forward_old  src/easevoice/soundstorm/auto_reg/models/t2s_model.py:431-490 (incl. the
+materialised float attention mask :456-479 and pad_y_eos :557-561), TransformerEncoderLayer (post-LN, relu)
+modules/transformer.py:266-339, multi_head_attention_forward_patched modules/patched_mha_with_cache.py:242-460,
+SinePositionalEmbedding modules/embedding.py:36-81, and ScaledAdam modules/optim.py:206-622 (per-tensor form).
+PINNED against tests/golden/s1_small.pt (reference's own modules) by tests/test_oracle_cpu.py."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def sine_pe(n, dim):
+    pos = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe = torch.zeros(n, dim)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def prefix_lm_mask(x_lens, y_lens, x_len, y_len):
+    """bool [B, L, L], True = masked (t2s_model.py:456-479)"""
+    B = x_lens.numel()
+    pad = torch.cat([torch.arange(x_len)[None] >= x_lens[:, None], torch.arange(y_len)[None] >= y_lens[:, None]], 1)
+    x_rows = F.pad(torch.zeros(x_len, x_len, dtype=torch.bool), (0, y_len), value=True)
+    y_rows = F.pad(torch.triu(torch.ones(y_len, y_len, dtype=torch.bool), diagonal=1), (x_len, 0), value=False)
+    base = torch.cat([x_rows, y_rows], 0)
+    return base[None].expand(B, -1, -1) | pad[:, None, :]
+
+
+def attention(qkv, mask_bool, n_head):
+    """qkv [B, L, 3E] -> [B, L, E]; mask_bool [B, L, L] True = masked"""
+    B, L_, E3 = qkv.shape
+    E = E3 // 3
+    d = E // n_head
+    q, k, v = qkv.split(E, dim=-1)
+    q = q.view(B, L_, n_head, d).transpose(1, 2)
+    k = k.view(B, L_, n_head, d).transpose(1, 2)
+    v = v.view(B, L_, n_head, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d)
+    s = s.masked_fill(mask_bool[:, None], float("-inf"))
+    return torch.matmul(F.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, L_, E)
+
+
+def forward_old(sd, cfg, x, x_lens, y, y_lens, bert_feature):
+    m = cfg["model"]
+    E, H, nl, EOS, V = m["hidden_dim"], m["head"], m["n_layer"], m["EOS"], m["vocab_size"]
+    xe = F.embedding(x, sd["ar_text_embedding.word_embeddings.weight"])
+    xe = xe + F.linear(bert_feature.transpose(1, 2), sd["bert_proj.weight"], sd["bert_proj.bias"])
+    xe = xe + sd["ar_text_position.alpha"] * sine_pe(x.size(1), E)[None]
+    y_mask = (torch.arange(y.size(1))[None] >= y_lens[:, None]).to(torch.int64)
+    codes = y.to(torch.int64) * (1 - y_mask)
+    t_full = F.pad(codes, (0, 1), value=0) + EOS * F.pad(y_mask, (0, 1), value=1)
+    y_in, targets = t_full[:, :-1], t_full[:, 1:]
+    ye = F.embedding(y_in, sd["ar_audio_embedding.word_embeddings.weight"])
+    ye = ye + sd["ar_audio_position.alpha"] * sine_pe(y.size(1), E)[None]
+    h = torch.cat([xe, ye], dim=1)
+    x_len, y_len = x.size(1), y.size(1)
+    mask = prefix_lm_mask(x_lens, y_lens, x_len, y_len)
+    for i in range(nl):
+        p = f"h.layers.{i}."
+        qkv = F.linear(h, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"])
+        sa = F.linear(attention(qkv, mask, H), sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        h = F.layer_norm(h + sa, (E,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+        ff = F.linear(F.relu(F.linear(h, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), sd[p + "linear2.weight"],
+                      sd[p + "linear2.bias"])
+        h = F.layer_norm(h + ff, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    logits = F.linear(h[:, x_len:], sd["ar_predict_layer.weight"]).permute(0, 2, 1)
+    loss = F.cross_entropy(logits, targets, reduction="sum")
+    top3 = logits.detach().topk(3, dim=1).indices
+    keep = targets != EOS
+    acc = ((top3 == targets.unsqueeze(1)).any(dim=1) & keep).sum().float() / keep.sum().clamp(min=1).float()
+    return loss, acc, logits
+
+
+class ScaledAdamRef:
+    """per-tensor restatement of optim.py:206-622 on plain tensors"""
+
+    def __init__(self, params, lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0, clipping_update_period=1000,
+                 scalar_lr_scale=0.1, eps=1e-8, param_min_rms=1e-5, param_max_rms=3.0, scalar_max=10.0,
+                 size_update_period=4):
+        self.p = params          # dict name -> tensor (updated in place)
+        self.lr, self.betas, self.cs, self.period = lr, betas, clipping_scale, clipping_update_period
+        self.slr, self.eps, self.minr, self.maxr, self.smax, self.P = scalar_lr_scale, eps, param_min_rms, param_max_rms, scalar_max, size_update_period
+        self.step_n = 0
+        self.st = {}
+        self.norms = torch.zeros(clipping_update_period)
+        self.thr = None
+
+    def step(self, grads):
+        b1, b2 = self.betas
+        step = self.step_n
+        if step == 0:
+            for k, p in self.p.items():
+                self.st[k] = dict(delta=torch.zeros_like(p), v=torch.zeros_like(p),
+                                  rms=(p ** 2).mean().sqrt() if p.numel() > 1 else None, sq=torch.zeros(()),
+                                  sg=torch.zeros(self.P))
+        clip = 1.0
+        if step > 0:
+            tot = sum(((grads[k] * self.st[k]["rms"]) ** 2).sum() if p.numel() > 1 else (grads[k] ** 2).sum()
+                      for k, p in self.p.items())
+            tot_norm = tot.sqrt()
+            self.norms[step % self.period] = tot_norm
+            if step % self.period == 0:
+                srt = self.norms.sort()[0]
+                self.thr = self.cs * srt[min(self.period - 1, (self.period // 4) * 2)].item()
+            if step >= self.period and self.thr is not None:
+                clip = min(1.0, (self.thr / (tot_norm + 1e-20)).item())
+        for k, p in self.p.items():
+            # NOTE (reference behaviour, optim.py:462-464 vs :574,:609): the clipped gradient is a LOCAL variable of
+            # _step_one_batch and only feeds scale_grads; _step / _step_scalar re-read the unclipped p.grad.
+            s, g = self.st[k], grads[k]
+            s["delta"].mul_(b1)
+            if p.numel() > 1:
+                s["sg"][step % self.P] = (p * (g * clip)).sum()
+                if step % self.P == self.P - 1:
+                    s["rms"] = (p ** 2).mean().sqrt()
+                    if step > 0:
+                        size_lr = self.lr * self.slr
+                        b2c = b2 ** self.P
+                        s["sq"] = s["sq"] * b2c + (1 - b2c) * (s["sg"] ** 2).mean()
+                        bc2 = 1 - b2c ** ((step + 1) // self.P)
+                        sstep = -size_lr * (bc2 ** 0.5) * s["sg"].sum() / (s["sq"].sqrt() + self.eps)
+                        if s["rms"] < self.minr:
+                            sstep = torch.zeros(())
+                        if s["rms"] > self.maxr:
+                            sstep = torch.tensor(-size_lr * self.P)
+                        s["delta"].add_(p * sstep, alpha=1 - b1)
+                s["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+                bc2 = 1 - b2 ** (step + 1)
+                v = s["v"] / bc2 if bc2 < 0.99 else s["v"]
+                alpha = -self.lr * (1 - b1) * s["rms"].clamp(min=self.minr)
+                s["delta"].add_(g / (v.sqrt() + self.eps) * alpha)
+                p.add_(s["delta"])
+            else:
+                s["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+                bc2 = 1 - b2 ** (step + 1)
+                denom = (s["v"] / bc2).sqrt() + self.eps
+                s["delta"].add_(g / denom, alpha=-self.lr * self.slr * (1 - b1))
+                p.clamp_(min=-self.smax, max=self.smax)
+                p.add_(s["delta"])
+        self.step_n += 1

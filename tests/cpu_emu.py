@@ -95,3 +95,68 @@ def cpu_emulation():
     finally:
         (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
          PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch) = saved
+
+
+@contextlib.contextmanager
+def cpu_emulation_s1():
+    """substitutes the three s1 autograd Functions and ScaledAdam's two kernel calls by torch CPU equivalents"""
+    from easevoice_trainer_amd.auto_reg import ops as AO, optim as OPT, t2s_model as TM
+    from oracle import s1_step as OS
+
+    saved = (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,
+             OPT.ScaledAdam._k_apply)
+
+    class _Attn:
+        @staticmethod
+        def apply(qkv, x_lens, y_lens, x_len, n_head, dropout_p, seed):
+            mask = OS.prefix_lm_mask(x_lens.long(), y_lens.long(), x_len, qkv.size(1) - x_len)
+            return OS.attention(qkv, mask, n_head)
+
+    class _LN:
+        @staticmethod
+        def apply(x, r, gamma, beta, eps):
+            return F.layer_norm(x + r if r is not None else x, (x.size(-1),), gamma, beta, eps)
+
+    class _CE:
+        @staticmethod
+        def apply(logits, targets, topk, ignore_index):
+            loss = F.cross_entropy(logits.float(), targets, reduction="sum")
+            lt = logits.detach().gather(1, targets[:, None])
+            gt = (logits.detach() > lt).sum(dim=1)
+            keep = targets != ignore_index
+            hits = torch.stack([((gt < topk) & keep).sum(), keep.sum()]).to(torch.int32)
+            return loss, hits
+
+    def k_stats(self):
+        a = self.arena
+        for b, e, t in self._chunk_list:
+            p, g = a.param[b:e], a.grad[b:e]
+            self._stats[t, 0] += (p * g).sum()
+            self._stats[t, 1] += (p * p).sum()
+            self._stats[t, 2] += (g * g).sum()
+
+    def k_apply(self, hp):
+        a = self.arena
+        bc2 = 1.0 - hp.beta2 ** (hp.step + 1)
+        for b, e, t in self._chunk_list:
+            p, g = a.param[b:e], a.grad[b:e]
+            d, v = self.delta[b:e], self.exp_avg_sq[b:e]
+            d.mul_(hp.beta1)
+            v.mul_(hp.beta2).addcmul_(g, g, value=1 - hp.beta2)
+            if float(self._coef[t, 2]) == 0.0:
+                d.add_(p * self._coef[t, 0])
+                vh = v / bc2 if bc2 < 0.99 else v
+                d.add_(g / (vh.sqrt() + hp.eps) * self._coef[t, 1])
+                p.add_(d)
+            else:
+                d.add_(g / ((v / bc2).sqrt() + hp.eps), alpha=-hp.lr * hp.scalar_lr_scale * (1 - hp.beta1))
+                p.clamp_(min=-hp.scalar_max, max=hp.scalar_max)
+                p.add_(d)
+
+    TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn = _Attn, _LN, _CE
+    OPT.ScaledAdam._k_stats, OPT.ScaledAdam._k_apply = k_stats, k_apply
+    try:
+        yield
+    finally:
+        (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,
+         OPT.ScaledAdam._k_apply) = saved

@@ -1,0 +1,82 @@
+"""s1 fixtures from the REFERENCE's own Text2SemanticDecoder / ScaledAdam (build container only)."""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util_fill import fill_module, s1_batch  # noqa: E402
+
+
+def make_s1():
+    import yaml
+    from src.easevoice.soundstorm.auto_reg.models.t2s_model import Text2SemanticDecoder
+    from src.easevoice.soundstorm.auto_reg.modules.optim import ScaledAdam
+
+    torch.set_num_threads(8)
+    cfg = yaml.safe_load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "gpt.yaml")))
+    model = Text2SemanticDecoder(config=cfg, top_k=3)
+    fill_module(model, 3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(m.dropout, float):
+            m.dropout = 0.0
+    model.train()
+    B, x_len, y_len = 3, 24, 40
+    b = s1_batch(B, x_len, y_len)
+    b["phoneme_ids_len"] = torch.tensor([24, 17, 9])
+    b["semantic_ids_len"] = torch.tensor([40, 29, 33])
+    loss, acc = model.forward_old(b["phoneme_ids"], b["phoneme_ids_len"], b["semantic_ids"], b["semantic_ids_len"],
+                                  b["bert_feature"])
+    model.zero_grad()
+    loss.backward()
+    names = ["bert_proj.weight", "ar_text_embedding.word_embeddings.weight", "ar_text_position.alpha",
+             "ar_audio_embedding.word_embeddings.weight", "ar_audio_position.alpha", "h.layers.0.self_attn.in_proj_weight",
+             "h.layers.0.self_attn.in_proj_bias", "h.layers.0.self_attn.out_proj.weight", "h.layers.11.linear1.weight",
+             "h.layers.23.linear2.bias", "h.layers.23.norm2.weight", "h.layers.5.norm1.bias", "ar_predict_layer.weight"]
+    params = dict(model.named_parameters())
+    grads = {n: params[n].grad.flatten()[:96].clone() for n in names}
+    gss = {}
+    for n, p in params.items():
+        top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
+        gss[top] = gss.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    out = dict(config=dict(B=B, x_len=x_len, y_len=y_len, x_lens=[24, 17, 9], y_lens=[40, 29, 33]),
+               loss=float(loss), acc=float(acc), grad_slices=grads, grad_sumsq=gss)
+
+    # ---- ScaledAdam trajectory on a small parameter set (covers batching by shape, the scalar branch, the size update
+    #      every 4 steps and clipping with a short update period) ----
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(w1=(8, 16), w2=(8, 16), b=(8,), s=(1,), e=(5, 7), s2=(1,))
+    ps = {k: torch.nn.Parameter(torch.randn(v, generator=g) * (0.5 if len(v) > 1 else 0.2)) for k, v in shapes.items()}
+    opt = ScaledAdam(list(ps.values()), lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0, clipping_update_period=4,
+                     parameters_names=[list(ps.keys())], show_dominant_parameters=False)
+    traj, grads_used = [], []
+    for step in range(14):
+        gs = {}
+        for k, p in ps.items():
+            scale = 5.0 if step in (9, 12) else 1.0       # spikes so that clipping engages
+            p.grad = torch.randn(p.shape, generator=g) * 0.1 * scale
+            gs[k] = p.grad.clone()
+        grads_used.append(gs)
+        opt.step()
+        for gr in opt.param_groups:
+            gr["lr"] = 0.002                                # what WarmupCosineLRSchedule.step() does after every step
+        traj.append({k: p.detach().clone() for k, p in ps.items()})
+    out["scaled_adam"] = dict(shapes=shapes, init={k: v for k, v in zip(ps.keys(), [None] * len(ps))},
+                              grads=grads_used, traj=traj)
+    g2 = torch.Generator().manual_seed(5)
+    out["scaled_adam"]["init"] = {k: torch.randn(v, generator=g2) * (0.5 if len(v) > 1 else 0.2) for k, v in shapes.items()}
+    path = os.path.join(HERE, "s1_small.pt")
+    torch.save(out, path)
+    print("wrote", path, "loss", out["loss"], "acc", out["acc"], "per-token nll", out["loss"] / (B * y_len))
+
+
+if __name__ == "__main__":
+    make_s1()

@@ -58,3 +58,37 @@ def test_mel_filterbank_properties():
     # below 1 kHz the scale is linear: equal spacing of the first filters' peaks
     lin = peaks[: 10]
     assert np.abs(np.diff(lin, 2)).max() <= 1
+
+
+def test_oracle_s1_matches_reference_fixture():
+    import yaml
+    from oracle import s1_step as OS
+    from util_fill import s1_batch
+
+    gold = torch.load(os.path.join(HERE, "golden", "s1_small.pt"), weights_only=False)
+    keys = json.load(open(os.path.join(HERE, "golden", "state_dict_keys.json")))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    sd = {k: v.requires_grad_(True) for k, v in _filled(keys["s1"], 3).items()}
+    c = gold["config"]
+    b = s1_batch(c["B"], c["x_len"], c["y_len"])
+    loss, acc, _ = OS.forward_old(sd, cfg, b["phoneme_ids"], torch.tensor(c["x_lens"]), b["semantic_ids"],
+                                  torch.tensor(c["y_lens"]), b["bert_feature"])
+    assert abs(float(loss) - gold["loss"]) <= 1e-4 * gold["loss"]
+    assert abs(float(acc) - gold["acc"]) < 1e-6
+    names = list(gold["grad_slices"])
+    grads = torch.autograd.grad(loss, [sd[n] for n in names])
+    for n, g in zip(names, grads):
+        assert rel(g.flatten()[:96], gold["grad_slices"][n]) < 2e-3, n
+
+
+def test_oracle_scaled_adam_matches_reference_trajectory():
+    from oracle import s1_step as OS
+
+    gold = torch.load(os.path.join(HERE, "golden", "s1_small.pt"), weights_only=False)["scaled_adam"]
+    params = {k: v.clone() for k, v in gold["init"].items()}
+    opt = OS.ScaledAdamRef(params, lr=0.01, clipping_update_period=4)
+    for step, (grads, want) in enumerate(zip(gold["grads"], gold["traj"])):
+        opt.step(grads)
+        opt.lr = 0.002
+        for k in params:
+            assert torch.allclose(params[k], want[k], rtol=2e-5, atol=1e-6), (step, k)
