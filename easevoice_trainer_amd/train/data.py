@@ -1,0 +1,95 @@
+"""Batch sources for the trainers.
+
+The reference's on-disk readers (src/easevoice/module/data_utils.py, soundstorm/auto_reg/data/*) depend on the text
+front-end and ffmpeg and are SURVEY §8(f) N1 ("next").  The trainers here take any iterable of batches with the
+reference's collate layout; two sources ship: fixed-shape synthetic batches and a tensor bundle
+(`torch.save` of a list of batch tuples) for pre-extracted features."""
+import os
+
+import torch
+
+
+class SyntheticS2Batches:
+    """(ssl, ssl_lengths, spec, spec_lengths, y, y_lengths, text, text_lengths) of data_utils.py:167-226"""
+
+    def __init__(self, batch_size, seconds, steps_per_epoch, device, seed=1234, t_text=60, rank=0, world=1):
+        self.B, self.T, self.steps, self.device = batch_size, int(seconds * 50), steps_per_epoch, device
+        self.seed, self.t_text, self.rank, self.world = seed, t_text, rank, world
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        from ..module.mel_processing import spectrogram_torch
+
+        g = torch.Generator().manual_seed(self.seed + 1000 * self.epoch + self.rank)
+        for _ in range(self.steps):
+            wav = (torch.rand(self.B, 1, self.T * 640, generator=g) - 0.5).to(self.device)
+            ssl = torch.randn(self.B, 768, self.T, generator=g).to(self.device)
+            text = torch.randint(0, 732, (self.B, self.t_text), generator=g).to(self.device)
+            lens = torch.full((self.B,), self.T, dtype=torch.long, device=self.device)
+            tl = torch.full((self.B,), self.t_text, dtype=torch.long, device=self.device)
+            spec = spectrogram_torch(wav.squeeze(1), 2048, 32000, 640, 2048)
+            yield ssl, lens, spec, lens, wav, lens * 640, text, tl
+
+
+class SyntheticS1Batches:
+    """dict batches of soundstorm/auto_reg/data/dataset.py:234-271"""
+
+    def __init__(self, batch_size, x_len, y_len, steps_per_epoch, device, seed=1234, rank=0):
+        self.B, self.x_len, self.y_len, self.steps, self.device, self.seed, self.rank = \
+            batch_size, x_len, y_len, steps_per_epoch, device, seed, rank
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + 1000 * self.epoch + self.rank)
+        d = self.device
+        for _ in range(self.steps):
+            yield dict(phoneme_ids=torch.randint(0, 732, (self.B, self.x_len), generator=g).to(d),
+                       phoneme_ids_len=torch.full((self.B,), self.x_len, dtype=torch.long, device=d),
+                       semantic_ids=torch.randint(0, 1024, (self.B, self.y_len), generator=g).to(d),
+                       semantic_ids_len=torch.full((self.B,), self.y_len, dtype=torch.long, device=d),
+                       bert_feature=torch.randn(self.B, 1024, self.x_len, generator=g).to(d))
+
+
+class TensorBundle:
+    """a `torch.save`d list of batches (tuples for s2, dicts for s1) with the reference's collate layout"""
+
+    def __init__(self, path, device):
+        self.batches = torch.load(path, map_location="cpu", weights_only=False)
+        self.device = device
+
+    def set_epoch(self, epoch):
+        pass
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for b in self.batches:
+            if isinstance(b, dict):
+                yield {k: v.to(self.device) for k, v in b.items()}
+            else:
+                yield tuple(t.to(self.device) for t in b)
+
+
+def open_source(kind, train_input_dir, device, synthetic_factory):
+    bundle = os.path.join(train_input_dir or "", f"evt_{kind}_batches.pt")
+    if train_input_dir and os.path.isfile(bundle):
+        return TensorBundle(bundle, device)
+    if os.environ.get("EVT_SYNTHETIC_STEPS"):
+        return synthetic_factory(int(os.environ["EVT_SYNTHETIC_STEPS"]))
+    raise FileNotFoundError(
+        f"{bundle} not found.  The reader of the reference's raw feature directories (2-name2text.txt, 4-cnhubert, "
+        "5-wav32k, 6-name2semantic.tsv) is SURVEY §8(f) N1 and not part of this round; provide a tensor bundle or set "
+        "EVT_SYNTHETIC_STEPS=<n> for fixed-shape synthetic batches.")

@@ -1,0 +1,124 @@
+"""GPTTrain — the reference's s1 trainer surface (src/train/gpt.py:27-195 + t2s_lightning_module.py:41-122) without
+pytorch_lightning: same params, configs/gpt.yaml, `<out>/logs/ckpt/epoch=E-step=S.ckpt` resume files (state_dict keys
+carry Lightning's `model.` prefix), `<out>/<name>-e{E}.ckpt` half-precision exports {"weight", "config", "info"} that
+src/easevoice/inference/tts.py:301-315 loads, and one `loss-of-easevoice` line per micro-step on rank 0."""
+import logging
+import os
+import re
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import torch
+import yaml
+
+from ..dist import GradReducer, init_process_group_from_env
+from ..utils.connector import MultiProcessOutputConnector
+from .data import SyntheticS1Batches, open_source
+from .helper import TrainOutput, get_gpt_train_dir, repo_root, train_logs_path
+from .s1_engine import S1Engine
+
+logger = logging.getLogger("easevoice")
+
+
+@dataclass
+class GPTTrainParams:
+    batch_size: int = 12
+    total_epochs: int = 15
+    save_every_epoch: int = 5
+    if_dpo: bool = False
+    if_save_latest: bool = True
+    if_save_every_weights: bool = True
+    gpu_ids: str = "0"
+    model_path: str = ""
+    train_input_dir: str = ""
+    output_model_name: str = ""
+    project_dir: str = ""
+
+
+class GPTTrain:
+    def __init__(self, params: GPTTrainParams, dtype=torch.bfloat16, config_path=None):
+        if params.if_dpo:
+            raise NotImplementedError("the DPO branch (t2s_model.py:393-429) is SURVEY §8(f) N4")
+        self.config = yaml.safe_load(open(config_path or os.path.join(repo_root(), "configs", "gpt.yaml")))
+        self.params, self.dtype = params, dtype
+        self.train_output = get_gpt_train_dir(params.project_dir, params.output_model_name)
+        self.train_logs_output = os.path.join(self.train_output, train_logs_path)
+        self.train_ckpts_output = os.path.join(self.train_logs_output, "ckpt")
+        for d in (self.train_output, self.train_logs_output, self.train_ckpts_output):
+            os.makedirs(d, exist_ok=True)
+        c = self.config["train"]
+        c["batch_size"], c["epochs"], c["save_every_n_epoch"] = params.batch_size, params.total_epochs, params.save_every_epoch
+        c["if_dpo"], c["if_save_latest"], c["if_save_every_weights"] = params.if_dpo, params.if_save_latest, params.if_save_every_weights
+        c["half_weights_save_dir"], c["output_name"] = self.train_output, params.output_model_name
+        self.config["pretrained_s1"] = params.model_path
+        self.config["logs_output_dir"] = self.train_logs_output
+        self.global_step = 0
+
+    @staticmethod
+    def _get_newest_ckpt(file_list):
+        info = []
+        for s in file_list or []:
+            m = re.match(r"epoch=(\d+)-step=(\d+)\.ckpt", s)
+            if m:
+                info.append((int(m.group(1)), int(m.group(2)), s))
+        return sorted(info, reverse=True)[0][2] if info else None
+
+    def _export(self, model, epoch):
+        od = OrderedDict()
+        od["weight"] = OrderedDict(("model." + k, v.detach().cpu().half()) for k, v in model.state_dict().items())
+        od["config"] = self.config
+        od["info"] = "GPT-e%s" % epoch
+        path = os.path.join(self.train_output, "%s-e%s.ckpt" % (self.params.output_model_name, epoch))
+        torch.save(od, path)
+        return path
+
+    def train(self):
+        world, rank, local = init_process_group_from_env()
+        cfg, c = self.config, self.config["train"]
+        torch.manual_seed(c["seed"])
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        reducer = GradReducer(world) if world > 1 else None
+        eng = S1Engine(cfg, device, self.dtype, reducer=reducer)
+        if cfg.get("pretrained_s1") and os.path.exists(cfg["pretrained_s1"]):
+            w = torch.load(cfg["pretrained_s1"], map_location="cpu", weights_only=False)["weight"]
+            eng.model.load_state_dict({k[len("model."):]: v.float() for k, v in w.items() if k.startswith("model.")})
+        start_epoch = 0
+        newest = self._get_newest_ckpt(os.listdir(self.train_ckpts_output))
+        if newest:
+            ck = torch.load(os.path.join(self.train_ckpts_output, newest), map_location="cpu", weights_only=False)
+            eng.model.load_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
+            eng.optimizer.load_state_dict({k: (v.to(device) if torch.is_tensor(v) else v)
+                                           for k, v in ck["optimizer_states"][0].items()})
+            start_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
+        if reducer is not None:
+            reducer.broadcast_params(eng.arena.param)
+        source = open_source("s1", self.params.train_input_dir, device,
+                             lambda n: SyntheticS1Batches(c["batch_size"], 256, 768, n, device, seed=c["seed"], rank=rank))
+        connector = MultiProcessOutputConnector()
+        step_no = 0
+        for epoch in range(start_epoch, c["epochs"]):
+            source.set_epoch(epoch)
+            for batch_idx, batch in enumerate(source):
+                loss, acc, stepped = eng.micro_step(batch, batch_idx)
+                self.global_step += int(stepped)
+                if rank == 0:
+                    connector.write_loss(step_no, loss=float(loss), other={
+                        "acc": float(acc), "lr": eng.scheduler.get_last_lr()[0], "epoch": epoch})
+                step_no += 1
+            if (epoch + 1) % c["save_every_n_epoch"] == 0 and rank == 0:
+                if c["if_save_latest"]:
+                    for name in os.listdir(self.train_ckpts_output):
+                        try:
+                            os.remove(os.path.join(self.train_ckpts_output, name))
+                        except OSError:
+                            pass
+                sd = OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in eng.model.state_dict().items())
+                opt_sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in eng.optimizer.state_dict().items()}
+                torch.save({"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
+                            "optimizer_states": [opt_sd], "hyper_parameters": {"config": cfg}},
+                           os.path.join(self.train_ckpts_output, f"epoch={epoch}-step={self.global_step}.ckpt"))
+                if c["if_save_every_weights"]:
+                    self._export(eng.model, epoch + 1)
+        self.engine = eng
+        return TrainOutput(model_path=self.train_output)

@@ -1,0 +1,141 @@
+"""CPU tests of the host-side surface: checkpoint layout, stdout protocol, directory naming, resume-file selection,
+flat-arena bookkeeping and the data-parallel reducer over gloo (world_size 2)."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Opt:
+    def __init__(self):
+        self.sd = {"state": {0: {"step": torch.tensor(3.0)}}, "param_groups": [{"lr": 1e-4}]}
+
+    def state_dict(self):
+        return self.sd
+
+    def load_state_dict(self, sd):
+        self.sd = sd
+
+
+def test_checkpoint_layout_and_latest_selection(tmp_path):
+    from easevoice_trainer_amd.utils import ckpt
+
+    m = torch.nn.Linear(4, 3)
+    opt = _Opt()
+    p1 = tmp_path / "G_100.pth"
+    p2 = tmp_path / "G_2333.pth"
+    ckpt.save_checkpoint(m, opt, 1e-4, 7, str(p1))
+    ckpt.save_checkpoint(m, opt, 1e-4, 9, str(p2))
+    d = torch.load(p2, weights_only=False)
+    assert set(d) == {"model", "iteration", "optimizer", "learning_rate"} and d["iteration"] == 9
+    assert ckpt.latest_checkpoint_path(str(tmp_path), "G_*.pth").endswith("G_2333.pth")
+    ckpt.save_checkpoint(m, opt, 1e-4, 11, str(tmp_path / "G_latest.pth"))
+    assert ckpt.latest_checkpoint_path(str(tmp_path), "G_*.pth").endswith("G_latest.pth")   # prefers *latest*
+    m2 = torch.nn.Linear(4, 3)
+    _, _, lr, it = ckpt.load_checkpoint(str(tmp_path / "G_latest.pth"), m2, _Opt())
+    assert it == 11 and lr == 1e-4 and torch.equal(m2.weight, m.weight)
+    # shape-mismatched keys keep the model's own tensor (ckpt.py:33-46)
+    m3 = torch.nn.Linear(5, 3)
+    ckpt.load_checkpoint(str(p1), m3, None)
+    assert m3.weight.shape == (3, 5)
+    with pytest.raises(IndexError):
+        ckpt.latest_checkpoint_path(str(tmp_path), "D_*.pth")
+
+
+def test_stdout_protocol_lines():
+    from easevoice_trainer_amd.utils.connector import MultiProcessOutputConnector, ResponseStatus
+
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        c = MultiProcessOutputConnector()
+        c.write_loss(10, 1.5, {"loss/d/total": 2.0})
+        c.write_response(ResponseStatus.SUCCESS, "Finish train sovits", {"model_path": "/x"})
+    l1, l2 = buf.getvalue().strip().splitlines()
+    assert l1.startswith("loss-of-easevoice ") and json.loads(l1.split(" ", 1)[1]) == {"step": 10, "loss": 1.5, "loss/d/total": 2.0}
+    r = json.loads(l2[len("response-of-easevoice "):])
+    assert r == {"status": "success", "message": "Finish train sovits", "data": {"model_path": "/x"}, "uuid": None}
+
+
+def test_dirs_and_resume_file_selection():
+    from easevoice_trainer_amd.train.gpt import GPTTrain
+    from easevoice_trainer_amd.train.helper import get_gpt_train_dir, get_sovits_train_dir
+
+    assert get_sovits_train_dir("/p", "n") == "/p/models/sovits_train/n"
+    assert get_gpt_train_dir("/p", "n") == "/p/models/gpt_train/n"
+    assert "/models/sovits_train/sovits_" in get_sovits_train_dir("/p", "")
+    assert GPTTrain._get_newest_ckpt(["epoch=1-step=10.ckpt", "epoch=12-step=3.ckpt", "x.txt", "epoch=2-step=99.ckpt"]) == "epoch=12-step=3.ckpt"
+    assert GPTTrain._get_newest_ckpt([]) is None
+
+
+def test_param_arena_views_and_state_dict():
+    from easevoice_trainer_amd.runtime import ParamArena
+
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    a = ParamArena(m, "cpu")
+    assert all(torch.equal(m.state_dict()[k], v) for k, v in before.items())
+    a.param.zero_()
+    assert float(m[0].weight.abs().sum()) == 0.0          # parameters are views of the arena
+    m[1].bias.grad.fill_(2.0)
+    b, e = a.range_of("1.bias", 3)
+    assert torch.equal(a.grad[b:e], torch.full((3,), 2.0)) and b % 64 == 0
+    m.load_state_dict(before)                               # load_state_dict copies INTO the views
+    assert torch.equal(a.param[a.offsets["0.weight"]: a.offsets["0.weight"] + 35].view(7, 5), before["0.weight"])
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from easevoice_trainer_amd.dist import GradReducer
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r = GradReducer(world, bucket_bytes=4096)             # several buckets
+    torch.manual_seed(0)
+    params = torch.randn(5000)
+    if rank != 0:
+        params += 1.0
+    r.broadcast_params(params)
+    g = torch.full((5000,), float(rank + 1))
+    r.all_reduce(g)
+    s = torch.tensor([float(rank)])
+    r.all_reduce_scalars(s)
+    q.put((rank, float(params.sum()), float(g[0]), float(g[-1]), float(s)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert out[0][1] == out[1][1]                 # broadcast made the parameters identical
+    for _, _, g0, g1, s in out:
+        assert g0 == 3.0 and g1 == 3.0            # 1 + 2 summed over every bucket
+        assert s == 0.5                           # averaged scalar
+
+
+def test_dp_flat_average_equals_full_batch():
+    """the DP recipe of S2Engine (sum-all-reduce of the flat grad arena, 1/world folded into the optimiser's grad_scale)
+    equals the gradient of the mean loss over the global batch, for a loss that is a mean over samples"""
+    torch.manual_seed(1)
+    w = torch.randn(6, requires_grad=True)
+    x = torch.randn(8, 6)
+    full = ((x @ w) ** 2).mean()
+    (gf,) = torch.autograd.grad(full, w)
+    shards = [((x[i::2] @ w) ** 2).mean() for i in range(2)]
+    gs = sum(torch.autograd.grad(s, w)[0] for s in shards) * 0.5
+    assert torch.allclose(gf, gs, atol=1e-6)
