@@ -35,11 +35,22 @@ struct AP {
 
 // Counter-based dropout mask (attention dropout of SDPA, patched_mha_with_cache.py:452-454): a pure function of
 // (seed, b*H+h, query, key) so forward and both backward kernels regenerate the same mask with no storage.
+// Only 24-bit multiplies (full rate on CDNA; 32-bit integer multiplies are quarter rate) and xor-shifts.
+__device__ __forceinline__ unsigned drop_row(const AP& p, unsigned bh, int qi) {
+  const unsigned a = (bh << 11) ^ (unsigned)qi;                    // < 2^24 for B*H <= 8192, L <= 2048
+  return __umul24(a & 0xFFFFFFu, 0x9E3779u) ^ p.seed ^ (a >> 7);
+}
+__device__ __forceinline__ float drop_mult2(const AP& p, unsigned row, int kj) {
+  unsigned x = row + __umul24((unsigned)kj, 0x85EBCBu);
+  x ^= x >> 15;
+  x = __umul24(x & 0xFFFFFFu, 0x2C1B3Du) ^ (x >> 9);
+  x ^= x << 13;
+  x ^= x >> 17;
+  return x >= p.drop_thr ? p.keep_scale : 0.f;
+}
 __device__ __forceinline__ float drop_mult(const AP& p, unsigned bh, int qi, int kj) {
   if (p.drop_thr == 0u) return 1.f;
-  unsigned x = p.seed ^ (bh * 0x9E3779B1u) ^ ((unsigned)qi * 0x85EBCA77u) ^ ((unsigned)kj * 0xC2B2AE3Du);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x >= p.drop_thr ? p.keep_scale : 0.f;
+  return drop_mult2(p, drop_row(p, bh, qi), kj);
 }
 
 __device__ __forceinline__ bool visible(int qi, int kj, int x_len, int xl, int yl) {
@@ -74,6 +85,36 @@ constexpr int PITCH = D + 8;   // LDS row pitch in elements (80 B: 16-byte align
 __device__ __forceinline__ int slot32(int g, int e) { return e < 4 ? g * 4 + e : 16 + g * 4 + (e - 4); }
 
 // ---------------------------------------------------------------------------------------------------------
+// tile classification (wave-uniform): a 16-query x 32-key (or 32-query x 16-key) tile is
+//   FULL  : every (q, k) pair visible -> no per-element mask arithmetic
+//   EMPTY : no pair visible          -> the tile is skipped, MFMAs included
+//   MIXED : evaluate visible() per element
+// ---------------------------------------------------------------------------------------------------------
+enum { TILE_EMPTY = 0, TILE_FULL = 1, TILE_MIXED = 2 };
+
+__device__ __forceinline__ int classify(int q0, int q1, int k0, int k1, int L, int x_len, int xl, int yl) {
+  // q in [q0, q1], k in [k0, k1] (inclusive)
+  if (k0 >= L || q0 >= L) return TILE_EMPTY;
+  // keys: padding
+  int key_state;  // 0 none visible, 1 all unpadded, 2 mixed
+  if (k1 < x_len) key_state = k1 < xl ? 1 : (k0 >= xl ? 0 : 2);
+  else if (k0 >= x_len) key_state = (k1 - x_len < yl) ? 1 : ((k0 - x_len >= yl) ? 0 : 2);
+  else key_state = 2;
+  if (key_state == 0) return TILE_EMPTY;
+  // causal / prefix structure
+  int c_state;
+  if (q1 < x_len) c_state = k1 < x_len ? 1 : (k0 >= x_len ? 0 : 2);          // text rows see text keys only
+  else if (q0 >= x_len) c_state = k1 <= q0 ? 1 : (k0 > q1 ? 0 : 2);          // audio rows see keys <= row
+  else c_state = 2;
+  if (c_state == 0) return TILE_EMPTY;
+  if (k1 >= L || q1 >= L) return TILE_MIXED;
+  return (key_state == 1 && c_state == 1) ? TILE_FULL : TILE_MIXED;
+}
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// ---------------------------------------------------------------------------------------------------------
 // forward (bf16): block = 4 waves x 2 query tiles (128 queries) of one (b, h); key blocks of 64 through LDS
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
@@ -87,21 +128,24 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
+  const float sc2 = p.scale * LOG2E;
 
   bf16x8 qf[2];
   f32x4 ot[2][2];
   float m[2], l[2];
-  int qi[2];
+  int qi[2], qt0[2];
+  unsigned drow[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    qi[t] = qblk + wave * 32 + t * 16 + n;
+    qt0[t] = qblk + wave * 32 + t * 16;
+    qi[t] = qt0[t] + n;
     const int qc = min(qi[t], p.L - 1);
     qf[t] = ld8(Q + qc * p.sl + g * 8);
     ot[t][0] = ot[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     m[t] = -INFINITY;
     l[t] = 0.f;
+    drow[t] = drop_row(p, blockIdx.y, qi[t]);
   }
-  // keys this query block can see: text-only block -> text keys; otherwise up to its last row
   const int qlast = min(qblk + 127, p.L - 1);
   const int kmax = (qlast < p.x_len) ? p.x_len : qlast + 1;
   for (int kb = 0; kb < kmax; kb += 64) {
@@ -115,6 +159,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
     __syncthreads();
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
+      const int k0 = kb + sb * 32;
+      int cls[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
+      if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
       const bf16x8 ka0 = ld8(Ks + (sb * 32 + n) * PITCH + g * 8);
       const bf16x8 ka1 = ld8(Ks + (sb * 32 + 16 + n) * PITCH + g * 8);
       const bf16_t* vrow = Vs + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
@@ -122,33 +171,37 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
       const bf16x8 va1 = tr2(vrow + 16, vrow + 16 * PITCH + 16);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (cls[t] == TILE_EMPTY) continue;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
         const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
         float s[8];
-        float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int kj = kb + sb * 32 + slot32(g, e);
-          const float raw = (e < 4 ? s0[e] : s1[e - 4]) * p.scale;
-          s[e] = (kj < p.L && visible(qi[t], kj, p.x_len, xl, yl)) ? raw : -INFINITY;
-          mx = fmaxf(mx, s[e]);
+        for (int e = 0; e < 8; ++e) s[e] = (e < 4 ? s0[e] : s1[e - 4]) * sc2;
+        if (cls[t] == TILE_MIXED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int kj = k0 + slot32(g, e);
+            if (!(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) s[e] = -INFINITY;
+          }
         }
+        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m[t], mx);
         const bool dead = mn == -INFINITY;                 // nothing visible yet for this query
-        const float alpha = dead ? 1.f : __expf(m[t] - mn);
+        const float alpha = dead ? 1.f : fexp2(m[t] - mn);
         float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = dead ? 0.f : __expf(s[e] - mn); sum += s[e]; }
+        for (int e = 0; e < 8; ++e) { s[e] = dead ? 0.f : fexp2(s[e] - mn); sum += s[e]; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         l[t] = l[t] * alpha + sum;
         m[t] = mn;
-        if (p.drop_thr)
+        if (p.drop_thr) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s[e] *= drop_mult(p, blockIdx.y, qi[t], kb + sb * 32 + slot32(g, e));
+          for (int e = 0; e < 8; ++e) s[e] *= drop_mult2(p, drow[t], k0 + slot32(g, e));
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ot[t][0][r] *= alpha; ot[t][1][r] *= alpha; }
         const bf16x8 pf = pack8(s);
@@ -169,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
       for (int r = 0; r < 4; ++r) o4[r] = f2bf(ot[t][mt][r] * inv);
       *reinterpret_cast<uint2*>(O + qi[t] * p.ol + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
-    if (g == 0) p.lse[((long)b * p.H + h) * p.L + qi[t]] = m[t] + __logf(l[t]);
+    if (g == 0) p.lse[((long)b * p.H + h) * p.L + qi[t]] = (m[t] + __log2f(l[t])) * LN2;
   }
 }
 
@@ -188,19 +241,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
   const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
+  const float sc2 = p.scale * LOG2E;
   bf16x8 qf[2], dof[2];
   f32x4 dqt[2][2];
-  float lse[2], dl[2];
-  int qi[2];
+  float lse2[2], dl[2];
+  int qi[2], qt0[2];
+  unsigned drow[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    qi[t] = qblk + wave * 32 + t * 16 + n;
+    qt0[t] = qblk + wave * 32 + t * 16;
+    qi[t] = qt0[t] + n;
     const int qc = min(qi[t], p.L - 1);
     qf[t] = ld8(Q + qc * p.sl + g * 8);
     dof[t] = ld8(dO + qc * p.ol + g * 8);
-    lse[t] = p.lse[((long)b * p.H + h) * p.L + qc];
+    lse2[t] = p.lse[((long)b * p.H + h) * p.L + qc] * LOG2E;
     dl[t] = p.delta[((long)b * p.H + h) * p.L + qc];
     dqt[t][0] = dqt[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    drow[t] = drop_row(p, blockIdx.y, qi[t]);
   }
   const int qlast = min(qblk + 127, p.L - 1);
   const int kmax = (qlast < p.x_len) ? p.x_len : qlast + 1;
@@ -215,6 +272,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
     __syncthreads();
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
+      const int k0 = kb + sb * 32;
+      int cls[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
+      if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
       const bf16x8 ka0 = ld8(Ks + (sb * 32 + n) * PITCH + g * 8);
       const bf16x8 ka1 = ld8(Ks + (sb * 32 + 16 + n) * PITCH + g * 8);
       const bf16x8 va0 = ld8(Vs + (sb * 32 + n) * PITCH + g * 8);
@@ -224,6 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
       const bf16x8 kt1 = tr2(krow + 16, krow + 16 * PITCH + 16);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (cls[t] == TILE_EMPTY) continue;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
         const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
@@ -232,12 +295,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
         float ds[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int kj = kb + sb * 32 + slot32(g, e);
-          const float raw = (e < 4 ? s0[e] : s1[e - 4]) * p.scale;
-          const float dp = (e < 4 ? d0[e] : d1[e - 4]);
-          const bool vis = kj < p.L && visible(qi[t], kj, p.x_len, xl, yl);
-          const float pr = vis ? __expf(raw - lse[t]) : 0.f;
-          ds[e] = pr * (dp * drop_mult(p, blockIdx.y, qi[t], kj) - dl[t]) * p.scale;
+          const int kj = k0 + slot32(g, e);
+          float pr = fexp2((e < 4 ? s0[e] : s1[e - 4]) * sc2 - lse2[t]);
+          if (cls[t] == TILE_MIXED && !(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) pr = 0.f;
+          float dp = (e < 4 ? d0[e] : d1[e - 4]);
+          if (p.drop_thr) dp *= drop_mult2(p, drow[t], kj);
+          ds[e] = pr * (dp - dl[t]) * p.scale;
         }
         const bf16x8 dsf = pack8(ds);
         dqt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsf, dqt[t][0], 0, 0, 0);
@@ -275,18 +338,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
   const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
+  const float sc2 = p.scale * LOG2E;
   bf16x8 kf[2], vf[2];
   f32x4 dkt[2][2], dvt[2][2];
-  int kj[2];
+  int kj[2], kt0[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    kj[t] = kblk + wave * 32 + t * 16 + n;
+    kt0[t] = kblk + wave * 32 + t * 16;
+    kj[t] = kt0[t] + n;
     const int kc = min(kj[t], p.L - 1);
     kf[t] = ld8(K + kc * p.sl + g * 8);
     vf[t] = ld8(V + kc * p.sl + g * 8);
     dkt[t][0] = dkt[t][1] = dvt[t][0] = dvt[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // queries that can see this key block: text keys are seen by every row, audio keys only by rows >= the key
   const int q_begin = (kblk >= p.x_len) ? (kblk / 64) * 64 : 0;
   for (int qb = q_begin; qb < p.L; qb += 64) {
     __syncthreads();
@@ -297,13 +361,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
       *reinterpret_cast<uint4*>(Os + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(dO + qq * p.ol + c8 * 8);
       if (tid < 64) {
         const int q2 = min(qb + tid, p.L - 1);
-        lse_s[tid] = p.lse[((long)b * p.H + h) * p.L + q2];
+        lse_s[tid] = p.lse[((long)b * p.H + h) * p.L + q2] * LOG2E;
         dl_s[tid] = p.delta[((long)b * p.H + h) * p.L + q2];
       }
     }
     __syncthreads();
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
+      const int q0 = qb + sb * 32;
+      int cls[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) cls[t] = classify(q0, q0 + 31, kt0[t], kt0[t] + 15, p.L, p.x_len, xl, yl);
+      if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
       const bf16x8 qa0 = ld8(Qs + (sb * 32 + n) * PITCH + g * 8);
       const bf16x8 qa1 = ld8(Qs + (sb * 32 + 16 + n) * PITCH + g * 8);
       const bf16x8 oa0 = ld8(Os + (sb * 32 + n) * PITCH + g * 8);
@@ -313,10 +382,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
       const bf16x8 qt0 = tr2(qrow, qrow + 16 * PITCH), qt1 = tr2(qrow + 16, qrow + 16 * PITCH + 16);
       const bf16x8 dt0 = tr2(orow, orow + 16 * PITCH), dt1 = tr2(orow + 16, orow + 16 * PITCH + 16);
       float lq[8], dq8[8];
+      unsigned drw[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { lq[e] = lse_s[sb * 32 + slot32(g, e)]; dq8[e] = dl_s[sb * 32 + slot32(g, e)]; }
+      for (int e = 0; e < 8; ++e) {
+        lq[e] = lse_s[sb * 32 + slot32(g, e)];
+        dq8[e] = dl_s[sb * 32 + slot32(g, e)];
+        drw[e] = p.drop_thr ? drop_row(p, blockIdx.y, q0 + slot32(g, e)) : 0u;
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (cls[t] == TILE_EMPTY) continue;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[t], z, 0, 0, 0);
         const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[t], z, 0, 0, 0);
@@ -325,12 +400,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
         float pr[8], ds[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int qi = qb + sb * 32 + slot32(g, e);
-          const float raw = (e < 4 ? s0[e] : s1[e - 4]) * p.scale;
+          const int qi = q0 + slot32(g, e);
+          float pe = fexp2((e < 4 ? s0[e] : s1[e - 4]) * sc2 - lq[e]);
+          if (cls[t] == TILE_MIXED && !(qi < p.L && kj[t] < p.L && visible(qi, kj[t], p.x_len, xl, yl))) pe = 0.f;
+          const float dm = p.drop_thr ? drop_mult2(p, drw[e], kj[t]) : 1.f;
           const float dp = (e < 4 ? d0[e] : d1[e - 4]);
-          const bool vis = qi < p.L && kj[t] < p.L && visible(qi, kj[t], p.x_len, xl, yl);
-          const float pe = vis ? __expf(raw - lq[e]) : 0.f;
-          const float dm = drop_mult(p, blockIdx.y, qi, kj[t]);
           ds[e] = pe * (dp * dm - dq8[e]) * p.scale;
           pr[e] = pe * dm;
         }
@@ -358,22 +432,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
   }
 }
 
-// delta[b,h,q] = sum_d dO * O
+// delta[b,h,q] = sum_d dO * O ; rows walked in memory order (b, q, h), 16-byte loads, 64/V lanes per row
 template <typename T>
 __global__ void attn_delta(AP p, int Dh) {
-  const long total = (long)p.B * p.H * p.L;
+  constexpr int V = 16 / sizeof(T);
+  const int lpr = Dh / V;                           // lanes per row (4 for bf16 D=32, 8 for f32 D=32)
+  const long rows = (long)p.B * p.L * p.H;
   const T* O = reinterpret_cast<const T*>(p.o);
   const T* dO = reinterpret_cast<const T*>(p.d_o);
   float* delta = const_cast<float*>(p.delta);
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % p.L);
-    const int h = (int)((i / p.L) % p.H);
-    const int b = (int)(i / ((long)p.L * p.H));
-    const long off = b * p.ob + q * p.ol + h * p.oh;
-    float acc = 0.f;
-    for (int d = 0; d < Dh; ++d) acc += to_f<T>(O[off + d]) * to_f<T>(dO[off + d]);
-    delta[i] = acc;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long row = gid / lpr;
+  const int part = (int)(gid % lpr);
+  float acc = 0.f;
+  int q = 0, h = 0, b = 0;
+  if (row < rows) {
+    h = (int)(row % p.H);
+    q = (int)((row / p.H) % p.L);
+    b = (int)(row / ((long)p.H * p.L));
+    const long off = b * p.ob + q * p.ol + h * p.oh + part * V;
+    const uint4 a = *reinterpret_cast<const uint4*>(O + off);
+    const uint4 c = *reinterpret_cast<const uint4*>(dO + off);
+    const T* pa = reinterpret_cast<const T*>(&a);
+    const T* pc = reinterpret_cast<const T*>(&c);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc += to_f<T>(pa[e]) * to_f<T>(pc[e]);
   }
+  for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (row < rows && part == 0) delta[((long)b * p.H + h) * p.L + q] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -554,7 +640,8 @@ int evt_attn_prefixlm_bwd(const evt_attn_params* a, const void* q, const void* k
   p.dq = dq; p.dk = dk; p.dv = dv; p.x_lens = x_lens; p.y_lens = y_lens;
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)a->B * a->H * a->L;
-  const int dblocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  const int lpr = a->D / (a->dtype == EVT_DT_BF16 ? 8 : 4);
+  const int dblocks = (int)((total * lpr + 255) / 256);
   if (a->dtype == EVT_DT_BF16) {
     hipLaunchKernelGGL(attn_delta<bf16_t>, dim3(dblocks), dim3(256), 0, st, p, a->D);
     hipLaunchKernelGGL(attn_bwd_dkv_bf16, dim3((a->L + 127) / 128, a->B * a->H), dim3(256), 0, st, p);

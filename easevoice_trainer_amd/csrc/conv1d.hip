@@ -105,6 +105,67 @@ __device__ __forceinline__ uint4 fuse_load16(uint4 v, bool has_act, uint4 va, in
   return v;
 }
 
+// ---- software-pipeline helpers (kept as force-inlined functions with explicit array references: lambdas capturing
+//      the register arrays defeated SROA in the largest instantiations and spilled the prefetch registers) ----
+template <typename T, int CK, int WPT, int TPR>
+__device__ __forceinline__ void igemm_load_w(uint4 (&wr)[WPT], const T* wg, const ConvP& p, int ch, int tg, int TG,
+                                             int wrow, int wsub) {
+  constexpr int SZ = sizeof(T);
+  const int t0 = tg * TG;
+  const int ppr = min(TG, p.KHp - t0) * CK * SZ / 16;
+  const T* src = wg + ((long)(wrow * p.nchunk + ch) * p.KHp + t0) * CK;
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int piece = wsub + i * TPR;
+    wr[i] = piece < ppr ? *reinterpret_cast<const uint4*>(src + piece * (16 / SZ)) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+template <typename T, int CK, int WPT, int TPR>
+__device__ __forceinline__ void igemm_store_w(const uint4 (&wr)[WPT], unsigned char* ws, const ConvP& p, int tg, int TG,
+                                              int WROW, int wrow, int wsub) {
+  constexpr int SZ = sizeof(T);
+  const int ppr = min(TG, p.KHp - tg * TG) * CK * SZ / 16;
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int piece = wsub + i * TPR;
+    if (piece < ppr) *reinterpret_cast<uint4*>(ws + wrow * WROW + piece * 16) = wr[i];
+  }
+}
+
+template <typename T, int CK, int XPT>
+__device__ __forceinline__ void igemm_load_x(uint4 (&xr)[XPT], uint4 (&ar)[XPT], const T* xg, const T* ag,
+                                             const ConvP& p, int ch, int R, int row0, int lane) {
+  constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = lane + i * 64;
+    const int r = idx / LPR, part = idx - r * LPR;
+    const int in_row = row0 + r;
+    const bool ok = idx < R * LPR && in_row >= 0 && in_row < p.Lin;
+    const long off = ok ? (long)in_row * p.Cin + ch * CK + part * (16 / SZ) : 0;
+    xr[i] = ok ? *reinterpret_cast<const uint4*>(xg + off) : make_uint4(0, 0, 0, 0);
+    ar[i] = (ok && ag) ? *reinterpret_cast<const uint4*>(ag + off) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+template <typename T, int CK, int XPT>
+__device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
+                                              bool has_act, const ConvP& p, int R, int row0, int lane, int XROW) {
+  constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int idx = lane + i * 64;
+    const int r = idx / LPR, part = idx - r * LPR;
+    const int in_row = row0 + r;
+    if (idx < R * LPR) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (in_row >= 0 && in_row < p.Lin) v = fuse_load16<T>(xr[i], has_act, ar[i], p.xact_kind, p.xact_slope, p.in_slope);
+      *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
+    }
+  }
+}
+
 template <typename T, int CK, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
@@ -151,54 +212,49 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Software pipeline (register prefetch): the global loads of stage s+1 are issued before the MFMAs of stage s and
+  // only written to LDS after the next barrier, so HBM/L2 latency hides behind compute.  The fused load-side
+  // arithmetic (leaky-relu / activation derivative) is applied at LDS-write time so nothing waits on a load early.
+  constexpr int TPR = 256 / TM;                 // threads per weight row
+  constexpr int WPT = (WK * SZ / 16) / TPR;     // 16-byte weight pieces per thread per stage (= 2*MT)
+  constexpr int XPT = (SZ == 2 ? 8 : 16);       // 16-byte activation pieces per lane per chunk (host checks the fit)
   const int ngroups = (p.KHp + TG - 1) / TG;
-  for (int ch = 0; ch < p.nchunk; ++ch) {
-    for (int tg = 0; tg < ngroups; ++tg) {
-      __syncthreads();  // previous stage's fragment reads are done
-      if (tg == 0 && active) {
-        // stage this unit's activation rows for channel chunk `ch` (wave-private region)
-        for (int idx = lane; idx < R * LPR; idx += 64) {
-          const int r = idx / LPR, part = idx - r * LPR;
-          const int in_row = row0 + r;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (in_row >= 0 && in_row < p.Lin) {
-            const long off = (long)in_row * p.Cin + ch * CK + part * (16 / SZ);
-            v = *reinterpret_cast<const uint4*>(xg + off);
-            uint4 va = make_uint4(0, 0, 0, 0);
-            if (ag) va = *reinterpret_cast<const uint4*>(ag + off);
-            v = fuse_load16<T>(v, ag != nullptr, va, p.xact_kind, p.xact_slope, p.in_slope);
-          }
-          *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
-        }
-      }
-      // stage weights for taps [t0, t0+ntap) of chunk ch: TM rows of ntap*CK contiguous elements
+  const int nst = p.nchunk * ngroups;
+  uint4 wr[WPT], xr[XPT], ar[XPT];
+  const int wrow = tid / TPR, wsub = tid % TPR;
+
+  igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, 0, 0, TG, wrow, wsub);
+  if (active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, 0, R, row0, lane);
+  for (int st = 0; st < nst; ++st) {
+    const int ch = st / ngroups, tg = st - ch * ngroups;
+    __syncthreads();  // previous stage's fragment reads are done
+    if (tg == 0 && active) igemm_store_x<T, CK, XPT>(xr, ar, xs, ag != nullptr, p, R, row0, lane, XROW);
+    igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
+    __syncthreads();
+    if (st + 1 < nst) {
+      const int nch = (st + 1) / ngroups, ntg = (st + 1) - nch * ngroups;
+      igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, nch, ntg, TG, wrow, wsub);
+      if (ntg == 0 && active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, nch, R, row0, lane);
+    }
+    if (active) {
       const int t0 = tg * TG;
       const int ntap = min(TG, p.KHp - t0);
-      const int ppr = ntap * CK * SZ / 16;  // 16-byte pieces per row
-      for (int idx = tid; idx < TM * ppr; idx += 256) {
-        const int r = idx / ppr, piece = idx - r * ppr;
-        const T* src = wg + ((long)(r * p.nchunk + ch) * p.KHp + t0) * CK + piece * (16 / SZ);
-        *reinterpret_cast<uint4*>(ws + r * WROW + piece * 16) = *reinterpret_cast<const uint4*>(src);
-      }
-      __syncthreads();
-      if (active) {
-        const int steps = ntap * CK / KS;
-        for (int st = 0; st < steps; ++st) {
-          const int kl = st * KS + g * EPL;  // K index inside this weight stage: [tap][ci]
-          const int tl = kl / CK, ci = kl - tl * CK;
-          const int tap = t0 + tl;
-          frag_t a[MT], b[NT];
+      const int steps = ntap * CK / KS;
+      for (int k = 0; k < steps; ++k) {
+        const int kl = k * KS + g * EPL;  // K index inside this weight stage: [tap][ci]
+        const int tl = kl / CK, ci = kl - tl * CK;
+        const int tap = t0 + tl;
+        frag_t a[MT], b[NT];
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-            a[i] = *reinterpret_cast<const frag_t*>(ws + (i * 16 + n) * WROW + kl * SZ);
+        for (int i = 0; i < MT; ++i)
+          a[i] = *reinterpret_cast<const frag_t*>(ws + (i * 16 + n) * WROW + kl * SZ);
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            b[j] = *reinterpret_cast<const frag_t*>(xs + ((j * 16 + n) * p.s_in + tap * p.dil) * XROW + ci * SZ);
+        for (int j = 0; j < NT; ++j)
+          b[j] = *reinterpret_cast<const frag_t*>(xs + ((j * 16 + n) * p.s_in + tap * p.dil) * XROW + ci * SZ);
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
-        }
+          for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(a[i], b[j], acc[i][j]);
       }
     }
   }
@@ -753,6 +809,7 @@ int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
   const int R = (16 * NT - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
   const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * R * XROW;
   if (lds > 160 * 1024) return EVT_ENOTSUP;
+  if (R * (CK * SZ / 16) > 64 * (SZ == 2 ? 8 : 16)) return EVT_ENOTSUP;   // activation prefetch registers (XPT)
   static size_t max_set = 0;
   if (lds > 48 * 1024 && lds > max_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT>),

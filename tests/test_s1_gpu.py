@@ -32,11 +32,17 @@ ATTN_CASES = [  # B, H, x_len, y_len, x_lens, y_lens
 
 
 def _hash_keep(seed, bh, L_, thr):
+    """python mirror of drop_row / drop_mult2 in csrc/attention.hip (24-bit multiplies, xor-shifts, mod 2^32)"""
+    M, M24 = 0xFFFFFFFF, 0xFFFFFF
     q = torch.arange(L_, dtype=torch.int64)[:, None]
     k = torch.arange(L_, dtype=torch.int64)[None, :]
-    M = 0xFFFFFFFF
-    x = (seed ^ ((bh * 0x9E3779B1) & M) ^ ((q * 0x85EBCA77) & M) ^ ((k * 0xC2B2AE3D) & M)) & M
-    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M; x = x ^ (x >> 15); x = (x * 0x846ca68b) & M; x = x ^ (x >> 16)
+    a = ((bh << 11) & M) ^ q
+    row = (((a & M24) * 0x9E3779) & M) ^ seed ^ (a >> 7)
+    x = (row + ((k & M24) * 0x85EBCB & M)) & M
+    x = x ^ (x >> 15)
+    x = ((((x & M24) * 0x2C1B3D) & M) ^ (x >> 9)) & M
+    x = (x ^ (x << 13)) & M
+    x = x ^ (x >> 17)
     return x >= thr
 
 
