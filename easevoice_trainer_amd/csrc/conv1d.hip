@@ -166,7 +166,27 @@ __device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint
   }
 }
 
-template <typename T, int CK, int MT, int NT>
+// synchronous staging (also the overflow path of the prefetching variant for pieces beyond its register budget)
+template <typename T, int CK>
+__device__ __forceinline__ void igemm_stage_x_sync(unsigned char* xs, const T* xg, const T* ag, const ConvP& p, int ch,
+                                                   int R, int row0, int lane, int XROW, int first_idx) {
+  constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
+  for (int idx = first_idx + lane; idx < R * LPR; idx += 64) {
+    const int r = idx / LPR, part = idx - r * LPR;
+    const int in_row = row0 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (in_row >= 0 && in_row < p.Lin) {
+      const long off = (long)in_row * p.Cin + ch * CK + part * (16 / SZ);
+      v = *reinterpret_cast<const uint4*>(xg + off);
+      uint4 va = make_uint4(0, 0, 0, 0);
+      if (ag) va = *reinterpret_cast<const uint4*>(ag + off);
+      v = fuse_load16<T>(v, ag != nullptr, va, p.xact_kind, p.xact_slope, p.in_slope);
+    }
+    *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
+  }
+}
+
+template <typename T, int CK, int MT, int NT, bool PF>
 __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
   constexpr int TM = 16 * MT, PW = 16 * NT;
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int TG = WK / CK;                    // taps per weight stage
   constexpr int WROW = WK * SZ + 16;             // bytes per staged weight row
   constexpr int LPR = CK * SZ / 16;              // 16-byte pieces per x row
+  (void)LPR;
   typedef typename Frag<T>::type frag_t;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -217,21 +238,32 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   // arithmetic (leaky-relu / activation derivative) is applied at LDS-write time so nothing waits on a load early.
   constexpr int TPR = 256 / TM;                 // threads per weight row
   constexpr int WPT = (WK * SZ / 16) / TPR;     // 16-byte weight pieces per thread per stage (= 2*MT)
-  constexpr int XPT = (SZ == 2 ? 8 : 16);       // 16-byte activation pieces per lane per chunk (host checks the fit)
+  constexpr int XPT = PF ? (SZ == 2 ? 8 : 12) : 1;  // 16-byte activation pieces per lane held in registers
   const int ngroups = (p.KHp + TG - 1) / TG;
   const int nst = p.nchunk * ngroups;
   uint4 wr[WPT], xr[XPT], ar[XPT];
   const int wrow = tid / TPR, wsub = tid % TPR;
 
-  igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, 0, 0, TG, wrow, wsub);
-  if (active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, 0, R, row0, lane);
+  if (PF) {
+    igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, 0, 0, TG, wrow, wsub);
+    if (active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, 0, R, row0, lane);
+  }
   for (int st = 0; st < nst; ++st) {
     const int ch = st / ngroups, tg = st - ch * ngroups;
     __syncthreads();  // previous stage's fragment reads are done
-    if (tg == 0 && active) igemm_store_x<T, CK, XPT>(xr, ar, xs, ag != nullptr, p, R, row0, lane, XROW);
-    igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
+    if (PF) {
+      if (tg == 0 && active) {
+        igemm_store_x<T, CK, XPT>(xr, ar, xs, ag != nullptr, p, R, row0, lane, XROW);
+        if (R * LPR > 64 * XPT) igemm_stage_x_sync<T, CK>(xs, xg, ag, p, ch, R, row0, lane, XROW, 64 * XPT);
+      }
+      igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
+    } else {
+      if (tg == 0 && active) igemm_stage_x_sync<T, CK>(xs, xg, ag, p, ch, R, row0, lane, XROW, 0);
+      igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, ch, tg, TG, wrow, wsub);
+      igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
+    }
     __syncthreads();
-    if (st + 1 < nst) {
+    if (PF && st + 1 < nst) {
       const int nch = (st + 1) / ngroups, ntg = (st + 1) - nch * ngroups;
       igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, nch, ntg, TG, wrow, wsub);
       if (ntg == 0 && active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, nch, R, row0, lane);
@@ -809,17 +841,21 @@ int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
   const int R = (16 * NT - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
   const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * R * XROW;
   if (lds > 160 * 1024) return EVT_ENOTSUP;
-  if (R * (CK * SZ / 16) > 64 * (SZ == 2 ? 8 : 16)) return EVT_ENOTSUP;   // activation prefetch registers (XPT)
-  static size_t max_set = 0;
-  if (lds > 48 * 1024 && lds > max_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return EVT_ELAUNCH;
-    max_set = 160 * 1024;
+  // register prefetch pays only when there are several (chunk, tap-group) stages to overlap
+  constexpr int WKc = (SZ == 2 ? 256 : 128);
+  const int nst = p.nchunk * ceil_div(p.KHp, WKc / CK);
+  const bool pf = nst >= 3;
+  static size_t max_set[2] = {0, 0};
+  if (lds > 48 * 1024 && lds > max_set[pf]) {
+    const void* fn = pf ? reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, true>)
+                        : reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EVT_ELAUNCH;
+    max_set[pf] = 160 * 1024;
   }
   const int gx = 8 * ceil_div(p.P, 8) * p.Y;
-  evt_set_last_tag("conv_igemm<%s, %d, %d, %d>", SZ == 2 ? "bf16" : "f32", CK, MT, NT);
-  hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT>), dim3(gx, nphase), dim3(256), lds, st, p);
+  evt_set_last_tag("conv_igemm<%s, %d, %d, %d, %s>", SZ == 2 ? "bf16" : "f32", CK, MT, NT, pf ? "pf" : "sync");
+  if (pf) hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, true>), dim3(gx, nphase), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, false>), dim3(gx, nphase), dim3(256), lds, st, p);
   return evt_check_launch();
 }
 

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--B", type=int, default=16)
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -59,6 +61,8 @@ def main():
     shapes.append(("WN in 192->384 k5 T200", B, 200, 192, 384, 5, 1, 2, 1, 1, False, 1.0, 0))
     shapes.append(("conv_post 16->1 k7", B, 20480, 16, 1, 7, 1, 3, 1, 1, False, 0.01, 2))
 
+    if a.only:
+        shapes = [sh for sh in shapes if any(tok in sh[0] for tok in a.only.split(','))]
     mods = nn.ModuleList()
     for (_, nseq, Lx, ci, co, k, s, p, d, g, tr, slope, oact) in shapes:
         mods.append(HC.EvtConv1d(ci, co, k, s, p, d, g, bias=True, transposed=tr, weight_norm=True))
@@ -77,9 +81,9 @@ def main():
         lout = y.size(1)
         macs = nseq * (lout if not tr else Lx) * ci * co * k / g
         bytes_act = (x.numel() + y.numel()) * sz
-        t_f = time_fn(lambda: HC._fwd(slot, x, None, slope, oact, 0.1))
-        t_d = time_fn(lambda: HC._bwd_data(slot, dy, y, x, None, nseq, Lx, slope, oact, 0.1))
-        t_w = time_fn(lambda: HC._bwd_weight(slot, x, dy, y, nseq, Lx, slope, oact, 0.1))
+        t_f = time_fn(lambda: HC._fwd(slot, x, None, slope, oact, 0.1), iters=a.iters)
+        t_d = time_fn(lambda: HC._bwd_data(slot, dy, y, x, None, nseq, Lx, slope, oact, 0.1), iters=a.iters)
+        t_w = time_fn(lambda: HC._bwd_weight(slot, x, dy, y, nseq, Lx, slope, oact, 0.1), iters=a.iters)
         row = dict(name=name, gmac=macs / 1e9, fwd_ms=t_f, bwdd_ms=t_d, bwdw_ms=t_w,
                    fwd_tflops=2 * macs / t_f / 1e9, bwdd_tflops=2 * macs / t_d / 1e9, bwdw_tflops=2 * macs / t_w / 1e9,
                    fwd_gbs=bytes_act / t_f / 1e6)
