@@ -78,31 +78,44 @@ template <> struct Frag<bf16_t> {
   }
 };
 
-// 16 bytes of T, with the two load-side fusions applied in fp32 and re-rounded to T
+// 16 bytes of T with the load-side fusion applied in fp32 and re-rounded to T.  MODE is resolved ONCE per staging call
+// (a wave-uniform switch outside the piece loops) so the per-element code is branch-free:
+//   0 copy | 1 leaky-relu(in_slope) | 2 x * lrelu'(act) | 3 x * tanh'(act) | 4 generic (both fusions)
+template <typename T, int MODE>
+__device__ __forceinline__ uint4 fuse16(uint4 v, uint4 va, float act_slope, float in_slope, int act_kind) {
+  if (MODE == 0) return v;
+  constexpr int V = 16 / sizeof(T);
+  T* h = reinterpret_cast<T*>(&v);
+  const T* a = reinterpret_cast<const T*>(&va);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float t = to_f<T>(h[i]);
+    if (MODE == 1) t = t > 0.f ? t : t * in_slope;
+    else if (MODE == 2) t = to_f<T>(a[i]) > 0.f ? t : t * act_slope;
+    else if (MODE == 3) { const float y = to_f<T>(a[i]); t *= 1.f - y * y; }
+    else { t *= dact_from_out(act_kind, to_f<T>(a[i]), act_slope); t = t > 0.f ? t : t * in_slope; }
+    h[i] = from_f<T>(t);
+  }
+  return v;
+}
+
+__device__ __forceinline__ int fuse_mode(bool has_act, int act_kind, float in_slope) {
+  if (!has_act) return in_slope == 1.f ? 0 : 1;
+  if (in_slope != 1.f) return 4;
+  return act_kind == EVT_ACT_LRELU ? 2 : (act_kind == EVT_ACT_TANH ? 3 : 0);
+}
+
+// legacy entry used by the weight-gradient kernels (mode resolved per call, still branch-free per element)
 template <typename T>
 __device__ __forceinline__ uint4 fuse_load16(uint4 v, bool has_act, uint4 va, int act_kind, float act_slope,
                                              float in_slope) {
-  if (!has_act && in_slope == 1.f) return v;
-  if constexpr (sizeof(T) == 4) {
-    float* f = reinterpret_cast<float*>(&v);
-    const float* a = reinterpret_cast<const float*>(&va);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float t = f[i];
-      if (has_act) t *= dact_from_out(act_kind, a[i], act_slope);
-      f[i] = lrelu_f(t, in_slope);
-    }
-  } else {
-    bf16_t* h = reinterpret_cast<bf16_t*>(&v);
-    const bf16_t* a = reinterpret_cast<const bf16_t*>(&va);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float t = bf2f(h[i]);
-      if (has_act) t *= dact_from_out(act_kind, bf2f(a[i]), act_slope);
-      h[i] = f2bf(lrelu_f(t, in_slope));
-    }
+  switch (fuse_mode(has_act, act_kind, in_slope)) {
+    case 0: return v;
+    case 1: return fuse16<T, 1>(v, va, act_slope, in_slope, act_kind);
+    case 2: return fuse16<T, 2>(v, va, act_slope, in_slope, act_kind);
+    case 3: return fuse16<T, 3>(v, va, act_slope, in_slope, act_kind);
+    default: return fuse16<T, 4>(v, va, act_slope, in_slope, act_kind);
   }
-  return v;
 }
 
 // ---- software-pipeline helpers (kept as force-inlined functions with explicit array references: lambdas capturing
@@ -149,9 +162,9 @@ __device__ __forceinline__ void igemm_load_x(uint4 (&xr)[XPT], uint4 (&ar)[XPT],
   }
 }
 
-template <typename T, int CK, int XPT>
-__device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
-                                              bool has_act, const ConvP& p, int R, int row0, int lane, int XROW) {
+template <typename T, int CK, int XPT, int MODE>
+__device__ __forceinline__ void igemm_store_x_m(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
+                                                const ConvP& p, int R, int row0, int lane, int XROW) {
   constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -159,17 +172,30 @@ __device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint
     const int r = idx / LPR, part = idx - r * LPR;
     const int in_row = row0 + r;
     if (idx < R * LPR) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (in_row >= 0 && in_row < p.Lin) v = fuse_load16<T>(xr[i], has_act, ar[i], p.xact_kind, p.xact_slope, p.in_slope);
+      const bool ok = in_row >= 0 && in_row < p.Lin;
+      uint4 v = fuse16<T, MODE>(xr[i], ar[i], p.xact_slope, p.in_slope, p.xact_kind);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
     }
   }
 }
 
+template <typename T, int CK, int XPT>
+__device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
+                                              int mode, const ConvP& p, int R, int row0, int lane, int XROW) {
+  switch (mode) {
+    case 0: igemm_store_x_m<T, CK, XPT, 0>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 1: igemm_store_x_m<T, CK, XPT, 1>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 2: igemm_store_x_m<T, CK, XPT, 2>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 3: igemm_store_x_m<T, CK, XPT, 3>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    default: igemm_store_x_m<T, CK, XPT, 4>(xr, ar, xs, p, R, row0, lane, XROW); break;
+  }
+}
+
 // synchronous staging (also the overflow path of the prefetching variant for pieces beyond its register budget)
-template <typename T, int CK>
-__device__ __forceinline__ void igemm_stage_x_sync(unsigned char* xs, const T* xg, const T* ag, const ConvP& p, int ch,
-                                                   int R, int row0, int lane, int XROW, int first_idx) {
+template <typename T, int CK, int MODE>
+__device__ __forceinline__ void igemm_stage_x_sync_m(unsigned char* xs, const T* xg, const T* ag, const ConvP& p, int ch,
+                                                     int R, int row0, int lane, int XROW, int first_idx) {
   constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
   for (int idx = first_idx + lane; idx < R * LPR; idx += 64) {
     const int r = idx / LPR, part = idx - r * LPR;
@@ -179,10 +205,22 @@ __device__ __forceinline__ void igemm_stage_x_sync(unsigned char* xs, const T* x
       const long off = (long)in_row * p.Cin + ch * CK + part * (16 / SZ);
       v = *reinterpret_cast<const uint4*>(xg + off);
       uint4 va = make_uint4(0, 0, 0, 0);
-      if (ag) va = *reinterpret_cast<const uint4*>(ag + off);
-      v = fuse_load16<T>(v, ag != nullptr, va, p.xact_kind, p.xact_slope, p.in_slope);
+      if (MODE >= 2) va = *reinterpret_cast<const uint4*>(ag + off);
+      v = fuse16<T, MODE>(v, va, p.xact_slope, p.in_slope, p.xact_kind);
     }
     *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
+  }
+}
+
+template <typename T, int CK>
+__device__ __forceinline__ void igemm_stage_x_sync(unsigned char* xs, const T* xg, const T* ag, int mode, const ConvP& p,
+                                                   int ch, int R, int row0, int lane, int XROW, int first_idx) {
+  switch (mode) {
+    case 0: igemm_stage_x_sync_m<T, CK, 0>(xs, xg, ag, p, ch, R, row0, lane, XROW, first_idx); break;
+    case 1: igemm_stage_x_sync_m<T, CK, 1>(xs, xg, ag, p, ch, R, row0, lane, XROW, first_idx); break;
+    case 2: igemm_stage_x_sync_m<T, CK, 2>(xs, xg, ag, p, ch, R, row0, lane, XROW, first_idx); break;
+    case 3: igemm_stage_x_sync_m<T, CK, 3>(xs, xg, ag, p, ch, R, row0, lane, XROW, first_idx); break;
+    default: igemm_stage_x_sync_m<T, CK, 4>(xs, xg, ag, p, ch, R, row0, lane, XROW, first_idx); break;
   }
 }
 
@@ -191,10 +229,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
   constexpr int TM = 16 * MT, PW = 16 * NT;
   constexpr int SZ = sizeof(T);
-  constexpr int XROW = CK * SZ + 16;             // bytes per staged x row (pad breaks pow2 pitch)
+  // row pitches in 16-byte slots are 2 x odd: ds_read_b128 lane groups then hit 16 distinct slots (no bank conflict)
+  constexpr int XROW = SZ == 4 ? CK * SZ + 16 : (CK == 16 ? 32 : 96);   // fp32 (ds_read_b32) keeps the +16 pitch
   constexpr int WK = (SZ == 2 ? 256 : 128);      // K elements per weight stage
   constexpr int TG = WK / CK;                    // taps per weight stage
-  constexpr int WROW = WK * SZ + 16;             // bytes per staged weight row
+  constexpr int WROW = WK * SZ + (SZ == 4 ? 16 : 32);  // bytes per staged weight row (bf16: 34 slots)
   constexpr int LPR = CK * SZ / 16;              // 16-byte pieces per x row
   (void)LPR;
   typedef typename Frag<T>::type frag_t;
@@ -243,6 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   const int nst = p.nchunk * ngroups;
   uint4 wr[WPT], xr[XPT], ar[XPT];
   const int wrow = tid / TPR, wsub = tid % TPR;
+  const int fmode = fuse_mode(ag != nullptr, p.xact_kind, p.in_slope);
 
   if (PF) {
     igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, 0, 0, TG, wrow, wsub);
@@ -253,12 +293,12 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
     __syncthreads();  // previous stage's fragment reads are done
     if (PF) {
       if (tg == 0 && active) {
-        igemm_store_x<T, CK, XPT>(xr, ar, xs, ag != nullptr, p, R, row0, lane, XROW);
-        if (R * LPR > 64 * XPT) igemm_stage_x_sync<T, CK>(xs, xg, ag, p, ch, R, row0, lane, XROW, 64 * XPT);
+        igemm_store_x<T, CK, XPT>(xr, ar, xs, fmode, p, R, row0, lane, XROW);
+        if (R * LPR > 64 * XPT) igemm_stage_x_sync<T, CK>(xs, xg, ag, fmode, p, ch, R, row0, lane, XROW, 64 * XPT);
       }
       igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
     } else {
-      if (tg == 0 && active) igemm_stage_x_sync<T, CK>(xs, xg, ag, p, ch, R, row0, lane, XROW, 0);
+      if (tg == 0 && active) igemm_stage_x_sync<T, CK>(xs, xg, ag, fmode, p, ch, R, row0, lane, XROW, 0);
       igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, ch, tg, TG, wrow, wsub);
       igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
     }
@@ -835,9 +875,9 @@ inline void pick_ck(int dtype, int b, int k, int stride_unused, int* ck, int* nc
 template <typename T, int CK, int MT, int NT>
 int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
   constexpr int SZ = sizeof(T);
-  constexpr int XROW = CK * SZ + 16;
+  constexpr int XROW = SZ == 4 ? CK * SZ + 16 : (CK == 16 ? 32 : 96);   // fp32 (ds_read_b32) keeps the +16 pitch
   constexpr int WK = (SZ == 2 ? 256 : 128);
-  constexpr int WROW = WK * SZ + 16;
+  constexpr int WROW = WK * SZ + (SZ == 4 ? 16 : 32);
   const int R = (16 * NT - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
   const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * R * XROW;
   if (lds > 160 * 1024) return EVT_ENOTSUP;

@@ -24,10 +24,10 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint3
 
 // round-to-nearest-even, NaN preserved (same rounding torch uses for float -> bfloat16)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const uint32_t u = __float_as_uint(f);
+  const uint32_t rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t nan = (u >> 16) | 0x40u;
+  return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);   // select, no branch
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
