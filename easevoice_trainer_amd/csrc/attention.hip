@@ -112,6 +112,26 @@ __device__ __forceinline__ int classify(int q0, int q1, int k0, int k1, int L, i
 }
 
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// all-reduce over the four lanes {n, n+16, n+32, n+48} that hold one query's scores, with the gfx950 VALU lane-swap
+// instructions instead of LDS-pipe shuffles: v_permlane32_swap exchanges the upper half of one operand with the lower
+// half of the other, v_permlane16_swap exchanges odd 16-lane rows with even rows.
+__device__ __forceinline__ float quad_max(float v) {
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  u = __float_as_uint(v);
+  auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  u = __float_as_uint(v);
+  auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // ---------------------------------------------------------------------------------------------------------
@@ -186,16 +206,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
           }
         }
         float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_max(mx);
         const float mn = fmaxf(m[t], mx);
         const bool dead = mn == -INFINITY;                 // nothing visible yet for this query
         const float alpha = dead ? 1.f : fexp2(m[t] - mn);
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = dead ? 0.f : fexp2(s[e] - mn); sum += s[e]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = quad_sum(sum);
         l[t] = l[t] * alpha + sum;
         m[t] = mn;
         if (p.drop_thr) {

@@ -146,53 +146,54 @@ __device__ __forceinline__ void igemm_store_w(const uint4 (&wr)[WPT], unsigned c
   }
 }
 
-template <typename T, int CK, int XPT>
+// region = a run of R rows of ONE sequence staged for one (or NT) 16-position tiles; a lane keeps XPR 16-byte pieces of
+// it in xr[I0 .. I0+XPR)
+template <typename T, int CK, int XPT, int I0, int XPR>
 __device__ __forceinline__ void igemm_load_x(uint4 (&xr)[XPT], uint4 (&ar)[XPT], const T* xg, const T* ag,
                                              const ConvP& p, int ch, int R, int row0, int lane) {
   constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
 #pragma unroll
-  for (int i = 0; i < XPT; ++i) {
+  for (int i = 0; i < XPR; ++i) {
     const int idx = lane + i * 64;
     const int r = idx / LPR, part = idx - r * LPR;
     const int in_row = row0 + r;
     const bool ok = idx < R * LPR && in_row >= 0 && in_row < p.Lin;
     const long off = ok ? (long)in_row * p.Cin + ch * CK + part * (16 / SZ) : 0;
-    xr[i] = ok ? *reinterpret_cast<const uint4*>(xg + off) : make_uint4(0, 0, 0, 0);
-    ar[i] = (ok && ag) ? *reinterpret_cast<const uint4*>(ag + off) : make_uint4(0, 0, 0, 0);
+    xr[I0 + i] = ok ? *reinterpret_cast<const uint4*>(xg + off) : make_uint4(0, 0, 0, 0);
+    ar[I0 + i] = (ok && ag) ? *reinterpret_cast<const uint4*>(ag + off) : make_uint4(0, 0, 0, 0);
   }
 }
 
-template <typename T, int CK, int XPT, int MODE>
+template <typename T, int CK, int XPT, int I0, int XPR, int MODE>
 __device__ __forceinline__ void igemm_store_x_m(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
                                                 const ConvP& p, int R, int row0, int lane, int XROW) {
   constexpr int SZ = sizeof(T), LPR = CK * SZ / 16;
 #pragma unroll
-  for (int i = 0; i < XPT; ++i) {
+  for (int i = 0; i < XPR; ++i) {
     const int idx = lane + i * 64;
     const int r = idx / LPR, part = idx - r * LPR;
     const int in_row = row0 + r;
     if (idx < R * LPR) {
       const bool ok = in_row >= 0 && in_row < p.Lin;
-      uint4 v = fuse16<T, MODE>(xr[i], ar[i], p.xact_slope, p.in_slope, p.xact_kind);
+      uint4 v = fuse16<T, MODE>(xr[I0 + i], ar[I0 + i], p.xact_slope, p.in_slope, p.xact_kind);
       if (!ok) v = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(xs + r * XROW + part * 16) = v;
     }
   }
 }
 
-template <typename T, int CK, int XPT>
+template <typename T, int CK, int XPT, int I0, int XPR>
 __device__ __forceinline__ void igemm_store_x(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
                                               int mode, const ConvP& p, int R, int row0, int lane, int XROW) {
   switch (mode) {
-    case 0: igemm_store_x_m<T, CK, XPT, 0>(xr, ar, xs, p, R, row0, lane, XROW); break;
-    case 1: igemm_store_x_m<T, CK, XPT, 1>(xr, ar, xs, p, R, row0, lane, XROW); break;
-    case 2: igemm_store_x_m<T, CK, XPT, 2>(xr, ar, xs, p, R, row0, lane, XROW); break;
-    case 3: igemm_store_x_m<T, CK, XPT, 3>(xr, ar, xs, p, R, row0, lane, XROW); break;
-    default: igemm_store_x_m<T, CK, XPT, 4>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 0: igemm_store_x_m<T, CK, XPT, I0, XPR, 0>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 1: igemm_store_x_m<T, CK, XPT, I0, XPR, 1>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 2: igemm_store_x_m<T, CK, XPT, I0, XPR, 2>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    case 3: igemm_store_x_m<T, CK, XPT, I0, XPR, 3>(xr, ar, xs, p, R, row0, lane, XROW); break;
+    default: igemm_store_x_m<T, CK, XPT, I0, XPR, 4>(xr, ar, xs, p, R, row0, lane, XROW); break;
   }
 }
 
-// synchronous staging (also the overflow path of the prefetching variant for pieces beyond its register budget)
 template <typename T, int CK, int MODE>
 __device__ __forceinline__ void igemm_stage_x_sync_m(unsigned char* xs, const T* xg, const T* ag, const ConvP& p, int ch,
                                                      int R, int row0, int lane, int XROW, int first_idx) {
@@ -224,7 +225,38 @@ __device__ __forceinline__ void igemm_stage_x_sync(unsigned char* xs, const T* x
   }
 }
 
-template <typename T, int CK, int MT, int NT, bool PF>
+// region loop helper: compile-time recursion over the (at most 4) regions of a wave
+template <typename T, int CK, int XPT, int XPR, int NREG, int J>
+struct RegionOps {
+  static __device__ __forceinline__ void load(uint4 (&xr)[XPT], uint4 (&ar)[XPT], const T* const (&xg)[NREG],
+                                              const T* const (&ag)[NREG], const bool (&ract)[NREG], const ConvP& p,
+                                              int ch, int Rr, const int (&rrow0)[NREG], int lane) {
+    if (ract[J]) igemm_load_x<T, CK, XPT, J * XPR, XPR>(xr, ar, xg[J], ag[J], p, ch, Rr, rrow0[J], lane);
+    if constexpr (J + 1 < NREG) RegionOps<T, CK, XPT, XPR, NREG, J + 1>::load(xr, ar, xg, ag, ract, p, ch, Rr, rrow0, lane);
+  }
+  static __device__ __forceinline__ void store(const uint4 (&xr)[XPT], const uint4 (&ar)[XPT], unsigned char* xs,
+                                               const T* const (&xg)[NREG], const T* const (&ag)[NREG],
+                                               const bool (&ract)[NREG], int mode, const ConvP& p, int ch, int Rr,
+                                               const int (&rrow0)[NREG], int lane, int XROW, bool prefetched) {
+    constexpr int LPR = CK * sizeof(T) / 16;
+    if (ract[J]) {
+      unsigned char* base = xs + J * Rr * XROW;
+      if (prefetched) {
+        igemm_store_x<T, CK, XPT, J * XPR, XPR>(xr, ar, base, mode, p, Rr, rrow0[J], lane, XROW);
+        if (Rr * LPR > 64 * XPR) igemm_stage_x_sync<T, CK>(base, xg[J], ag[J], mode, p, ch, Rr, rrow0[J], lane, XROW, 64 * XPR);
+      } else {
+        igemm_stage_x_sync<T, CK>(base, xg[J], ag[J], mode, p, ch, Rr, rrow0[J], lane, XROW, 0);
+      }
+    }
+    if constexpr (J + 1 < NREG)
+      RegionOps<T, CK, XPT, XPR, NREG, J + 1>::store(xr, ar, xs, xg, ag, ract, mode, p, ch, Rr, rrow0, lane, XROW, prefetched);
+  }
+};
+
+// SPLIT = false: a wave owns 16*NT CONSECUTIVE positions of one sequence (one staged region, halo shared).
+// SPLIT = true : a wave owns NT independent 16-position units that may belong to different sequences (NT regions);
+//                short sequences (DiscriminatorP with period 5/7/11: 23..51 positions) keep the 4x4 register tiling.
+template <typename T, int CK, int MT, int NT, bool PF, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int EPL = Frag<T>::EPL, KS = Frag<T>::KS;
   constexpr int TM = 16 * MT, PW = 16 * NT;
@@ -234,8 +266,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   constexpr int WK = (SZ == 2 ? 256 : 128);      // K elements per weight stage
   constexpr int TG = WK / CK;                    // taps per weight stage
   constexpr int WROW = WK * SZ + (SZ == 4 ? 16 : 32);  // bytes per staged weight row (bf16: 34 slots)
-  constexpr int LPR = CK * SZ / 16;              // 16-byte pieces per x row
-  (void)LPR;
+  constexpr int NREG = SPLIT ? NT : 1;
   typedef typename Frag<T>::type frag_t;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -251,18 +282,28 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   if (pb >= p.P) return;
   const int phase = blockIdx.y;
 
-  const int R = (PW - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;  // staged rows per unit
+  // rows staged per region
+  const int Rr = ((SPLIT ? 16 : PW) - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
   unsigned char* ws = smem;
-  unsigned char* xs = smem + TM * WROW + wave * (R * XROW);
+  unsigned char* xs = smem + TM * WROW + wave * (NREG * Rr * XROW);
 
-  const long u = (long)pb * 4 + wave;
-  const bool active = u < (long)p.nseq * p.U;
-  const int seq = active ? (int)(u / p.U) : 0;
-  const int q0 = active ? (int)(u % p.U) * PW : 0;
-  const int row0 = q0 * p.s_in + p.off_in;
-
-  const T* xg = reinterpret_cast<const T*>(p.x) + (long)seq * p.Lin * p.Cin;
-  const T* ag = p.xact ? reinterpret_cast<const T*>(p.xact) + (long)seq * p.Lin * p.Cin : nullptr;
+  // units: p.U units per sequence, each SPLIT ? 16 : PW positions
+  bool ract[NREG];
+  int rseq[NREG], rq0[NREG], rrow0[NREG];
+  const T* xg[NREG];
+  const T* ag[NREG];
+  bool active = false;
+#pragma unroll
+  for (int j = 0; j < NREG; ++j) {
+    const long u = ((long)pb * 4 + wave) * NREG + j;
+    ract[j] = u < (long)p.nseq * p.U;
+    rseq[j] = ract[j] ? (int)(u / p.U) : 0;
+    rq0[j] = ract[j] ? (int)(u % p.U) * (SPLIT ? 16 : PW) : 0;
+    rrow0[j] = rq0[j] * p.s_in + p.off_in;
+    xg[j] = reinterpret_cast<const T*>(p.x) + (long)rseq[j] * p.Lin * p.Cin;
+    ag[j] = p.xact ? reinterpret_cast<const T*>(p.xact) + (long)rseq[j] * p.Lin * p.Cin : nullptr;
+    active = active || ract[j];
+  }
   const T* wg = reinterpret_cast<const T*>(p.w) + (long)phase * p.w_phase_stride +
                 (long)yi * TM * p.nchunk * p.KHp * CK;
 
@@ -277,36 +318,30 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   // arithmetic (leaky-relu / activation derivative) is applied at LDS-write time so nothing waits on a load early.
   constexpr int TPR = 256 / TM;                 // threads per weight row
   constexpr int WPT = (WK * SZ / 16) / TPR;     // 16-byte weight pieces per thread per stage (= 2*MT)
-  constexpr int XPT = PF ? (SZ == 2 ? 8 : 12) : 1;  // 16-byte activation pieces per lane held in registers
+  constexpr int XPT = PF ? (SZ == 2 ? 8 : 12) : NREG;  // 16-byte activation pieces per lane held in registers
+  constexpr int XPR = XPT / NREG;               // ... per region
   const int ngroups = (p.KHp + TG - 1) / TG;
   const int nst = p.nchunk * ngroups;
   uint4 wr[WPT], xr[XPT], ar[XPT];
   const int wrow = tid / TPR, wsub = tid % TPR;
-  const int fmode = fuse_mode(ag != nullptr, p.xact_kind, p.in_slope);
+  const int fmode = fuse_mode(p.xact != nullptr, p.xact_kind, p.in_slope);
+  typedef RegionOps<T, CK, XPT, XPR, NREG, 0> RO;
 
   if (PF) {
     igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, 0, 0, TG, wrow, wsub);
-    if (active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, 0, R, row0, lane);
+    RO::load(xr, ar, xg, ag, ract, p, 0, Rr, rrow0, lane);
   }
   for (int st = 0; st < nst; ++st) {
     const int ch = st / ngroups, tg = st - ch * ngroups;
     __syncthreads();  // previous stage's fragment reads are done
-    if (PF) {
-      if (tg == 0 && active) {
-        igemm_store_x<T, CK, XPT>(xr, ar, xs, fmode, p, R, row0, lane, XROW);
-        if (R * LPR > 64 * XPT) igemm_stage_x_sync<T, CK>(xs, xg, ag, fmode, p, ch, R, row0, lane, XROW, 64 * XPT);
-      }
-      igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
-    } else {
-      if (tg == 0 && active) igemm_stage_x_sync<T, CK>(xs, xg, ag, fmode, p, ch, R, row0, lane, XROW, 0);
-      igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, ch, tg, TG, wrow, wsub);
-      igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
-    }
+    if (tg == 0) RO::store(xr, ar, xs, xg, ag, ract, fmode, p, ch, Rr, rrow0, lane, XROW, PF);
+    if (!PF) igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, ch, tg, TG, wrow, wsub);
+    igemm_store_w<T, CK, WPT, TPR>(wr, ws, p, tg, TG, WROW, wrow, wsub);
     __syncthreads();
     if (PF && st + 1 < nst) {
       const int nch = (st + 1) / ngroups, ntg = (st + 1) - nch * ngroups;
       igemm_load_w<T, CK, WPT, TPR>(wr, wg, p, nch, ntg, TG, wrow, wsub);
-      if (ntg == 0 && active) igemm_load_x<T, CK, XPT>(xr, ar, xg, ag, p, nch, R, row0, lane);
+      if (ntg == 0) RO::load(xr, ar, xg, ag, ract, p, nch, Rr, rrow0, lane);
     }
     if (active) {
       const int t0 = tg * TG;
@@ -321,8 +356,10 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
         for (int i = 0; i < MT; ++i)
           a[i] = *reinterpret_cast<const frag_t*>(ws + (i * 16 + n) * WROW + kl * SZ);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          b[j] = *reinterpret_cast<const frag_t*>(xs + ((j * 16 + n) * p.s_in + tap * p.dil) * XROW + ci * SZ);
+        for (int j = 0; j < NT; ++j) {
+          const int rowj = SPLIT ? j * Rr + n * p.s_in : (j * 16 + n) * p.s_in;
+          b[j] = *reinterpret_cast<const frag_t*>(xs + (rowj + tap * p.dil) * XROW + ci * SZ);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -333,14 +370,16 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
   if (!active) return;
 
   // epilogue: lane holds rows (channels) g*4..g*4+3, column (position) n of each 16x16 tile
-  T* yg = reinterpret_cast<T*>(p.y) + (long)seq * p.Lout * p.Cout;
-  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long)seq * p.Lout * p.Cout : nullptr;
-  const T* gg = p.gate ? reinterpret_cast<const T*>(p.gate) + (long)seq * p.Lout * p.Cout : nullptr;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int q = q0 + j * 16 + n;
+    const int rj = SPLIT ? j : 0;
+    const int q = SPLIT ? rq0[rj] + n : rq0[0] + j * 16 + n;
     const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
-    if (q >= p.Q || orow < 0 || orow >= p.Lout) continue;
+    if (!ract[rj] || q >= p.Q || orow < 0 || orow >= p.Lout) continue;
+    const long sbase = (long)rseq[rj] * p.Lout * p.Cout;
+    T* yg = reinterpret_cast<T*>(p.y) + sbase;
+    const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + sbase : nullptr;
+    const T* gg = p.gate ? reinterpret_cast<const T*>(p.gate) + sbase : nullptr;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int co = yi * TM + i * 16 + g * 4;
@@ -873,47 +912,59 @@ inline void pick_ck(int dtype, int b, int k, int stride_unused, int* ck, int* nc
 }
 
 template <typename T, int CK, int MT, int NT>
-int launch_igemm_inst(const ConvP& p, int nphase, hipStream_t st) {
+int launch_igemm_inst(const ConvP& p, int nphase, bool split, hipStream_t st) {
   constexpr int SZ = sizeof(T);
-  constexpr int XROW = SZ == 4 ? CK * SZ + 16 : (CK == 16 ? 32 : 96);   // fp32 (ds_read_b32) keeps the +16 pitch
+  constexpr int XROW = SZ == 4 ? CK * SZ + 16 : (CK == 16 ? 32 : 96);
   constexpr int WK = (SZ == 2 ? 256 : 128);
   constexpr int WROW = WK * SZ + (SZ == 4 ? 16 : 32);
-  const int R = (16 * NT - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
-  const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * R * XROW;
+  const int nreg = split ? NT : 1;
+  const int Rr = ((split ? 16 : 16 * NT) - 1) * p.s_in + (p.KHp - 1) * p.dil + 1;
+  const size_t lds = (size_t)16 * MT * WROW + (size_t)4 * nreg * Rr * XROW;
   if (lds > 160 * 1024) return EVT_ENOTSUP;
   // register prefetch pays only when there are several (chunk, tap-group) stages to overlap
-  constexpr int WKc = (SZ == 2 ? 256 : 128);
-  const int nst = p.nchunk * ceil_div(p.KHp, WKc / CK);
-  const bool pf = nst >= 3;
-  static size_t max_set[2] = {0, 0};
-  if (lds > 48 * 1024 && lds > max_set[pf]) {
-    const void* fn = pf ? reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, true>)
-                        : reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, false>);
+  const int nst = p.nchunk * ceil_div(p.KHp, WK / CK);
+  const bool pf = nst >= 3 || split;
+  const void* fn;
+  if constexpr (NT > 1) {
+    fn = split ? reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, true, true>)
+               : (pf ? reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, true, false>)
+                     : reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, false, false>));
+  } else {
+    fn = pf ? reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, true, false>)
+            : reinterpret_cast<const void*>(&conv_igemm<T, CK, MT, NT, false, false>);
+  }
+  static size_t max_set[3] = {0, 0, 0};
+  const int vi = split ? 2 : (pf ? 1 : 0);
+  if (lds > 48 * 1024 && lds > max_set[vi]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EVT_ELAUNCH;
-    max_set[pf] = 160 * 1024;
+    max_set[vi] = 160 * 1024;
   }
   const int gx = 8 * ceil_div(p.P, 8) * p.Y;
-  evt_set_last_tag("conv_igemm<%s, %d, %d, %d, %s>", SZ == 2 ? "bf16" : "f32", CK, MT, NT, pf ? "pf" : "sync");
-  if (pf) hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, true>), dim3(gx, nphase), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, false>), dim3(gx, nphase), dim3(256), lds, st, p);
+  evt_set_last_tag("conv_igemm<%s, %d, %d, %d, %s>", SZ == 2 ? "bf16" : "f32", CK, MT, NT,
+                   split ? "split" : (pf ? "pf" : "sync"));
+  if constexpr (NT > 1) {
+    if (split) { hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, true, true>), dim3(gx, nphase), dim3(256), lds, st, p); return evt_check_launch(); }
+  }
+  if (pf) hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, true, false>), dim3(gx, nphase), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_igemm<T, CK, MT, NT, false, false>), dim3(gx, nphase), dim3(256), lds, st, p);
   return evt_check_launch();
 }
 
 template <typename T, int CK, int MT>
-int launch_igemm_nt(const ConvP& p, int NT, int nphase, hipStream_t st) {
+int launch_igemm_nt(const ConvP& p, int NT, int nphase, bool split, hipStream_t st) {
   switch (NT) {
-    case 1: return launch_igemm_inst<T, CK, MT, 1>(p, nphase, st);
-    case 2: return launch_igemm_inst<T, CK, MT, 2>(p, nphase, st);
-    default: return launch_igemm_inst<T, CK, MT, 4>(p, nphase, st);
+    case 1: return launch_igemm_inst<T, CK, MT, 1>(p, nphase, false, st);
+    case 2: return launch_igemm_inst<T, CK, MT, 2>(p, nphase, split, st);
+    default: return launch_igemm_inst<T, CK, MT, 4>(p, nphase, split, st);
   }
 }
 
 template <typename T, int CK>
-int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, hipStream_t st) {
+int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, bool split, hipStream_t st) {
   switch (MT) {
-    case 1: return launch_igemm_nt<T, CK, 1>(p, NT, nphase, st);
-    case 2: return launch_igemm_nt<T, CK, 2>(p, NT, nphase, st);
-    default: return launch_igemm_nt<T, CK, 4>(p, NT, nphase, st);
+    case 1: return launch_igemm_nt<T, CK, 1>(p, NT, nphase, split, st);
+    case 2: return launch_igemm_nt<T, CK, 2>(p, NT, nphase, split, st);
+    default: return launch_igemm_nt<T, CK, 4>(p, NT, nphase, split, st);
   }
 }
 
@@ -923,25 +974,32 @@ int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st) {
   const int CK = (B % 32 == 0) ? 32 : 16;
   const int MT = (A % 64 == 0) ? 4 : (A % 32 == 0 ? 2 : 1);
   p.Y = A / (16 * MT);
-  // positions per wave: largest NT that still gives the chip >= ~2 blocks per CU, without
-  // padding short sequences by more than a tile
+  // Short sequences (a 64-position unit would be mostly padding): 16-position units from any sequence, NT per wave.
+  // Long sequences: the largest contiguous unit that still gives the chip ~2 blocks per CU.
+  const bool split = p.Q < 56 && dtype == EVT_DT_BF16;
   int NT = 4;
-  while (NT > 1) {
-    const long units = (long)p.nseq * ceil_div(p.Q, 16 * NT);
-    const long blocks = ((units + 3) / 4) * p.Y * nphase;
-    const int waste = ceil_div(p.Q, 16 * NT) * 16 * NT - p.Q;
-    if (blocks >= 512 && waste * 4 <= p.Q) break;
-    NT >>= 1;
+  if (split) {
+    const long units16 = (long)p.nseq * ceil_div(p.Q, 16);
+    while (NT > 1 && ((units16 + 4 * NT - 1) / (4 * NT)) * p.Y * nphase < 384) NT >>= 1;
+  } else {
+    while (NT > 1) {
+      const long units = (long)p.nseq * ceil_div(p.Q, 16 * NT);
+      const long blocks = ((units + 3) / 4) * p.Y * nphase;
+      const int waste = ceil_div(p.Q, 16 * NT) * 16 * NT - p.Q;
+      if (blocks >= 512 && waste * 3 <= p.Q) break;
+      NT >>= 1;
+    }
   }
   for (;; NT >>= 1) {
-    p.U = ceil_div(p.Q, 16 * NT);
+    const bool sp = split && NT > 1;
+    p.U = ceil_div(p.Q, sp ? 16 : 16 * NT);
     const long units = (long)p.nseq * p.U;
-    p.P = (int)((units + 3) / 4);
+    p.P = (int)((units + (sp ? 4 * NT : 4) - 1) / (sp ? 4 * NT : 4));
     int rc;
     if (dtype == EVT_DT_BF16)
-      rc = (CK == 32) ? launch_igemm_mt<bf16_t, 32>(p, MT, NT, nphase, st) : launch_igemm_mt<bf16_t, 16>(p, MT, NT, nphase, st);
+      rc = (CK == 32) ? launch_igemm_mt<bf16_t, 32>(p, MT, NT, nphase, sp, st) : launch_igemm_mt<bf16_t, 16>(p, MT, NT, nphase, sp, st);
     else
-      rc = (CK == 32) ? launch_igemm_mt<float, 32>(p, MT, NT, nphase, st) : launch_igemm_mt<float, 16>(p, MT, NT, nphase, st);
+      rc = (CK == 32) ? launch_igemm_mt<float, 32>(p, MT, NT, nphase, sp, st) : launch_igemm_mt<float, 16>(p, MT, NT, nphase, sp, st);
     if (rc != EVT_ENOTSUP || NT == 1) return rc;  // ENOTSUP here = LDS too large: shrink the unit
   }
 }

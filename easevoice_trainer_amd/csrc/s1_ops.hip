@@ -10,76 +10,129 @@
 
 namespace {
 
-// ---- y = LayerNorm(x + r): one wave per row, C <= 64*16 ------------------------------------------------------
-template <typename T, int EPT>
+// ---- y = LayerNorm(x + r): one wave per row, 16-byte loads; a lane owns V = 16/sizeof(T) consecutive channels per
+//      pass (C % V == 0, C <= 64*V*NP) -------------------------------------------------------------------------------
+template <typename T> struct Vec16 { static constexpr int V = 16 / sizeof(T); };
+
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void add_ln_fwd(const T* x, const T* r, const float* gamma, const float* beta, T* y,
                                                   float* mean, float* rstd, long rows, int C, float eps) {
+  constexpr int V = Vec16<T>::V;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float v[EPT];
+  float v[NP][V];
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int c = e * 64 + lane;
-    float t = 0.f;
-    if (c < C) { t = to_f<T>(x[row * C + c]); if (r) t += to_f<T>(r[row * C + c]); }
-    v[e] = t; s += t;
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C) {
+      const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + c0);
+      uint4 b = make_uint4(0, 0, 0, 0);
+      if (r) b = *reinterpret_cast<const uint4*>(r + row * C + c0);
+      const T* pa = reinterpret_cast<const T*>(&a);
+      const T* pb = reinterpret_cast<const T*>(&b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { v[pss][e] = to_f<T>(pa[e]) + (r ? to_f<T>(pb[e]) : 0.f); s += v[pss][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[pss][e] = 0.f;
+    }
   }
   const float mu = wave_reduce_sum(s) / C;
   float q = 0.f;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) { const int c = e * 64 + lane; if (c < C) { const float d = v[e] - mu; q += d * d; } }
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C)
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = v[pss][e] - mu; q += d * d; }
+  }
   const float rs = rsqrtf(wave_reduce_sum(q) / C + eps);
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int c = e * 64 + lane;
-    if (c < C) y[row * C + c] = from_f<T>((v[e] - mu) * rs * gamma[c] + beta[c]);
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C) {
+      uint4 o;
+      T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) po[e] = from_f<T>((v[pss][e] - mu) * rs * gamma[c0 + e] + beta[c0 + e]);
+      *reinterpret_cast<uint4*>(y + row * C + c0) = o;
+    }
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <typename T, int EPT>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void add_ln_bwd(const T* x, const T* r, const float* gamma, const T* dy,
                                                   const float* mean, const float* rstd, T* dxr, float* dgamma,
                                                   float* dbeta, long rows, int C, int rows_per_block) {
-  __shared__ float sg[4][64 * EPT], sb[4][64 * EPT];
+  constexpr int V = Vec16<T>::V;
+  __shared__ float sg[4][64 * V * NP], sb[4][64 * V * NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[EPT], ab[EPT];
+  float ag[NP][V], ab[NP][V], gm[NP][V];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) ag[e] = ab[e] = 0.f;
+  for (int pss = 0; pss < NP; ++pss)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      ag[pss][e] = ab[pss][e] = 0.f;
+      const int c = (pss * 64 + lane) * V + e;
+      gm[pss][e] = c < C ? gamma[c] : 0.f;
+    }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
   for (long row = r0 + wave; row < r1; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[EPT], dh[EPT];
+    float xh[NP][V], dh[NP][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int c = e * 64 + lane;
-      xh[e] = dh[e] = 0.f;
-      if (c < C) {
-        float t = to_f<T>(x[row * C + c]);
-        if (r) t += to_f<T>(r[row * C + c]);
-        const float d = to_f<T>(dy[row * C + c]);
-        xh[e] = (t - mu) * rs;
-        dh[e] = d * gamma[c];
-        ag[e] += d * xh[e];
-        ab[e] += d;
-        s1 += dh[e];
-        s2 += dh[e] * xh[e];
+    for (int pss = 0; pss < NP; ++pss) {
+      const int c0 = (pss * 64 + lane) * V;
+      if (c0 < C) {
+        const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + c0);
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (r) b = *reinterpret_cast<const uint4*>(r + row * C + c0);
+        const uint4 d4 = *reinterpret_cast<const uint4*>(dy + row * C + c0);
+        const T* pa = reinterpret_cast<const T*>(&a);
+        const T* pb = reinterpret_cast<const T*>(&b);
+        const T* pd = reinterpret_cast<const T*>(&d4);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float t = to_f<T>(pa[e]) + (r ? to_f<T>(pb[e]) : 0.f);
+          const float d = to_f<T>(pd[e]);
+          xh[pss][e] = (t - mu) * rs;
+          dh[pss][e] = d * gm[pss][e];
+          ag[pss][e] += d * xh[pss][e];
+          ab[pss][e] += d;
+          s1 += dh[pss][e];
+          s2 += dh[pss][e] * xh[pss][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) xh[pss][e] = dh[pss][e] = 0.f;
       }
     }
     s1 = wave_reduce_sum(s1) / C;
     s2 = wave_reduce_sum(s2) / C;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int c = e * 64 + lane;
-      if (c < C) dxr[row * C + c] = from_f<T>(rs * (dh[e] - s1 - xh[e] * s2));
+    for (int pss = 0; pss < NP; ++pss) {
+      const int c0 = (pss * 64 + lane) * V;
+      if (c0 < C) {
+        uint4 o;
+        T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) po[e] = from_f<T>(rs * (dh[pss][e] - s1 - xh[pss][e] * s2));
+        *reinterpret_cast<uint4*>(dxr + row * C + c0) = o;
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) { sg[wave][e * 64 + lane] = ag[e]; sb[wave][e * 64 + lane] = ab[e]; }
+  for (int pss = 0; pss < NP; ++pss)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      sg[wave][(pss * 64 + lane) * V + e] = ag[pss][e];
+      sb[wave][(pss * 64 + lane) * V + e] = ab[pss][e];
+    }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
@@ -187,13 +240,13 @@ extern "C" {
 int evt_add_layernorm_fwd(int32_t dtype, const void* x, const void* r, const float* gamma, const float* beta, void* y,
                           float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return EVT_EINVAL;
-  if (C > 1024) return EVT_ENOTSUP;
+  if (C > 1024 || C % 8) return EVT_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)((rows + 3) / 4);
 #define LN_FWD(T, E) hipLaunchKernelGGL((add_ln_fwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)r, \
                                         gamma, beta, (T*)y, mean, rstd, (long)rows, C, eps)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_FWD(bf16_t, 8); else LN_FWD(bf16_t, 16); }
-  else if (dtype == EVT_DT_F32) { if (C <= 512) LN_FWD(float, 8); else LN_FWD(float, 16); }
+  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_FWD(bf16_t, 1); else LN_FWD(bf16_t, 2); }
+  else if (dtype == EVT_DT_F32) { if (C <= 512) LN_FWD(float, 2); else LN_FWD(float, 4); }
   else return EVT_EINVAL;
 #undef LN_FWD
   return evt_check_launch();
@@ -203,15 +256,15 @@ int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const flo
                           const float* mean, const float* rstd, void* dxr, float* dgamma, float* dbeta, int64_t rows,
                           int32_t C, void* stream) {
   if (!x || !gamma || !dy || !mean || !rstd || !dxr || !dgamma || !dbeta || rows <= 0 || C <= 0) return EVT_EINVAL;
-  if (C > 1024) return EVT_ENOTSUP;
+  if (C > 1024 || C % 8) return EVT_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
   long rpb = (rows + 1023) / 1024;
   if (rpb < 16) rpb = 16;
   const int blocks = (int)((rows + rpb - 1) / rpb);
 #define LN_BWD(T, E) hipLaunchKernelGGL((add_ln_bwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)r, \
                                         gamma, (const T*)dy, mean, rstd, (T*)dxr, dgamma, dbeta, (long)rows, C, (int)rpb)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_BWD(bf16_t, 8); else LN_BWD(bf16_t, 16); }
-  else if (dtype == EVT_DT_F32) { if (C <= 512) LN_BWD(float, 8); else LN_BWD(float, 16); }
+  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_BWD(bf16_t, 1); else LN_BWD(bf16_t, 2); }
+  else if (dtype == EVT_DT_F32) { if (C <= 512) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else return EVT_EINVAL;
 #undef LN_BWD
   return evt_check_launch();

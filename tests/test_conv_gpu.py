@@ -36,6 +36,9 @@ CASES = [
     (32, 128, 5, 3, 2, 1, 1, False, True, 100, 4),
     (128, 64, 5, 3, 2, 1, 1, False, True, 23, 6),
     (64, 64, 5, 1, 2, 1, 1, False, True, 23, 6),
+    (64, 128, 5, 1, 2, 1, 1, False, True, 37, 5),      # short sequences -> split-unit tiling (bf16)
+    (32, 64, 3, 1, 1, 1, 1, False, True, 51, 7),
+    (128, 128, 5, 3, 2, 1, 1, False, True, 152, 9),    # strided, output length 51
     # degenerate / grouped shapes -> direct kernels: conv_post 16->1 k7 no bias, D first layers, D post,
     # DiscriminatorS grouped k41 s4
     (16, 1, 7, 1, 3, 1, 1, False, False, 90, 2),
