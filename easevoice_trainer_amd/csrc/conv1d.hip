@@ -569,6 +569,28 @@ __device__ __forceinline__ bf16x8 lds_tr2(const bf16_t* p0, const bf16_t* p1) {
   return r.v;
 }
 
+// four fragments (eight transpose reads) behind ONE wait: the MFMAs that consume them then issue back to back
+__device__ __forceinline__ void lds_tr2x4(const bf16_t* p0, const bf16_t* p1, const bf16_t* p2, const bf16_t* p3, int hi_off,
+                                          bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+  const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1, a2 = (unsigned)(uintptr_t)p2,
+                 a3 = (unsigned)(uintptr_t)p3;
+  const unsigned b0 = a0 + hi_off, b1 = a1 + hi_off, b2 = a2 + hi_off, b3 = a3 + hi_off;
+  uint2 l0, h0, l1, h1, l2, h2, l3, h3;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+      : "memory");
+  union { uint4 u; bf16x8 v; } r;
+  r.u = make_uint4(l0.x, l0.y, h0.x, h0.y); f0 = r.v;
+  r.u = make_uint4(l1.x, l1.y, h1.x, h1.y); f1 = r.v;
+  r.u = make_uint4(l2.x, l2.y, h2.x, h2.y); f2 = r.v;
+  r.u = make_uint4(l3.x, l3.y, h3.x, h3.y); f3 = r.v;
+}
+
 template <int CK, int TA>
 __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
   typedef bf16_t T;
@@ -649,16 +671,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       const int kb = ps * 64 + ks * 32 + g8 * 8;  // first of this lane group's 8 positions
       const T* pa = As + (kb + (j16 >> 2)) * PA + ct * 16 + 4 * (j16 & 3);
       const bf16x8 a = lds_tr2(pa, pa + 4 * PA);
+      // taps beyond ntap read rows that are staged (the B tile always covers KT taps) and are simply not accumulated
+      const T* pb0 = Bs + ((kb + (j16 >> 2)) * p.s) * PB + 4 * (j16 & 3);
+      const int hi = 4 * p.s * PB * (int)sizeof(T);
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        if (t < ntap) {
-          const T* pb = Bs + ((kb + (j16 >> 2)) * p.s + t * p.dil) * PB + 4 * (j16 & 3);
-#pragma unroll
-          for (int j = 0; j < NTB; ++j) {
-            const bf16x8 b = lds_tr2(pb + j * 16, pb + j * 16 + 4 * p.s * PB);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t][j], 0, 0, 0);
-          }
-        }
+      for (int j = 0; j < NTB; ++j) {
+        bf16x8 b0, b1, b2, b3;
+        lds_tr2x4(pb0 + j * 16, pb0 + p.dil * PB + j * 16, pb0 + 2 * p.dil * PB + j * 16,
+                  pb0 + 3 * p.dil * PB + j * 16, hi, b0, b1, b2, b3);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0][j], 0, 0, 0);
+        if (ntap > 1) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1][j], 0, 0, 0);
+        if (ntap > 2) acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[2][j], 0, 0, 0);
+        if (ntap > 3) acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b3, acc[3][j], 0, 0, 0);
       }
     }
   }

@@ -369,9 +369,11 @@ class ResidualVectorQuantizer(nn.Module):
     def forward(self, x):
         """x [B, T, D] fp32 -> (quantized [B, T, D], codes [1, B, T])"""
         cb = self.vq.layers[0]._codebook
-        if not bool(cb.inited.item() if cb.inited.device.type == "cpu" else cb.inited.cpu().item()):
-            raise L.EvtError("quantizer codebook is not initialised: load pretrained weights "
-                             "(the reference would run k-means on the first batch, core_vq.py:140-149)")
+        if not getattr(self, "_inited_ok", False):     # checked once (a host sync), not every step
+            if not bool(cb.inited.cpu().item()):
+                raise L.EvtError("quantizer codebook is not initialised: load pretrained weights "
+                                 "(the reference would run k-means on the first batch, core_vq.py:140-149)")
+            self._inited_ok = True
         b, t, d = x.shape
         ind = cb.nearest(x.reshape(b * t, d).float())
         q = F.embedding(ind, cb.embed).view(b, t, d)
@@ -597,8 +599,9 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             quantized, _codes = self._quantize(ssl.transpose(1, 2))
             x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge)
             eps_cl = eps.transpose(1, 2) if eps is not None else None
-            z, m_q, logs_q = self.enc_q(y_cl, y_mask, g=ge, eps=eps_cl)
-            z_p = self.flow(z, y_mask, g=ge)
+            ym = y_mask.to(self.cd)      # 0/1 mask in the compute dtype: the WN stacks stay in one dtype (no cast kernels)
+            z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge, eps=eps_cl)
+            z_p = self.flow(z, ym, g=ge)
             if ids_slice is None:
                 z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
             else:
