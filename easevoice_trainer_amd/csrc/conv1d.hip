@@ -19,6 +19,7 @@
 // channel tiles that re-read the same activation rows sit on the same XCD (same L2).
 #include "evt_common.h"
 #include "../../include/evt.h"
+#include "conv_p.h"
 
 extern "C" int evt_grouped_supported(const evt_conv1d_params* c);
 extern "C" int evt_grouped_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
@@ -38,29 +39,7 @@ extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, co
 
 namespace {
 
-struct ConvP {
-  const void* x;     // K-side operand, [nseq][Lin][Cin]
-  const void* xact;  // optional activation OUTPUT with x's shape: x_eff = x * dact(xact)
-  const void* w;     // prepared weights [phase][Cout][nchunk][KHp][CK]
-  const float* bias; // [Cout] or null
-  const void* res;   // [nseq][Lout][Cout] or null (added last)
-  const void* gate;  // [nseq][Lout][Cout] or null: result *= (gate > 0 ? 1 : gate_slope) before res
-  void* y;           // [nseq][Lout][Cout]
-  int nseq, Lin, Lout, Cin, Cout;
-  int KHp;           // taps in the prepared image (zero padded)
-  int s_in, dil, off_in;
-  int s_out, off_out, off_out_phase;
-  int Q, U;          // q per sequence, units per sequence
-  int nchunk;
-  long w_phase_stride;  // elements
-  float in_slope;
-  int xact_kind;
-  float xact_slope;
-  int out_act;
-  float out_slope;
-  float gate_slope;
-  int P, Y;          // position blocks, channel tiles
-};
+using evt_conv::ConvP;
 
 template <typename T> struct Frag;
 template <> struct Frag<float> {
@@ -408,22 +387,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
 // tiles are accumulated with fp32 global atomics.  Fragments are gathered element-wise from
 // position-major LDS tiles (k = position is the strided index of a channels-last tensor).
 // ---------------------------------------------------------------------------------------------
-struct WgP {
-  const void* A;      // [nseq][LA][CA]   q-indexed operand
-  const void* Aact;   // optional activation output (A_eff = A * dact(Aact))
-  const void* B;      // [nseq][LB][CB]   tap-shifted operand
-  const void* Bact;
-  float* dw;          // [CA][nchunk][KHp][CK] fp32
-  int nseq, LA, LB, CA, CB;
-  int KH, KHp, s, dil, off, Q;
-  int nchunk;
-  float a_slope, b_slope;     // lrelu-on-load slopes (1 = identity)
-  int aact_kind, bact_kind;
-  float aact_slope, bact_slope;
-  int nsplit;
-  int ntapgrp;
-  float* dbias;       // optional: += column sums of A_eff (only valid when A is dy)
-};
+using evt_conv::WgP;
 
 template <typename T> union FragBuf;
 template <> union FragBuf<float> { float v; float e[1]; };
@@ -993,8 +957,9 @@ int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, bool split, hipS
 }
 
 // Generic igemm launch.  A = output channels, B = K-side channels.
-int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st) {
+int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st, bool allow_deep) {
   if (A % 16 || B % 16) return EVT_ENOTSUP;
+  if (allow_deep && evt_conv::deep_eligible(p, dtype, A, B, nphase)) return evt_conv::launch_conv_deep(p, A, B, nphase, st);
   const int CK = (B % 32 == 0) ? 32 : 16;
   const int MT = (A % 64 == 0) ? 4 : (A % 32 == 0 ? 2 : 1);
   p.Y = A / (16 * MT);
@@ -1146,6 +1111,26 @@ int32_t evt_conv1d_lout(const evt_conv1d_params* c) {
   return (c->lin - 1) * c->stride - 2 * c->pad + c->dil * (c->k - 1) + 1;
 }
 
+int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c) {
+  if (!c || valid(c) != EVT_OK) return 0;
+  if (c->impl != EVT_IMPL_AUTO || c->dtype != EVT_DT_BF16 || c->transposed || !igemm_ok(c)) return 0;
+  if (c->out_act == EVT_ACT_NONE || c->in_slope != 1.f) return 0;
+  // same descriptor geometry evt_conv1d_bwd_data builds (K side = cout, output channels = cin)
+  ConvP p{};
+  p.in_slope = 1.f;
+  p.nseq = c->nseq;
+  p.nchunk = c->cout / 32;
+  int nphase = 1;
+  if (c->stride == 1) p.Q = c->lin;
+  else { nphase = c->stride; p.Q = (c->lin - 1 + c->pad) / c->stride + 1; }
+  if (evt_conv::deep_eligible(p, c->dtype, c->cin, c->cout, nphase)) return 1;
+  // ... or the weight gradient does (A = dy [nseq][lout][cout], B = x)
+  WgP w{};
+  w.nseq = c->nseq; w.KHp = c->k; w.Q = w.LA = evt_conv1d_lout(c); w.CA = c->cout; w.CB = c->cin;
+  w.a_slope = w.b_slope = 1.f;
+  return evt_conv::wgrad_deep_eligible(w, c->dtype) ? 1 : 0;
+}
+
 int evt_conv1d_layout(const evt_conv1d_params* c, evt_wlayout* o) {
   if (!c || !o) return EVT_EINVAL;
   const int d0 = c->transposed ? c->cin : c->cout;
@@ -1220,7 +1205,7 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
       p.w_phase_stride = (long)c->cout * l.alt_nchunk * l.alt_kp * l.alt_ck;
     }
   }
-  return launch_igemm(c->dtype, p, c->cout, c->cin, nphase, st);
+  return launch_igemm(c->dtype, p, c->cout, c->cin, nphase, st, c->impl == EVT_IMPL_AUTO);
 }
 
 int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
@@ -1280,7 +1265,7 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
     p.s_in = c->stride; p.dil = 1; p.off_in = -c->pad;
     p.s_out = 1; p.off_out = 0; p.off_out_phase = 0; p.Q = c->lin; p.w_phase_stride = 0;
   }
-  return launch_igemm(c->dtype, p, c->cin, c->cout, nphase, st);
+  return launch_igemm(c->dtype, p, c->cin, c->cout, nphase, st, c->impl == EVT_IMPL_AUTO);
 }
 
 int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
@@ -1295,8 +1280,25 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   evt_wlayout l; evt_conv1d_layout(c, &l);
   const bool grouped = c->impl != EVT_IMPL_NAIVE && evt_grouped_supported(c);
   const bool igemm_path = !grouped && c->impl != EVT_IMPL_NAIVE && igemm_ok(c) && l.reg_kp <= 64;
+  // descriptor of the MFMA weight-gradient kernels
+  WgP p{};
+  p.dw = dw; p.nseq = c->nseq; p.KH = c->k; p.KHp = l.reg_kp; p.s = c->stride; p.dil = c->dil; p.off = -c->pad;
+  if (!c->transposed) {
+    // dW[co][.][t][ci] += dy_eff[q][co] * lrelu(x)[q*s + t*dil - pad][ci]
+    p.A = dy; p.Aact = ysv; p.aact_kind = c->out_act; p.aact_slope = c->out_slope; p.a_slope = 1.f;
+    p.B = x; p.Bact = nullptr; p.bact_kind = 0; p.bact_slope = 1.f; p.b_slope = c->in_slope;
+    p.LA = lout; p.CA = c->cout; p.LB = c->lin; p.CB = c->cin; p.Q = lout;
+  } else {
+    // dW[ci][.][t][co] += lrelu(x)[i][ci] * dy_eff[i*s + t - pad][co]
+    p.A = x; p.Aact = nullptr; p.aact_kind = 0; p.aact_slope = 1.f; p.a_slope = c->in_slope;
+    p.B = dy; p.Bact = ysv; p.bact_kind = c->out_act; p.bact_slope = c->out_slope; p.b_slope = 1.f;
+    p.LA = c->lin; p.CA = c->cin; p.LB = lout; p.CB = c->cout; p.Q = c->lin;
+  }
+  p.dbias = nullptr;
+  // wide layers with plain operands: LDS-DMA GEMM kernel (conv_deep.hip); its dbias comes from the column-sum kernel
+  const bool deep_w = igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
-  const bool fuse_bias = dbias && igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed;
+  const bool fuse_bias = dbias && igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed && !deep_w;
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
@@ -1347,19 +1349,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
       hipLaunchKernelGGL(conv_naive_bwd_weight<float>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
     return evt_check_launch();
   }
-  WgP p{};
-  p.dw = dw; p.nseq = c->nseq; p.KH = c->k; p.KHp = l.reg_kp; p.s = c->stride; p.dil = c->dil; p.off = -c->pad;
-  if (!c->transposed) {
-    // dW[co][.][t][ci] += dy_eff[q][co] * lrelu(x)[q*s + t*dil - pad][ci]
-    p.A = dy; p.Aact = ysv; p.aact_kind = c->out_act; p.aact_slope = c->out_slope; p.a_slope = 1.f;
-    p.B = x; p.Bact = nullptr; p.bact_kind = 0; p.bact_slope = 1.f; p.b_slope = c->in_slope;
-    p.LA = lout; p.CA = c->cout; p.LB = c->lin; p.CB = c->cin; p.Q = lout;
-  } else {
-    // dW[ci][.][t][co] += lrelu(x)[i][ci] * dy_eff[i*s + t - pad][co]
-    p.A = x; p.Aact = nullptr; p.aact_kind = 0; p.aact_slope = 1.f; p.a_slope = c->in_slope;
-    p.B = dy; p.Bact = ysv; p.bact_kind = c->out_act; p.bact_slope = c->out_slope; p.b_slope = 1.f;
-    p.LA = c->lin; p.CA = c->cin; p.LB = lout; p.CB = c->cout; p.Q = c->lin;
-  }
+  if (deep_w) return evt_conv::launch_wgrad_deep(p, st);
   if (c->dtype == EVT_DT_BF16) {
     p.dbias = fuse_bias ? dbias : nullptr;
     rc = launch_wgrad_tr(p, st);

@@ -1,0 +1,431 @@
+// conv_deep: GEMM-grade implicit-GEMM convolution for the wide bf16 layers (gfx950).
+//
+// Reference call sites: DiscriminatorP's 128->512, 512->1024 (k5 s3) and 1024->1024 (k5 s1) Conv2d((k,1)) layers,
+// src/easevoice/module/models.py:481-536, forward and backward-data; the same descriptor (conv_p.h) as conv_igemm.
+//
+// GEMM view: M = output channels, N = FLAT positions (seq, q) of all sequences (a 128-position tile may span several
+// of DiscriminatorP's short sequences), K = (tap, K-side channel).  Block tile 128 x 128, 4 waves in 2 x 2, a wave
+// owns 64 x 64 = 4 x 4 MFMA tiles (mfma_f32_16x16x32_bf16).  One K stage = one tap x 64 channels:
+//   A stage  [128 out-channels][64 k]  from the prepared weight image [co][chunk32][tap][32] (two 64-byte pieces)
+//   B stage  [128 positions][64 k]     row (seq, q*s_in + tap*dil + off_in), 128 contiguous bytes of a channels-last row
+// Both are written by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  The DMA destination
+// is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and undone with the same XOR
+// on the fragment read: LDS[row][slot] = G[row][slot ^ (row & 7)] (16-byte slots of a 128-byte row; every
+// ds_read_b128 lane group then touches 16 distinct slots).  Rows outside a sequence (conv padding, tile tail) read a
+// zero page.  Two LDS stages (64 KiB): the DMA of stage s+1 is issued right after the barrier that publishes stage s
+// and flies under its 32 MFMAs per wave; one barrier per stage.
+#include "conv_p.h"
+
+namespace evt_conv {
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // 256 zero bytes
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+
+__global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware decode (same convention as conv_igemm): all channel tiles of a position tile on one XCD
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int yi = slot % p.Y;
+  const int pb = xcd + 8 * (slot / p.Y);
+  if (pb >= p.P) return;
+  const int phase = blockIdx.y;
+
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const int total_units = p.nseq * p.Q;
+
+  // ---- per-lane DMA sources: wave w stages rows [32w, 32w+32) of both tiles, 8 rows per instruction ----
+  const int rsub = lane >> 3, pslot = lane & 7;
+  long aoff[4], boff[4];
+  int brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + rsub;
+    const int c = pslot ^ (row & 7);                 // logical 16-byte k-slot this lane fetches
+    const int co = yi * BM + row;
+    aoff[i] = ((long)co * p.nchunk + (c >> 2)) * p.KHp * 32 + (c & 3) * 8;
+    const int u = pb * BN + row;                      // launcher guarantees nseq * Q < 2^31
+    const bool ok = u < total_units;
+    const int seq = ok ? u / p.Q : 0;
+    const int q = ok ? u - seq * p.Q : 0;
+    brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
+    boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
+  }
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  unsigned char* my_a = smem + wave * 32 * 128;              // + buf*STAGE_BYTES + i*1024
+  unsigned char* my_b = smem + BM * 128 + wave * 32 * 128;
+
+  const int nch2 = p.nchunk >> 1;
+  const int nst = nch2 * p.KHp;
+
+  auto issue = [&](int st, int buf) {
+    const int ch2 = st / p.KHp, tap = st - ch2 * p.KHp;
+    const long wsoff = ((long)(2 * ch2) * p.KHp + tap) * 32;
+    const int rshift = tap * p.dil;
+    const long xsoff = (long)rshift * p.Cin + ch2 * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(W + aoff[i] + wsoff, my_a + buf * STAGE_BYTES + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (unsigned)(brow[i] + rshift) < (unsigned)p.Lin;
+      const bf16_t* src = ok ? X + boff[i] + xsoff : zsrc;
+      glds16(src, my_b + buf * STAGE_BYTES + i * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = tile_row0 + t*16 + n, logical slot c = ks*4 + g, physical slot = c ^ (row & 7);
+  // (row & 7) == (n & 7) because every tile row base is a multiple of 16
+  const int sw = n & 7;
+  const int a_base = (wr * 64 + n) * 128;
+  const int b_base = BM * 128 + (wc * 64 + n) * 128;
+  const int so0 = ((0 + g) ^ sw) * 16, so1 = ((4 + g) ^ sw) * 16;
+
+  issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    __syncthreads();                       // (compiler drains vmcnt before it) stage st has landed; buf^1 is free
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    const unsigned char* sa = smem + buf * STAGE_BYTES + a_base;
+    const unsigned char* sb = smem + buf * STAGE_BYTES + b_base;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ks ? so1 : so0;
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + so);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + so);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds channels g*4..g*4+3 (rows) of position n (column) of each 16 x 16 tile ----
+  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
+  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.gate);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int u = pb * BN + wc * 64 + j * 16 + n;
+    if (u >= total_units) continue;
+    const int seq = u / p.Q;
+    const int q = u - seq * p.Q;
+    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
+    if (orow < 0 || orow >= p.Lout) continue;
+    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = yi * BM + wr * 64 + i * 16 + g * 4;
+      const long off = rbase + co;
+      bf16_t outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co + r];
+        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
+        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
+        if (G) v *= (bf2f(G[off + r]) > 0.f ? 1.f : p.gate_slope);
+        if (R) v += bf2f(R[off + r]);
+        outv[r] = f2bf(v);
+      }
+      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// wgrad_deep: weight gradient of the same layers on the same LDS-DMA structure.
+//   dW[a][chunk][tap][cc] += sum over flat positions u = (seq, q) of A[u][a] * B[seq][q*s + tap*dil + off][chunk*32+cc]
+// GEMM view: M = A channels (dy), N = (tap, B channel), K = flat positions.  Block tile: 128 A channels x (KT = 5 taps
+// x 32 B channels), K stage = 64 positions; 4 waves in 2 x 2, a wave owns 64 A channels x 16 B channels x 5 taps
+// (4 x 5 MFMA tiles).  Both operands are position-major in HBM (channels-last), i.e. K is the ROW index, so the MFMA
+// fragments (8 consecutive positions of one channel) come from ds_read_b64_tr_b16 (LDS transpose read; inside a 16-lane
+// group lane j supplies row j>>2, columns 4*(j&3).., lane i receives column i -- tools/probe_tr.hip).
+// LDS stage: A tile [64 pos][128 ch] (256-byte rows) + KT tiles [64 pos][32 ch] (64-byte rows), written by LDS-DMA;
+// the 16-byte-slot swizzles (applied on the DMA source, undone on the read) make every 32-lane transpose read touch
+// 16 distinct slots:  A: slot ^= 2*((row&3) | ((row>>3)&1)<<2),   B: slot ^= 2*((row>>3)&1).
+// Positions are split over blockIdx.y; partial tiles are accumulated into the fp32 dW image with atomics.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int WKT = 5;                                   // taps per block
+constexpr int WPOS = 64;                                 // positions per K stage
+constexpr int WA_BYTES = WPOS * 256;                     // 16 KiB
+constexpr int WB_BYTES = WPOS * 64;                      // 4 KiB per tap
+constexpr int WSTAGE = WA_BYTES + WKT * WB_BYTES;        // 36 KiB
+
+// All 18 transpose reads of one K = 32 step (4 A tiles, 5 tap tiles, low + high halves) behind ONE wait; the row /
+// tap / k-step displacements are instruction offsets, so the step needs five address registers.
+template <int KS>
+__device__ __forceinline__ void tr_load_step(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[WKT]) {
+  uint2 al[4], ah[4], bl[WKT], bh[WKT];
+  if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %18 offset:0\n\t"
+        "ds_read_b64_tr_b16 %4, %18 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %19 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %19 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %20 offset:0\n\t"
+        "ds_read_b64_tr_b16 %6, %20 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %21 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %21 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %8, %22 offset:0\n\t"
+        "ds_read_b64_tr_b16 %13, %22 offset:256\n\t"
+        "ds_read_b64_tr_b16 %9, %22 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %14, %22 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %10, %22 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %15, %22 offset:8448\n\t"
+        "ds_read_b64_tr_b16 %11, %22 offset:12288\n\t"
+        "ds_read_b64_tr_b16 %16, %22 offset:12544\n\t"
+        "ds_read_b64_tr_b16 %12, %22 offset:16384\n\t"
+        "ds_read_b64_tr_b16 %17, %22 offset:16640\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]),
+          "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]),
+          "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %18 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %4, %18 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %1, %19 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %5, %19 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %2, %20 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %6, %20 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %3, %21 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %7, %21 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %8, %22 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %13, %22 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %9, %22 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %14, %22 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %10, %22 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %15, %22 offset:10496\n\t"
+        "ds_read_b64_tr_b16 %11, %22 offset:14336\n\t"
+        "ds_read_b64_tr_b16 %16, %22 offset:14592\n\t"
+        "ds_read_b64_tr_b16 %12, %22 offset:18432\n\t"
+        "ds_read_b64_tr_b16 %17, %22 offset:18688\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]),
+          "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]),
+          "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+  }
+  union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+  for (int t = 0; t < WKT; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j16 = lane & 15, g8 = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  int bx = blockIdx.x;
+  const int ch = bx % p.nchunk; bx /= p.nchunk;
+  const int tgi = bx % p.ntapgrp;
+  const int atile = bx / p.ntapgrp;
+  const int t0 = tgi * WKT;
+  const int ntap = min(WKT, p.KHp - t0);
+  const int a0 = atile * 128;
+
+  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const int total_units = p.nseq * p.Q;
+  const int nstages = (total_units + WPOS - 1) / WPOS;
+  const int st_begin = blockIdx.y * stages_per_split;
+  const int st_end = min(nstages, st_begin + stages_per_split);
+  if (st_begin >= st_end) return;
+
+  // ---- DMA roles: wave w stages rows [16w, 16w+16) of every tile ----
+  // A: 4 instructions of 4 rows x 16 slots;  B: one instruction per tap, 16 rows x 4 slots
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  int arow[4], acol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    arow[i] = wave * 16 + i * 4 + (lane >> 4);
+    const int f = 2 * ((arow[i] & 3) | (((arow[i] >> 3) & 1) << 2));
+    acol[i] = a0 + (((lane & 15) ^ f) * 8);
+  }
+  const int brow = wave * 16 + (lane >> 2);
+  const int bcol = ch * 32 + (((lane & 3) ^ (2 * ((brow >> 3) & 1))) * 8);
+
+  auto issue = [&](int st, int buf) {
+    unsigned char* base = smem + buf * WSTAGE;
+    const int u0 = st * WPOS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = u0 + arow[i];
+      const bf16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
+      glds16(src, base + wave * 4096 + i * 1024);
+    }
+    const int u = u0 + brow;
+    const bool uok = u < total_units;
+    const int seq = uok ? u / p.Q : 0;
+    const int q = u - seq * p.Q;
+    const int r0 = q * p.s + t0 * p.dil + p.off;
+    const bf16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
+#pragma unroll
+    for (int t = 0; t < WKT; ++t) {
+      const int r = r0 + t * p.dil;
+      const bool ok = uok && (unsigned)r < (unsigned)p.LB;
+      const bf16_t* src = ok ? rsrc + (long)t * p.dil * p.CB : zsrc;
+      glds16(src, base + WA_BYTES + t * WB_BYTES + wave * 1024);
+    }
+  };
+
+  f32x4 acc[4][WKT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < WKT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses (bytes, relative to the stage base) for ks = 0; ks = 1 adds 32 rows
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int frow = g8 * 8 + (j16 >> 2);                         // + ks*32 (+4 for the high half)
+  const int fa = 2 * ((frow & 3) | (((frow >> 3) & 1) << 2));   // unchanged by +4 and +32
+  const int fb = 2 * ((frow >> 3) & 1);
+  const int half = (j16 & 1) * 8;
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = frow * 256 + (((wr * 8 + i * 2 + ((j16 & 3) >> 1)) ^ fa) * 16) + half;
+  const int b_off = WA_BYTES + frow * 64 + (((wc * 2 + ((j16 & 3) >> 1)) ^ fb) * 16) + half;
+
+  issue(st_begin, 0);
+  for (int st = st_begin; st < st_end; ++st) {
+    const int buf = (st - st_begin) & 1;
+    __syncthreads();
+    if (st + 1 < st_end) issue(st + 1, buf ^ 1);
+    const unsigned sbase = lds0 + buf * WSTAGE;
+    unsigned aa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aa[i] = sbase + a_off[i];
+    const unsigned ba = sbase + b_off;
+    bf16x8 a[4], b[WKT];
+    tr_load_step<0>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < WKT; ++t)
+      if (t < ntap)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    tr_load_step<1>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < WKT; ++t)
+      if (t < ntap)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+  }
+
+  // lane holds A channels g8*4..+3 (rows) x B channel j16 (column) of each tile
+#pragma unroll
+  for (int t = 0; t < WKT; ++t) {
+    if (t >= ntap) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wr * 64 + i * 16 + g8 * 4 + r;
+        const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * 32 + wc * 16 + j16;
+        atomicAdd(p.dw + off, acc[i][t][r]);
+      }
+  }
+}
+
+}  // namespace
+
+bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
+  if (dtype != EVT_DT_BF16) return false;
+  if (out_ch % BM || k_ch % BK) return false;
+  if (p.xact || p.in_slope != 1.f) return false;          // no load-side fusion on the DMA path
+  if (p.nchunk * 32 != k_ch) return false;                 // prepared image must be the ck = 32 layout
+  if ((long)p.nseq * p.Q >= (1L << 31) - BN) return false;
+  const long tiles = (((long)p.nseq * p.Q + BN - 1) / BN) * (out_ch / BM) * nphase;
+  return tiles >= 192;                                     // enough blocks to cover the chip once
+}
+
+int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStream_t st) {
+  ConvP p = p_in;
+  if (!deep_eligible(p, EVT_DT_BF16, out_ch, k_ch, nphase)) return EVT_ENOTSUP;
+  p.Y = out_ch / BM;
+  p.P = (int)(((long)p.nseq * p.Q + BN - 1) / BN);
+  p.U = 0;
+  static bool attr = false;
+  const size_t lds = 2 * STAGE_BYTES;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_deep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  const int gx = 8 * ((p.P + 7) / 8) * p.Y;
+  evt_set_last_tag("conv_deep<bf16, 128, 128, 64>");
+  hipLaunchKernelGGL(conv_deep, dim3(gx, nphase), dim3(256), lds, st, p);
+  return evt_check_launch();
+}
+
+bool wgrad_deep_eligible(const WgP& p, int dtype) {
+  if (dtype != EVT_DT_BF16) return false;
+  if (p.CA % 128 || p.CB % 32) return false;
+  if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f || p.dbias) return false;
+  if (p.LA != p.Q) return false;                            // A rows are addressed by the flat position
+  if ((long)p.nseq * p.Q >= (1L << 31) - WPOS) return false;
+  // worth it only for GEMM-sized problems: enough (A tile, chunk) pairs and enough positions
+  const long tiles = (long)(p.CA / 128) * (p.CB / 32) * ((p.KHp + WKT - 1) / WKT);
+  return tiles >= 16 && (long)p.nseq * p.Q >= 2048;
+}
+
+int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
+  WgP p = p_in;
+  if (!wgrad_deep_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  p.nchunk = p.CB / 32;
+  p.ntapgrp = (p.KHp + WKT - 1) / WKT;
+  const long tiles = (long)(p.CA / 128) * p.nchunk * p.ntapgrp;
+  const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
+  // ~2 blocks per CU in flight, >= 8 K stages per block so the pipeline amortises its fill and the atomics
+  long split = (1024 + tiles - 1) / tiles;
+  if (split > nstages / 8) split = nstages / 8;
+  if (split < 1) split = 1;
+  const int per = (int)((nstages + split - 1) / split);
+  split = (nstages + per - 1) / per;
+  p.nsplit = (int)split;
+  static bool attr = false;
+  const size_t lds = 2 * WSTAGE;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_deep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  evt_set_last_tag("wgrad_deep<bf16, 128, 5x32, 64>");
+  hipLaunchKernelGGL(wgrad_deep, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
+  return evt_check_launch();
+}
+
+}  // namespace evt_conv

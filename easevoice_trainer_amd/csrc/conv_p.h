@@ -1,0 +1,57 @@
+// Launch descriptor of the implicit-GEMM conv kernels (conv1d.hip: conv_igemm, conv_deep.hip: conv_deep).
+#pragma once
+#include "evt_common.h"
+
+namespace evt_conv {
+
+struct ConvP {
+  const void* x;     // K-side operand, [nseq][Lin][Cin]
+  const void* xact;  // optional activation OUTPUT with x's shape: x_eff = x * dact(xact)
+  const void* w;     // prepared weights [phase][Cout][nchunk][KHp][CK]
+  const float* bias; // [Cout] or null
+  const void* res;   // [nseq][Lout][Cout] or null (added last)
+  const void* gate;  // [nseq][Lout][Cout] or null: result *= (gate > 0 ? 1 : gate_slope) before res
+  void* y;           // [nseq][Lout][Cout]
+  int nseq, Lin, Lout, Cin, Cout;
+  int KHp;           // taps in the prepared image (zero padded)
+  int s_in, dil, off_in;
+  int s_out, off_out, off_out_phase;
+  int Q, U;          // q per sequence, units per sequence
+  int nchunk;
+  long w_phase_stride;  // elements
+  float in_slope;
+  int xact_kind;
+  float xact_slope;
+  int out_act;
+  float out_slope;
+  float gate_slope;
+  int P, Y;          // position blocks, channel tiles
+};
+
+// Weight-gradient descriptor: dW[a][chunk(b)][tap][cc] += sum_{seq,q} A[seq][q][a] * B[seq][q*s + tap*dil + off][b]
+struct WgP {
+  const void* A;      // [nseq][LA][CA]   q-indexed operand
+  const void* Aact;   // optional activation output (A_eff = A * dact(Aact))
+  const void* B;      // [nseq][LB][CB]   tap-shifted operand
+  const void* Bact;
+  float* dw;          // [CA][nchunk][KHp][CK] fp32
+  int nseq, LA, LB, CA, CB;
+  int KH, KHp, s, dil, off, Q;
+  int nchunk;
+  float a_slope, b_slope;     // lrelu-on-load slopes (1 = identity)
+  int aact_kind, bact_kind;
+  float aact_slope, bact_slope;
+  int nsplit;
+  int ntapgrp;
+  float* dbias;       // optional: += column sums of A_eff (only valid when A is dy)
+};
+
+// conv_deep.hip: GEMM-grade path for wide bf16 layers (K-side channels % 64 == 0, output channels % 128 == 0, no
+// load-side fusion).  Returns EVT_ENOTSUP when the descriptor does not qualify.
+bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase);
+int launch_conv_deep(const ConvP& p, int out_ch, int k_ch, int nphase, hipStream_t st);
+// weight gradient on the same LDS-DMA structure (A channels % 128 == 0, B channels % 32 == 0, plain operands, no dbias)
+bool wgrad_deep_eligible(const WgP& p, int dtype);
+int launch_wgrad_deep(const WgP& p, hipStream_t st);
+
+}  // namespace evt_conv

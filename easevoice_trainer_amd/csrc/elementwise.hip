@@ -101,6 +101,26 @@ __global__ void add3_scale_kernel(const T* a, const T* b, const T* c, float scal
   }
 }
 
+// out = dy * act'(y) with the derivative expressed through the activation OUTPUT y; 8 (bf16) / 4 (fp32) elements per lane
+template <typename T>
+__global__ void dact_mul_kernel(const T* dy, const T* y, int kind, float slope, T* out, long n) {
+  constexpr int V = 16 / sizeof(T);
+  const long nv = n / V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    uint4 d = reinterpret_cast<const uint4*>(dy)[i];
+    const uint4 a = reinterpret_cast<const uint4*>(y)[i];
+    T* dh = reinterpret_cast<T*>(&d);
+    const T* ah = reinterpret_cast<const T*>(&a);
+#pragma unroll
+    for (int e = 0; e < V; ++e) dh[e] = from_f<T>(to_f<T>(dh[e]) * dact_from_out(kind, to_f<T>(ah[e]), slope));
+    reinterpret_cast<uint4*>(out)[i] = d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - nv * V) {
+    const long i = nv * V + threadIdx.x;
+    out[i] = from_f<T>(to_f<T>(dy[i]) * dact_from_out(kind, to_f<T>(y[i]), slope));
+  }
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <typename T>
@@ -243,6 +263,21 @@ int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, f
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(add3_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b,
                        (const float*)c, scale, (float*)out, (long)n);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_dact_mul(int32_t dtype, const void* dy, const void* y, int32_t act_kind, float slope, void* out, int64_t n,
+                 void* stream) {
+  if (!dy || !y || !out || n <= 0) return EVT_EINVAL;
+  if (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(dact_mul_kernel<bf16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)y, act_kind, slope, (bf16_t*)out, (long)n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(dact_mul_kernel<float>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (const float*)dy,
+                       (const float*)y, act_kind, slope, (float*)out, (long)n);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

@@ -164,7 +164,7 @@ class WeightBank:
                 "evt_wn_grad_multi")
 
 
-TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1) per launch
+TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1, shape) per launch
 
 
 def _t0():
@@ -184,7 +184,9 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
     act = nseq * (lin * m.cin + m.lout(lin) * m.cout) + extra_elems
     wbytes = m.v.numel() * (4 if kind == "bwd_weight" else sz)
     L.lib().evt_last_kernel_tag.restype = C.c_char_p
-    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1))
+    shape = (f"{'T' if m.transposed else ''}{m.cin}>{m.cout} k{m.k} s{m.stride} d{m.dil} g{m.groups} "
+             f"n{nseq} L{lin}")
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape))
 
 
 def _fwd(slot, x, res, in_slope, out_act, out_slope):
@@ -255,6 +257,13 @@ class ConvFn(torch.autograd.Function):
         in_slope, out_act, out_slope = ctx.cfg
         dy = dy.contiguous()
         nseq, lin = x.size(0), x.size(1)
+        if out_act != L.ACT_NONE and L.lib().evt_conv1d_wants_plain_dy(
+                C.byref(slot.params(nseq, lin, in_slope, out_act, out_slope))):
+            # wide layers: apply the activation derivative once, both backward GEMMs then take plain operands
+            dy_eff = torch.empty_like(dy)
+            L.check(L.lib().evt_dact_mul(L.dt_of(dy), L.ptr(dy), L.ptr(y), int(out_act), C.c_float(out_slope),
+                                         L.ptr(dy_eff), C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
+            dy, y, out_act, out_slope = dy_eff, None, L.ACT_NONE, 1.0
         if slot.bank.weight_grads:
             _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
         dx = None

@@ -64,6 +64,10 @@ typedef struct evt_conv1d_params {
 } evt_conv1d_params;
 
 /* output length for these hyper-parameters (torch semantics) */
+/* 1 when the backward of this conv runs on the LDS-DMA GEMM path (conv_deep), which takes dy with the output
+ * activation's derivative already applied (evt_dact_mul) and out_act = EVT_ACT_NONE in the backward calls; else 0. */
+int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c);
+
 int32_t evt_conv1d_lout(const evt_conv1d_params* p);
 
 /* Prepared-weight layouts.  The parameter tensor is W[d0][d1][k] (Conv1d: d0=cout, d1=cin/g;
@@ -125,6 +129,13 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* p, const void* x, const void*
 /* out = (a + b + c) * scale ; b, c may be NULL.  (Generator stage mean, models.py:457-466) */
 int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, float scale, void* out,
                    int64_t n, void* stream);
+
+/* out = dy * act'(y), the activation derivative taken through the activation OUTPUT y (leaky-relu keeps the sign,
+ * tanh' = 1 - y^2).  Replaces the autograd node of F.leaky_relu after a wide DiscriminatorP conv
+ * (models.py:527-531) when evt_conv1d_wants_plain_dy() says the GEMM-grade path will consume dy: both backward
+ * GEMMs then read the pre-multiplied tensor instead of fusing the derivative into their loads.  16-byte aligned. */
+int evt_dact_mul(int32_t dtype, const void* dy, const void* y, int32_t act_kind, float slope, void* out, int64_t n,
+                 void* stream);
 
 /* WN gated activation, commons.py:94-101 (fused_add_tanh_sigmoid_multiply), channels-last:
  *   acts[n][t][h] = tanh(xin[n][t][h] + g[n][h]) * sigmoid(xin[n][t][H+h] + g[n][H+h])

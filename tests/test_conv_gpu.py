@@ -126,3 +126,30 @@ def test_conv_parity(gpu, ci, impl, dtype):
         if fusion["res"] and case[7]:
             continue
         _run_case(gpu, case, fusion, dtype, impl)
+
+
+# wide layers of DiscriminatorP (models.py:487-536) at sizes that select the LDS-DMA GEMM path (conv_deep):
+# forward, backward-data (stride 1 and polyphase) and the pre-multiplied activation derivative
+DEEP_CASES = [
+    (512, 1024, 5, 3, 2, 1, 1, False, True, 225, 40),
+    (1024, 1024, 5, 1, 2, 1, 1, False, True, 37, 90),     # sequences shorter than a 128-position tile
+    (128, 512, 5, 3, 2, 1, 1, False, True, 207, 130),
+    (256, 256, 7, 1, 9, 3, 1, False, True, 700, 20),      # dilated, long sequences
+]
+
+
+@pytest.mark.parametrize("ci", range(len(DEEP_CASES)))
+def test_conv_deep_parity(gpu, ci):
+    from easevoice_trainer_amd.hip import conv as HC
+
+    case = DEEP_CASES[ci]
+    for fusion in (FUSIONS[2], FUSIONS[0]):
+        HC.TRACE = []
+        try:
+            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            tags = {(r[1], r[0]) for r in HC.TRACE}
+        finally:
+            HC.TRACE = None
+        assert ("fwd", "conv_deep<bf16, 128, 128, 64>") in tags, tags
+        assert ("bwd_data", "conv_deep<bf16, 128, 128, 64>") in tags, tags
+        assert ("bwd_weight", "wgrad_deep<bf16, 128, 5x32, 64>") in tags, tags

@@ -55,6 +55,9 @@ def main():
         H = (Hin + 4 - 5) // s + 1
     # DiscriminatorP p=11 deep layer (short sequences)
     shapes.append(("dP11 1024->1024 s1 H23", 2 * B * 11, 23, 1024, 1024, 5, 1, 2, 1, 1, False, 1.0, 1))
+    shapes.append(("dP11 512->1024 s3 H69", 2 * B * 11, 69, 512, 1024, 5, 3, 2, 1, 1, False, 1.0, 1))
+    shapes.append(("dP5 512->1024 s3 H152", 2 * B * 5, 152, 512, 1024, 5, 3, 2, 1, 1, False, 1.0, 1))
+    shapes.append(("dP11 128->512 s3 H207", 2 * B * 11, 207, 128, 512, 5, 3, 2, 1, 1, False, 1.0, 1))
     shapes.append(("dS 1024->1024 k5 L80", 2 * B, 80, 1024, 1024, 5, 1, 2, 1, 1, False, 1.0, 1))
     shapes.append(("dS grouped 16->64 k41 s4 g4", 2 * B, 20480, 16, 64, 41, 4, 20, 1, 4, False, 1.0, 1))
     shapes.append(("dS grouped 256->1024 k41 s4 g64", 2 * B, 1280, 256, 1024, 41, 4, 20, 1, 64, False, 1.0, 1))
@@ -82,8 +85,11 @@ def main():
         macs = nseq * (lout if not tr else Lx) * ci * co * k / g
         bytes_act = (x.numel() + y.numel()) * sz
         t_f = time_fn(lambda: HC._fwd(slot, x, None, slope, oact, 0.1), iters=a.iters)
-        t_d = time_fn(lambda: HC._bwd_data(slot, dy, y, x, None, nseq, Lx, slope, oact, 0.1), iters=a.iters)
-        t_w = time_fn(lambda: HC._bwd_weight(slot, x, dy, y, nseq, Lx, slope, oact, 0.1), iters=a.iters)
+        boact, by = oact, y
+        if oact and L.lib().evt_conv1d_wants_plain_dy(C.byref(slot.params(nseq, Lx, slope, oact, 0.1))):
+            boact, by = 0, None        # the autograd node pre-multiplies dy by the activation derivative (evt_dact_mul)
+        t_d = time_fn(lambda: HC._bwd_data(slot, dy, by, x, None, nseq, Lx, slope, boact, 0.1), iters=a.iters)
+        t_w = time_fn(lambda: HC._bwd_weight(slot, x, dy, by, nseq, Lx, slope, boact, 0.1), iters=a.iters)
         row = dict(name=name, gmac=macs / 1e9, fwd_ms=t_f, bwdd_ms=t_d, bwdw_ms=t_w,
                    fwd_tflops=2 * macs / t_f / 1e9, bwdd_tflops=2 * macs / t_d / 1e9, bwdw_tflops=2 * macs / t_w / 1e9,
                    fwd_gbs=bytes_act / t_f / 1e6)

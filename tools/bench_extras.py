@@ -35,7 +35,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
     finally:
         HC.TRACE = None
     agg = {}
-    for tag, kind, flops, nbytes, e0, e1 in rec:
+    for tag, kind, flops, nbytes, e0, e1, _shape in rec:
         a = agg.setdefault(tag, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
         a["ms"] += e0.elapsed_time(e1)
         a["calls"] += 1
