@@ -650,6 +650,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       }
     }
   }
+  if (do_bias) {
+    // one atomic per column and block: same-address fp32 atomics from different XCDs serialise at the memory side
+    // (~50 ns each), so 256 per block made this the whole cost of the narrow layers
+    float* bred = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    bred[tid] = bsum;
+    __syncthreads();
+    if (tid < TA) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 256 / TA; ++r) sum += bred[r * TA + tid];
+      atomicAdd(p.dbias + a0 + tid, sum);
+    }
+  }
   if (NPS > 1) {
     // sum the position-slice waves inside the block first: 1/NPS of the global atomics
     float* red = reinterpret_cast<float*>(smem);
@@ -661,10 +675,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(((wave * KT + t) * NTB + j) * 4 + r) * 64 + lane] = acc[t][j][r];
     __syncthreads();
-    if (ps != 0) {
-      if (do_bias) atomicAdd(p.dbias + a0 + bcol, bsum);
-      return;
-    }
+    if (ps != 0) return;
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -689,7 +700,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       }
     }
   }
-  if (do_bias) atomicAdd(p.dbias + a0 + bcol, bsum);
 }
 
 // dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last; per-block LDS accumulation, 16-byte loads
@@ -1303,7 +1313,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
     if (c->cout % V == 0 && c->cout <= 1024) {
-      long rpb = (rows + 1023) / 1024;
+      long rpb = (rows + 127) / 128;   // <= 128 blocks: every block ends with one global atomic per channel
       if (rpb < 16) rpb = 16;
       const int blocks = (int)((rows + rpb - 1) / rpb);
       if (c->dtype == EVT_DT_BF16)

@@ -398,7 +398,10 @@ bool wgrad_deep_eligible(const WgP& p, int dtype) {
   if ((long)p.nseq * p.Q >= (1L << 31) - WPOS) return false;
   // worth it only for GEMM-sized problems: enough (A tile, chunk) pairs and enough positions
   const long tiles = (long)(p.CA / 128) * (p.CB / 32) * ((p.KHp + WKT - 1) / WKT);
-  return tiles >= 16 && (long)p.nseq * p.Q >= 2048;
+  const long nstages = ((long)p.nseq * p.Q + WPOS - 1) / WPOS;
+  long split = (1024 + tiles - 1) / tiles;
+  if (split > nstages / 8) split = nstages / 8;
+  return split >= 1 && tiles * split >= 256;                // enough blocks of >= 8 K stages to fill the chip
 }
 
 int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
