@@ -35,7 +35,13 @@ extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const vo
 extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
                                     void* stream);
 extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
-                                   void* stream);
+                                   float* dbias, void* stream);
+extern "C" int evt_cin1_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
+                            void* stream);
+extern "C" int evt_cin1_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
+                                 const void* gate, const void* dx_add, void* dx, void* stream);
+extern "C" int evt_cout1_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
+                                  const void* gate, const void* dx_add, void* dx, void* stream);
 
 namespace {
 
@@ -1180,6 +1186,10 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
     if (!w_reg) return EVT_EINVAL;
     return evt_cout1_fwd(c, x, w_reg, bias, y, stream);
   }
+  if (c->impl != EVT_IMPL_NAIVE && !res && evt_small_kind(c) == 2) {
+    if (!w_reg) return EVT_EINVAL;
+    return evt_cin1_fwd(c, x, w_reg, bias, y, stream);
+  }
   if (!use_igemm) {
     if (!w_reg) return EVT_EINVAL;
     NvP p = make_nvp(c);
@@ -1237,6 +1247,12 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
     if (!w_reg) return EVT_EINVAL;
     evt_set_last_tag("grouped_bwd_data");
     return evt_grouped_bwd_data(c, dy, y, w_reg, dx, stream);
+  }
+  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) != 0) {
+    if (!w_reg) return EVT_EINVAL;
+    rc = evt_small_kind(c) == 1 ? evt_cout1_bwd_data(c, dy, y, w_reg, gate, dx_add, dx, stream)
+                                : evt_cin1_bwd_data(c, dy, y, w_reg, gate, dx_add, dx, stream);
+    if (rc != EVT_ENOTSUP) return rc;
   }
   if (!use_igemm) {
     if (!w_reg) return EVT_EINVAL;
@@ -1308,7 +1324,8 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   // wide layers with plain operands: LDS-DMA GEMM kernel (conv_deep.hip); its dbias comes from the column-sum kernel
   const bool deep_w = igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
-  const bool fuse_bias = dbias && igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed && !deep_w;
+  const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
+  const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed && !deep_w) || cin1);
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
@@ -1338,7 +1355,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   evt_set_last_tag("conv_other_bwd_weight");
   if (grouped) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
   if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, stream);
-  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2) return evt_cin1_bwd_weight(c, x, dy, y, dw, stream);
+  if (cin1) return evt_cin1_bwd_weight(c, x, dy, y, dw, dbias, stream);
   const bool use_igemm = igemm_path;
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   if (!use_igemm) {
