@@ -67,6 +67,10 @@ def run_s2(args, world, rank, local):
         reducer.broadcast_params(eng.rt_g.arena.param)
         reducer.broadcast_params(eng.rt_d.arena.param)
     eng.build_optimizers()
+    use_graphs = bool(getattr(args, "graphs", 0))
+    if use_graphs:
+        # fixed-shape batches: after two eager steps the step is captured once and replayed as three HIP graphs
+        eng.enable_graphs(warmup_steps=2)
     B, T, t_text = args.batch, args.clip_seconds * 50, 60
     wav, ssl, text, lengths, tl = synth_s2_batch(B, T, t_text, dev, 1234 + rank)
     spec = spectrogram_torch(wav.squeeze(1), 2048, 32000, 640, 2048)
@@ -74,7 +78,7 @@ def run_s2(args, world, rank, local):
     def step():
         return eng.step(ssl, spec, lengths, wav, text, tl)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 4 if use_graphs else 0)):   # graph mode: 2 eager + capture + 1 replay first
         out = step()
     if world > 1:
         torch.distributed.barrier()
@@ -99,7 +103,8 @@ def run_s2(args, world, rank, local):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"s2 SoVITS generator+discriminator GAN step, batch={B}/GPU, {args.clip_seconds} s 32 kHz "
                                f"clips (T={T} frames), configs/s2.json, random-init weights",
-                   "global_batch": world * B, "parallelism": f"dp{world}"},
+                   "global_batch": world * B, "parallelism": f"dp{world}",
+                   "launch": "hip-graph replay (3 graphs/step)" if use_graphs else "eager"},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
@@ -115,6 +120,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--clip-seconds", type=int, default=4)
+    ap.add_argument("--graphs", type=int, default=1, help="1: replay the step as HIP graphs (default), 0: eager launches")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
     args = ap.parse_args()
     world, rank, local = init_dist(args.gpus)

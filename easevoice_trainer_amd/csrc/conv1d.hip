@@ -708,32 +708,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
   }
 }
 
-// dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last; per-block LDS accumulation, 16-byte loads
+// dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last.  A thread owns one 16-byte column group and walks
+// the block's rows with register accumulators (rows_par rows in flight per pass); one LDS merge and one global atomic per
+// channel and block.  Requires C % V == 0 and C / V <= 256.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_act2(const T* dy, const T* ys, float* out, long rows, int C, int kind,
                                                    float slope, int rows_per_block) {
-  __shared__ float acc[1024];
+  __shared__ float acc[2048];
   constexpr int V = 16 / sizeof(T);
   for (int c = threadIdx.x; c < C; c += 256) acc[c] = 0.f;
   __syncthreads();
+  const int ppr = C / V;
+  const int rows_par = 256 / ppr;
+  const int piece = threadIdx.x % ppr, rsub = threadIdx.x / ppr;
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
-  const long n = (r1 - r0) * C / V;   // C % V == 0 guaranteed by the launcher
-  const T* base = dy + r0 * C;
-  const T* ybase = ys ? ys + r0 * C : nullptr;
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const uint4 v = *reinterpret_cast<const uint4*>(base + i * V);
-    uint4 va = make_uint4(0, 0, 0, 0);
-    if (ybase) va = *reinterpret_cast<const uint4*>(ybase + i * V);
-    const T* pv = reinterpret_cast<const T*>(&v);
-    const T* pa = reinterpret_cast<const T*>(&va);
-    const int c0 = (int)((i * V) % C);
+  float a[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float d = to_f<T>(pv[e]);
-      if (ybase) d *= dact_from_out(kind, to_f<T>(pa[e]), slope);
-      atomicAdd(&acc[c0 + e], d);
+  for (int e = 0; e < V; ++e) a[e] = 0.f;
+  if (rsub < rows_par) {
+    for (long r = r0 + rsub; r < r1; r += rows_par) {
+      const long off = r * C + piece * V;
+      const uint4 v = *reinterpret_cast<const uint4*>(dy + off);
+      uint4 va = make_uint4(0, 0, 0, 0);
+      if (ys) va = *reinterpret_cast<const uint4*>(ys + off);
+      const T* pv = reinterpret_cast<const T*>(&v);
+      const T* pa = reinterpret_cast<const T*>(&va);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float d = to_f<T>(pv[e]);
+        if (ys) d *= dact_from_out(kind, to_f<T>(pa[e]), slope);
+        a[e] += d;
+      }
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e) atomicAdd(&acc[piece * V + e], a[e]);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) atomicAdd(out + c, acc[c]);
@@ -1329,8 +1338,8 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
-    if (c->cout % V == 0 && c->cout <= 1024) {
-      long rpb = (rows + 127) / 128;   // <= 128 blocks: every block ends with one global atomic per channel
+    if (c->cout % V == 0 && c->cout / V <= 256) {
+      long rpb = (rows + 255) / 256;   // <= 256 blocks: every block ends with one global atomic per channel
       if (rpb < 16) rpb = 16;
       const int blocks = (int)((rows + rpb - 1) / rpb);
       if (c->dtype == EVT_DT_BF16)

@@ -208,6 +208,32 @@ __global__ void adamw_flat_kernel(float* p, const float* g, float* m, float* v, 
   }
 }
 
+__global__ void counter_inc_kernel(int* c) { *c += 1; }
+
+// same update, bias corrections from a step number held in device memory (graph-replayable: no per-step host argument)
+__global__ void adamw_flat_dev_kernel(float* p, const float* g, float* m, float* v, const evt_adamw_seg* segs, int nseg,
+                                      float b1, float b2, float eps, const int* stepp, float gscale, long lo, long hi) {
+  const float stepf = (float)*stepp;
+  const float bc1 = 1.f - powf(b1, stepf);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, stepf));
+  for (long i = lo + blockIdx.x * (long)blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
+    int si = -1;
+    for (int s = 0; s < nseg; ++s)
+      if (i >= segs[s].begin && i < segs[s].end) { si = s; break; }
+    if (si < 0) continue;
+    const float lr = segs[si].lr, wd = segs[si].weight_decay;
+    const float gr = g[i] * gscale;
+    float pv = p[i];
+    pv *= 1.f - lr * wd;
+    const float mv = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mv; v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv;
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -354,6 +380,17 @@ int evt_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_a
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, segs, nseg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, 0L, (long)n);
+  return evt_check_launch();
+}
+
+int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                       int32_t* step_counter, float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || !step_counter || n <= 0)
+    return EVT_EINVAL;
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, 0L, (long)n);
   return evt_check_launch();
 }
 

@@ -124,11 +124,26 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_PINNED_KEEP = []   # host staging buffers referenced by captured H2D copy nodes must outlive the graphs
+
+
 def struct_to_device(items, device) -> torch.Tensor:
-    """copy a python list of ctypes structures to a device uint8 tensor"""
+    """copy a python list of ctypes structures to a device uint8 tensor.  The staging buffer is pinned and the copy
+    is asynchronous on the current stream, so the call is legal while a HIP graph is being captured (the copy becomes
+    a graph node that re-reads the pinned buffer on every replay; the buffer is kept alive for that)."""
     if not items:
         raise EvtError("empty table")
     arr = (type(items[0]) * len(items))(*items)
     buf = bytes(arr)
-    host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
-    return host.to(device)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
+    host = torch.empty(len(buf), dtype=torch.uint8, pin_memory=True)
+    host.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+    dev = torch.empty(len(buf), dtype=torch.uint8, device=device)
+    dev.copy_(host, non_blocking=True)
+    if torch.cuda.is_current_stream_capturing():
+        _PINNED_KEEP.append(host)
+    else:
+        dev._evt_host = host     # the copy may still be in flight when this function returns
+    return dev

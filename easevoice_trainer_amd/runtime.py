@@ -62,6 +62,7 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(arena.param)
         self.exp_avg_sq = torch.zeros_like(arena.param)
         self.step_count = 0
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=arena.device)   # the kernels' copy of step_count
         self.groups = []
         named = dict(arena.model.named_parameters())
         for g in groups:
@@ -90,7 +91,11 @@ class FlatAdamW:
                     segs.append(L.AdamWSeg(b, e, g["lr"], self.weight_decay))
             if len(segs) > 64:
                 raise L.EvtError(f"{len(segs)} AdamW segments (max 64): register parameters group-contiguously")
-            self._table = L.struct_to_device(segs, self.arena.device)
+            new = L.struct_to_device(segs, self.arena.device)
+            if self._table is None:
+                self._table = new
+            else:
+                self._table.copy_(new)     # in place: captured graphs keep reading the same device table
             self._nseg = len(segs)
             self._table_lrs = lrs
         return self._table, self._nseg
@@ -99,10 +104,15 @@ class FlatAdamW:
         self.step_count += 1
         tab, nseg = self._segments()
         a = self.arena
-        L.check(L.lib().evt_adamw_flat(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                       C.c_int64(a.numel), L.ptr(tab), nseg, C.c_float(self.betas[0]),
-                                       C.c_float(self.betas[1]), C.c_float(self.eps), self.step_count,
-                                       C.c_float(grad_scale), L.stream_ptr()), "evt_adamw_flat")
+        L.check(L.lib().evt_adamw_flat_dev(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                           C.c_int64(a.numel), L.ptr(tab), nseg, C.c_float(self.betas[0]),
+                                           C.c_float(self.betas[1]), C.c_float(self.eps), L.ptr(self._step_dev),
+                                           C.c_float(grad_scale), L.stream_ptr()), "evt_adamw_flat_dev")
+
+    def note_replayed_step(self):
+        """a captured graph ran the update: keep the python-side counter (checkpoints) in step with the device one"""
+        self.step_count += 1
+        self._segments()    # pick up learning-rate changes made by a scheduler (in-place table update)
 
     # ---- torch.optim-compatible checkpoint surface (src/utils/path/ckpt.py:78-93 stores optimizer.state_dict()) ----
     def state_dict(self):
@@ -135,6 +145,7 @@ class FlatAdamW:
                     self.exp_avg_sq[b:e].copy_(st["exp_avg_sq"].reshape(-1))
                     self.step_count = max(self.step_count, int(float(st["step"])))
                 idx += 1
+        self._step_dev.fill_(self.step_count)
 
 
 class ModelRuntime:

@@ -10,6 +10,7 @@ Differences from the reference that do not change the arithmetic of the losses /
   * bf16 compute needs no GradScaler (the reference's fp16 autocast + GradScaler is SURVEY §8(f) N4).
 """
 from dataclasses import dataclass, field
+from types import SimpleNamespace
 from typing import Optional
 
 import torch
@@ -49,6 +50,7 @@ class S2Engine:
         self.rt_d = ModelRuntime(self.net_d, dtype, self.device, impl)
         self.reducer = reducer  # dist.GradReducer or None
         self.optim_g = self.optim_d = None
+        self.graphs_enabled = False
 
     # -- optimisers: 4 groups for G exactly as sovits.py:286-319 (text_embedding / encoder_text / mrte at a
     #    lower lr), everything that receives no gradient (ssl_proj) left out
@@ -69,9 +71,15 @@ class S2Engine:
                                  betas=tuple(t["betas"]), eps=t["eps"])
         return self.optim_g, self.optim_d
 
-    def step(self, ssl, spec, spec_lengths, y, text, text_lengths, eps=None, ids_slice=None, do_opt=True,
-             hook_after_d=None) -> S2Losses:
-        """One GAN step.  Layouts as in the reference: ssl [B,768,T], spec [B,1025,T], y [B,1,T*hop], text [B,Tt]."""
+    # ------------------------------------------------------------------------------------------------------------
+    # The step is three phases with the two gradient exchanges between them:
+    #   A  zero grads, fold weights, G forward, mel targets, D step forward + backward          -> all-reduce(D grads)
+    #   B  D grad-norm + AdamW, refold D, G step through D forward + backward                   -> all-reduce(G grads)
+    #   C  G grad-norm + AdamW
+    # Each phase has no host synchronisation and no per-step host argument, so with fixed batch shapes it is captured
+    # once into a HIP graph and replayed (enable_graphs): ~4600 launches per step become three graph launches.
+    # ------------------------------------------------------------------------------------------------------------
+    def _phase_a(self, st):
         d, t = self.hps["data"], self.hps["train"]
         hop, seg = d["hop_length"], t["segment_size"]
         net_g, net_d, rt_g, rt_d = self.net_g, self.net_d, self.rt_g, self.rt_d
@@ -79,55 +87,134 @@ class S2Engine:
         rt_d.zero_grad()
         rt_g.prepare()
         rt_d.prepare()
-
-        (y_hat, kl_ssl, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), _q) = net_g(
-            ssl, spec, spec_lengths, text, text_lengths, eps=eps, ids_slice=ids_slice)
-        mel = spec_to_mel_torch(spec, d["filter_length"], d["n_mel_channels"], d["sampling_rate"], d["mel_fmin"],
+        (st.y_hat, st.kl_ssl, st.ids_slice, st.x_mask, st.z_mask, st.lat, st.q) = net_g(
+            st.ssl, st.spec, st.spec_lengths, st.text, st.text_lengths, eps=st.eps, ids_slice=st.ids_slice_in)
+        mel = spec_to_mel_torch(st.spec, d["filter_length"], d["n_mel_channels"], d["sampling_rate"], d["mel_fmin"],
                                 d["mel_fmax"])
-        y_mel = commons.slice_segments(mel.transpose(1, 2), ids_slice, seg // hop).transpose(1, 2)
-        y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
-                                          d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
-        y_seg = commons.slice_segments_1d(y.squeeze(1), ids_slice * hop, seg)
-
+        st.y_mel = commons.slice_segments(mel.transpose(1, 2), st.ids_slice, seg // hop).transpose(1, 2)
+        st.y_hat_mel = mel_spectrogram_torch(st.y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
+                                             d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
+        st.y_seg = commons.slice_segments_1d(st.y.squeeze(1), st.ids_slice * hop, seg)
         # ---- discriminator step (sovits.py:497-507) ----
         rt_d.bank.weight_grads = True
-        y_d_hat_r, y_d_hat_g, _, _ = net_d(y_seg, y_hat.detach())
-        loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
-        loss_disc.backward()
+        y_d_hat_r, y_d_hat_g, _, _ = net_d(st.y_seg, st.y_hat.detach())
+        st.loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
+        st.loss_disc.backward()
         rt_d.finish_grads()
-        inv_world = 1.0
-        if self.reducer is not None:
-            # averaged inside the AdamW launch (grad_scale); the generator-side work below does not depend on it
-            self.reducer.all_reduce(rt_d.arena.grad)
-            inv_world = 1.0 / self.reducer.world
-        gss_d = rt_d.grad_sumsq().clone()
-        if hook_after_d is not None:
-            hook_after_d()
-        if do_opt:
-            self.optim_d.step(grad_scale=inv_world)
-            rt_d.prepare()   # D weights changed: refold before the generator's pass through D
 
+    def _phase_b(self, st):
+        t = self.hps["train"]
+        net_d, rt_g, rt_d = self.net_d, self.rt_g, self.rt_d
+        st.gss_d = rt_d.grad_sumsq().clone()
+        if st.hook_after_d is not None:
+            st.hook_after_d()
+        if st.do_opt:
+            self.optim_d.step(grad_scale=st.inv_world)   # 1/world averaging folded into the AdamW launch
+            rt_d.prepare()   # D weights changed: refold before the generator's pass through D
         # ---- generator step (sovits.py:509-525) ----
         rt_d.bank.weight_grads = False
         with torch.no_grad():
-            _, fmap_r = net_d.forward_single(y_seg)
-        y_d_hat_g, fmap_g = net_d.forward_single(y_hat)
-        loss_mel = F.l1_loss(y_mel, y_hat_mel) * t["c_mel"]
-        loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * t["c_kl"]
-        loss_fm = feature_loss(fmap_r, fmap_g)
-        loss_gen = generator_loss(y_d_hat_g)
-        loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
-        loss_gen_all.backward()
+            _, fmap_r = net_d.forward_single(st.y_seg)
+        st.y_d_hat_g, fmap_g = net_d.forward_single(st.y_hat)
+        z, z_p, m_p, logs_p, m_q, logs_q = st.lat
+        st.loss_mel = F.l1_loss(st.y_mel, st.y_hat_mel) * t["c_mel"]
+        st.loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, st.z_mask) * t["c_kl"]
+        st.loss_fm = feature_loss(fmap_r, fmap_g)
+        st.loss_gen = generator_loss(st.y_d_hat_g)
+        st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
+        st.loss_gen_all.backward()
         rt_d.bank.weight_grads = True
         rt_g.finish_grads()
-        if self.reducer is not None:
-            self.reducer.all_reduce(rt_g.arena.grad)
-        gss_g = rt_g.grad_sumsq().clone()
-        if do_opt:
-            self.optim_g.step(grad_scale=inv_world)
-        return S2Losses(loss_disc.detach(), loss_gen.detach(), loss_fm.detach(), loss_mel.detach(), loss_kl.detach(),
-                        kl_ssl.detach(), loss_gen_all.detach(), gss_d, gss_g,
-                        extras=dict(y_hat=y_hat.detach(), y_hat_mel=y_hat_mel.detach(), y_mel=y_mel.detach(),
-                                    ids_slice=ids_slice, z=z.detach(), z_p=z_p.detach(), m_p=m_p.detach(),
+
+    def _phase_c(self, st):
+        st.gss_g = self.rt_g.grad_sumsq().clone()
+        if st.do_opt:
+            self.optim_g.step(grad_scale=st.inv_world)
+
+    @staticmethod
+    def _result(st) -> S2Losses:
+        z, z_p, m_p, logs_p, m_q, logs_q = st.lat
+        return S2Losses(st.loss_disc.detach(), st.loss_gen.detach(), st.loss_fm.detach(), st.loss_mel.detach(),
+                        st.loss_kl.detach(), st.kl_ssl.detach(), st.loss_gen_all.detach(), st.gss_d, st.gss_g,
+                        extras=dict(y_hat=st.y_hat.detach(), y_hat_mel=st.y_hat_mel.detach(), y_mel=st.y_mel.detach(),
+                                    ids_slice=st.ids_slice, z=z.detach(), z_p=z_p.detach(), m_p=m_p.detach(),
                                     logs_p=logs_p.detach(), m_q=m_q.detach(), logs_q=logs_q.detach(),
-                                    d_logits=[o.detach() for o in y_d_hat_g], quantized=_q.detach()))
+                                    d_logits=[o.detach() for o in st.y_d_hat_g], quantized=st.q.detach()))
+
+    def _reduce(self, arena):
+        if self.reducer is not None:
+            self.reducer.all_reduce(arena.grad)
+
+    def step(self, ssl, spec, spec_lengths, y, text, text_lengths, eps=None, ids_slice=None, do_opt=True,
+             hook_after_d=None) -> S2Losses:
+        """One GAN step.  Layouts as in the reference: ssl [B,768,T], spec [B,1025,T], y [B,1,T*hop], text [B,Tt]."""
+        if self.graphs_enabled and do_opt and hook_after_d is None:
+            return self._step_graphed((ssl, spec, spec_lengths, y, text, text_lengths, eps, ids_slice))
+        st = SimpleNamespace(ssl=ssl, spec=spec, spec_lengths=spec_lengths, y=y, text=text, text_lengths=text_lengths,
+                             eps=eps, ids_slice_in=ids_slice, do_opt=do_opt, hook_after_d=hook_after_d,
+                             inv_world=1.0 / self.reducer.world if self.reducer is not None else 1.0)
+        self._phase_a(st)
+        self._reduce(self.rt_d.arena)
+        self._phase_b(st)
+        self._reduce(self.rt_g.arena)
+        self._phase_c(st)
+        return self._result(st)
+
+    # ---- HIP-graph replay of the step for repeated batch shapes ----
+    def enable_graphs(self, warmup_steps: int = 2, max_shapes: int = 16):
+        """Capture the three phases per distinct batch shape after `warmup_steps` eager steps of that shape and replay
+        them afterwards.  Every captured shape keeps its own activation pool in HBM (a few GB each; 288 GB holds the
+        bucketed shapes of a run), `max_shapes` bounds it -- further shapes run eagerly."""
+        self.graphs_enabled = True
+        self._graph_warmup, self._graph_max = warmup_steps, max_shapes
+        self._graph_cache = {}
+
+    def _step_graphed(self, inputs) -> S2Losses:
+        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in inputs)
+        ent = self._graph_cache.get(key)
+        if ent is None:
+            ent = self._graph_cache[key] = dict(seen=0, graphs=None)
+        if ent["graphs"] is None:
+            ent["seen"] += 1
+            captured = sum(1 for e in self._graph_cache.values() if e["graphs"] is not None)
+            if ent["seen"] <= self._graph_warmup or captured >= self._graph_max:
+                self.graphs_enabled = False
+                try:
+                    return self.step(*inputs)
+                finally:
+                    self.graphs_enabled = True
+            self._capture(ent, inputs)
+        for dst, src in zip(ent["static"], inputs):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        ga, gb, gc = ent["graphs"]
+        ga.replay()
+        self._reduce(self.rt_d.arena)
+        gb.replay()
+        self._reduce(self.rt_g.arena)
+        gc.replay()
+        self.optim_d.note_replayed_step()
+        self.optim_g.note_replayed_step()
+        return ent["result"]
+
+    def _capture(self, ent, inputs):
+        static = [t.clone() if t is not None else None for t in inputs]
+        ssl, spec, spec_lengths, y, text, text_lengths, eps, ids_slice = static
+        st = SimpleNamespace(ssl=ssl, spec=spec, spec_lengths=spec_lengths, y=y, text=text, text_lengths=text_lengths,
+                             eps=eps, ids_slice_in=ids_slice, do_opt=True, hook_after_d=None,
+                             inv_world=1.0 / self.reducer.world if self.reducer is not None else 1.0)
+        self.optim_d._segments()   # device tables exist before capture
+        self.optim_g._segments()
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        for phase in (self._phase_a, self._phase_b, self._phase_c):
+            g = torch.cuda.CUDAGraph()
+            # "relaxed": pinned staging buffers of the loss tables may be allocated while capturing
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="relaxed"):
+                phase(st)
+            graphs.append(g)
+        # capture records the optimiser launches without running them: undo the python-side counters it bumped
+        self.optim_d.step_count -= 1
+        self.optim_g.step_count -= 1
+        ent.update(graphs=tuple(graphs), static=static, st=st, result=self._result(st))

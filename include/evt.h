@@ -177,6 +177,12 @@ typedef struct evt_adamw_seg { int64_t begin, end; float lr; float weight_decay;
 int evt_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps, int32_t step,
                    float grad_scale, void* stream);
+/* The same update with the step number in DEVICE memory: *step_counter is incremented by one (a 1-thread launch) and
+ * the bias corrections are computed from it on the device.  No argument changes from step to step, so the call can be
+ * captured into a HIP graph and replayed. */
+int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                       int32_t* step_counter, float grad_scale, void* stream);
 /* out[0] = sum(x^2) over n floats (grad-norm at commons.py:140-155 without the per-parameter .item()) */
 int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
 

@@ -27,6 +27,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
     from easevoice_trainer_amd.hip import conv as HC
 
     HC.TRACE = []
+    graphs, eng.graphs_enabled = eng.graphs_enabled, False   # per-launch events need the eager path
     try:
         for _ in range(n_steps):
             step_fn()
@@ -34,6 +35,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         rec = HC.TRACE
     finally:
         HC.TRACE = None
+        eng.graphs_enabled = graphs
     agg = {}
     for tag, kind, flops, nbytes, e0, e1, _shape in rec:
         a = agg.setdefault(tag, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
