@@ -8,6 +8,7 @@ torch.nn.Conv1d / ConvTranspose1d / Conv2d((k,1)) with optional old-style weight
 modules.py:154-185,226-296.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -98,6 +99,12 @@ class WeightBank:
         self.dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
         self.dtype, self.device, self.impl = dtype, torch.device(device), impl
         self.weight_grads = True
+        # EVT_ASYNC_WGRAD=1: weight gradients on a side HIP stream next to the backward-data chain; grads() joins and
+        # the operands are held until then.  Measured on MI355X: -1.6 ms/step with eager launches, +7 ms/step under
+        # HIP-graph replay (fork/join edges per conv), so it is off by default.
+        self.async_wgrad = self.device.type == "cuda" and os.environ.get("EVT_ASYNC_WGRAD", "0") == "1"
+        self._side = None
+        self._held = []
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
         self.slots = []
         reg_n = alt_n = 0
@@ -158,8 +165,19 @@ class WeightBank:
     def zero_dw(self):
         self.dw_arena.zero_()
 
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def join_side(self):
+        if self._side is not None and self._held:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._held.clear()
+
     def grads(self):
         """dW images -> weight_v.grad / weight_g.grad (or weight.grad): ONE launch."""
+        self.join_side()
         L.check(L.lib().evt_wn_grad_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
                 "evt_wn_grad_multi")
 
@@ -225,6 +243,18 @@ def _bwd_data(slot, dy, y, x, dx_add, nseq, lin, in_slope, out_act, out_slope):
 
 
 def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
+    bank = slot.bank
+    if bank.async_wgrad and TRACE is None:
+        side = bank.side_stream()
+        side.wait_stream(torch.cuda.current_stream(bank.device))
+        with torch.cuda.stream(side):
+            _bwd_weight_now(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
+        bank._held.append((x, dy, y))
+        return
+    _bwd_weight_now(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
+
+
+def _bwd_weight_now(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
     m = slot.module
     p = slot.params(nseq, lin, in_slope, out_act, out_slope)
     dbias = None

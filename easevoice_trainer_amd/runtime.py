@@ -112,7 +112,6 @@ class FlatAdamW:
     def note_replayed_step(self):
         """a captured graph ran the update: keep the python-side counter (checkpoints) in step with the device one"""
         self.step_count += 1
-        self._segments()    # pick up learning-rate changes made by a scheduler (in-place table update)
 
     # ---- torch.optim-compatible checkpoint surface (src/utils/path/ckpt.py:78-93 stores optimizer.state_dict()) ----
     def state_dict(self):

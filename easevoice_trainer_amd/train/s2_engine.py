@@ -188,6 +188,8 @@ class S2Engine:
             if dst is not None:
                 dst.copy_(src, non_blocking=True)
         ga, gb, gc = ent["graphs"]
+        self.optim_d._segments()    # scheduler changes reach the device tables (in place) before the replay
+        self.optim_g._segments()
         ga.replay()
         self._reduce(self.rt_d.arena)
         gb.replay()

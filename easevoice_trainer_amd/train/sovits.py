@@ -79,6 +79,10 @@ class SovitsTrain:
         reducer = GradReducer(world) if world > 1 else None
         eng = S2Engine(hps, device, self.dtype, reducer=reducer)
         optim_g, optim_d = eng.build_optimizers()
+        if os.environ.get("EVT_GRAPHS", "1") != "0":
+            # batches whose shapes repeat (bucketed / fixed-length sources) are replayed as HIP graphs after two eager
+            # steps of that shape; other shapes keep running eagerly
+            eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "16")))
         source = open_source("s2", hps["data"]["exp_dir"], device,
                              lambda n: SyntheticS2Batches(t["batch_size"], 4, n, device, seed=t["seed"], rank=rank, world=world))
         # resume, else pretrained (sovits.py:327-366)

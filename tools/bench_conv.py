@@ -72,6 +72,7 @@ def main():
     mods = mods.to(dev)
     bank = HC.WeightBank(mods, dtype, dev, impl=a.impl)
     bank.build_tables()
+    bank.async_wgrad = False      # per-call timings below are taken on the current stream
     bank.fold()
     torch.cuda.synchronize()
     rows = []
