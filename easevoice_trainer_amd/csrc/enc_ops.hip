@@ -1,0 +1,268 @@
+// Fused glue of the s2 relative-position transformer encoders (enc_p: encoder_ssl / encoder_text / encoder2), gfx950.
+//
+// Reference call sites (file:line under /root/reference), src/easevoice/module/attentions.py:
+//   :60-75   y = drop(attn(x)); x = norm_1(x + y); y = drop(ffn(x)); x = norm_2(x + y)      -> res_drop_ln_fwd/bwd
+//   modules.py:19-31 LayerNorm over channels (gamma, beta)
+// The reference issues dropout, add, (autocast casts,) layer_norm and the x * x_mask of the next consumer as separate
+// element-wise launches over a [B, T, 192] tensor -- ~3 us of launch each for ~1 us of HBM traffic.  Here one launch
+// reads x and y once, and writes LayerNorm(x + dropout(y)) * row_mask in the compute dtype; the backward regenerates
+// the dropout mask from the counter hash instead of storing it.
+//
+// Row mask: row (b, t) is live iff t < lens[b].  Masked rows are written as zeros.  (The reference leaves LayerNorm(beta)
+// garbage in masked rows and multiplies by x_mask at every consumer; masked rows never reach a live row -- attention masks
+// them as keys, the FFN convolutions take x * x_mask -- so live rows and all parameter gradients are unchanged.)
+//
+// Dropout: keep(element) = hash(*seed_dev, site, element index) >= p * 2^32, scaled by 1/(1-p).  *seed_dev is a device
+// counter the engine bumps once per step (evt_counter_inc), so a replayed HIP graph draws fresh masks every step.
+#include "evt_common.h"
+#include "../../include/evt.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {   // lowbias32 finaliser
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+struct DropCfg {
+  unsigned key;      // mix of *seed_dev and the site id
+  unsigned thr;      // keep iff hash >= thr; 0 = dropout off
+  float scale;       // 1 / (1 - p)
+};
+
+__device__ __forceinline__ DropCfg drop_cfg(float p, const unsigned* seed_dev, unsigned site) {
+  DropCfg d;
+  d.thr = p > 0.f ? (unsigned)fminf(p * 4294967296.f, 4294967040.f) : 0u;
+  d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  d.key = mix32((seed_dev ? *seed_dev : 0u) * 0x9E3779B1u + site * 0x85EBCA77u + 0x165667B1u);
+  return d;
+}
+
+__device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned long idx) {
+  if (d.thr == 0u) return 1.f;
+  const unsigned h = mix32((unsigned)idx ^ d.key ^ (unsigned)(idx >> 32) * 0xC2B2AE35u);
+  return h >= d.thr ? d.scale : 0.f;
+}
+
+template <typename T> struct Vec16 { static constexpr int V = 16 / sizeof(T); };
+
+// one wave per row, 16-byte accesses; a lane owns V consecutive channels per pass (C % V == 0, C <= 64*V*NP)
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void res_drop_ln_fwd(const T* x, const T* y, const float* gamma, const float* beta,
+                                                       const int* lens, int rows_per_seq, float p,
+                                                       const unsigned* seed_dev, unsigned site, T* out, float* mean,
+                                                       float* rstd, long rows, int C, float eps) {
+  constexpr int V = Vec16<T>::V;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  bool live = true;
+  if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+  if (!live) {   // wave-uniform
+#pragma unroll
+    for (int pss = 0; pss < NP; ++pss) {
+      const int c0 = (pss * 64 + lane) * V;
+      if (c0 < C) *reinterpret_cast<uint4*>(out + row * C + c0) = make_uint4(0, 0, 0, 0);
+    }
+    if (lane == 0) { mean[row] = 0.f; rstd[row] = 0.f; }
+    return;
+  }
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  float v[NP][V];
+  float s = 0.f;
+#pragma unroll
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C) {
+      const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + c0);
+      const uint4 b = *reinterpret_cast<const uint4*>(y + row * C + c0);
+      const T* pa = reinterpret_cast<const T*>(&a);
+      const T* pb = reinterpret_cast<const T*>(&b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        v[pss][e] = to_f<T>(pa[e]) + to_f<T>(pb[e]) * drop_mult(dc, (unsigned long)(row * C + c0 + e));
+        s += v[pss][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[pss][e] = 0.f;
+    }
+  }
+  const float mu = wave_reduce_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C)
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = v[pss][e] - mu; q += d * d; }
+  }
+  const float rs = rsqrtf(wave_reduce_sum(q) / C + eps);
+#pragma unroll
+  for (int pss = 0; pss < NP; ++pss) {
+    const int c0 = (pss * 64 + lane) * V;
+    if (c0 < C) {
+      uint4 o;
+      T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) po[e] = from_f<T>((v[pss][e] - mu) * rs * gamma[c0 + e] + beta[c0 + e]);
+      *reinterpret_cast<uint4*>(out + row * C + c0) = o;
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = d(x + drop(y)) (residual branch), dy = dx * dropout multiplier (sub-layer branch; null when p == 0: same tensor)
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void res_drop_ln_bwd(const T* x, const T* y, const float* gamma, const T* dout,
+                                                       const float* mean, const float* rstd, const int* lens,
+                                                       int rows_per_seq, float p, const unsigned* seed_dev,
+                                                       unsigned site, T* dx, T* dy, float* dgamma, float* dbeta,
+                                                       long rows, int C, int rows_per_block) {
+  constexpr int V = Vec16<T>::V;
+  __shared__ float sg[4][64 * V * NP], sb[4][64 * V * NP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  float ag[NP][V], ab[NP][V], gm[NP][V];
+#pragma unroll
+  for (int pss = 0; pss < NP; ++pss)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      ag[pss][e] = ab[pss][e] = 0.f;
+      const int c = (pss * 64 + lane) * V + e;
+      gm[pss][e] = c < C ? gamma[c] : 0.f;
+    }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  for (long row = r0 + wave; row < r1; row += 4) {
+    bool live = true;
+    if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+    if (!live) {
+#pragma unroll
+      for (int pss = 0; pss < NP; ++pss) {
+        const int c0 = (pss * 64 + lane) * V;
+        if (c0 < C) {
+          *reinterpret_cast<uint4*>(dx + row * C + c0) = make_uint4(0, 0, 0, 0);
+          if (dy) *reinterpret_cast<uint4*>(dy + row * C + c0) = make_uint4(0, 0, 0, 0);
+        }
+      }
+      continue;
+    }
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NP][V], dh[NP][V], dm[NP][V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int pss = 0; pss < NP; ++pss) {
+      const int c0 = (pss * 64 + lane) * V;
+      if (c0 < C) {
+        const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + c0);
+        const uint4 b = *reinterpret_cast<const uint4*>(y + row * C + c0);
+        const uint4 d4 = *reinterpret_cast<const uint4*>(dout + row * C + c0);
+        const T* pa = reinterpret_cast<const T*>(&a);
+        const T* pb = reinterpret_cast<const T*>(&b);
+        const T* pd = reinterpret_cast<const T*>(&d4);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          dm[pss][e] = drop_mult(dc, (unsigned long)(row * C + c0 + e));
+          const float t = to_f<T>(pa[e]) + to_f<T>(pb[e]) * dm[pss][e];
+          const float d = to_f<T>(pd[e]);
+          xh[pss][e] = (t - mu) * rs;
+          dh[pss][e] = d * gm[pss][e];
+          ag[pss][e] += d * xh[pss][e];
+          ab[pss][e] += d;
+          s1 += dh[pss][e];
+          s2 += dh[pss][e] * xh[pss][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) xh[pss][e] = dh[pss][e] = dm[pss][e] = 0.f;
+      }
+    }
+    s1 = wave_reduce_sum(s1) / C;
+    s2 = wave_reduce_sum(s2) / C;
+#pragma unroll
+    for (int pss = 0; pss < NP; ++pss) {
+      const int c0 = (pss * 64 + lane) * V;
+      if (c0 < C) {
+        uint4 o, o2;
+        T* po = reinterpret_cast<T*>(&o);
+        T* po2 = reinterpret_cast<T*>(&o2);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float g = rs * (dh[pss][e] - s1 - xh[pss][e] * s2);
+          po[e] = from_f<T>(g);
+          po2[e] = from_f<T>(g * dm[pss][e]);
+        }
+        *reinterpret_cast<uint4*>(dx + row * C + c0) = o;
+        if (dy) *reinterpret_cast<uint4*>(dy + row * C + c0) = o2;
+      }
+    }
+  }
+#pragma unroll
+  for (int pss = 0; pss < NP; ++pss)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      sg[wave][(pss * 64 + lane) * V + e] = ag[pss][e];
+      sb[wave][(pss * 64 + lane) * V + e] = ab[pss][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+__global__ void counter_add_kernel(unsigned* c, unsigned inc) { *c += inc; }
+
+}  // namespace
+
+extern "C" {
+
+int evt_counter_inc(uint32_t* counter, uint32_t inc, void* stream) {
+  if (!counter) return EVT_EINVAL;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+  return evt_check_launch();
+}
+
+int evt_res_dropout_ln_fwd(int32_t dtype, const void* x, const void* y, const float* gamma, const float* beta,
+                           const int32_t* lens, int32_t rows_per_seq, float p, const uint32_t* seed_dev, uint32_t site,
+                           void* out, float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || !out || !mean || !rstd || rows <= 0 || C <= 0) return EVT_EINVAL;
+  if (lens && rows_per_seq <= 0) return EVT_EINVAL;
+  if (p < 0.f || p >= 1.f) return EVT_EINVAL;
+  if (C > 1024 || C % 8) return EVT_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((rows + 3) / 4);
+#define RDL_FWD(T, E) hipLaunchKernelGGL((res_drop_ln_fwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, \
+                                         gamma, beta, lens, rows_per_seq, p, seed_dev, site, (T*)out, mean, rstd, (long)rows, C, eps)
+  if (dtype == EVT_DT_BF16) { if (C <= 512) RDL_FWD(bf16_t, 1); else RDL_FWD(bf16_t, 2); }
+  else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_FWD(float, 2); else RDL_FWD(float, 4); }
+  else return EVT_EINVAL;
+#undef RDL_FWD
+  return evt_check_launch();
+}
+
+int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const float* gamma, const void* dout,
+                           const float* mean, const float* rstd, const int32_t* lens, int32_t rows_per_seq, float p,
+                           const uint32_t* seed_dev, uint32_t site, void* dx, void* dy, float* dgamma, float* dbeta,
+                           int64_t rows, int32_t C, void* stream) {
+  if (!x || !y || !gamma || !dout || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return EVT_EINVAL;
+  if (lens && rows_per_seq <= 0) return EVT_EINVAL;
+  if (p < 0.f || p >= 1.f) return EVT_EINVAL;
+  if (p > 0.f && !dy) return EVT_EINVAL;
+  if (C > 1024 || C % 8) return EVT_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  long rpb = (rows + 255) / 256;     // <= 256 blocks: each ends with one atomic per channel
+  if (rpb < 16) rpb = 16;
+  const int blocks = (int)((rows + rpb - 1) / rpb);
+#define RDL_BWD(T, E) hipLaunchKernelGGL((res_drop_ln_bwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, \
+                                         gamma, (const T*)dout, mean, rstd, lens, rows_per_seq, p, seed_dev, site, (T*)dx,   \
+                                         (T*)dy, dgamma, dbeta, (long)rows, C, (int)rpb)
+  if (dtype == EVT_DT_BF16) { if (C <= 512) RDL_BWD(bf16_t, 1); else RDL_BWD(bf16_t, 2); }
+  else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_BWD(float, 2); else RDL_BWD(float, 4); }
+  else return EVT_EINVAL;
+#undef RDL_BWD
+  return evt_check_launch();
+}
+
+}  // extern "C"

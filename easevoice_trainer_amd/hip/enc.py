@@ -1,0 +1,82 @@
+"""Fused element-wise blocks of the s2 transformer encoders (csrc/enc_ops.hip) as autograd functions, plus the
+device-side RNG counter their dropout masks are keyed on.
+
+The counter lives in device memory and is bumped by a 1-thread launch (`bump_rng`), never by a host argument, so a
+captured HIP graph of the training step draws a new dropout mask on every replay."""
+import ctypes as C
+import itertools
+
+import torch
+
+from . import lib as L
+
+_RNG = {}
+_SITES = itertools.count(1)
+
+
+def rng_counter(device) -> torch.Tensor:
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _RNG.get(key)
+    if t is None:
+        t = _RNG[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def seed_rng(device, seed: int):
+    rng_counter(device).fill_(int(seed) & 0x7FFFFFFF)
+
+
+def bump_rng(device):
+    """advance the dropout stream by one step (call once per training step, inside the captured region)"""
+    t = rng_counter(device)
+    L.check(L.lib().evt_counter_inc(L.ptr(t), C.c_uint32(1), L.stream_ptr()), "evt_counter_inc")
+
+
+def new_site() -> int:
+    """a distinct dropout stream id per call site (module instance)"""
+    return next(_SITES)
+
+
+class ResDropLNFn(torch.autograd.Function):
+    """out = LayerNorm(x + dropout(y)) * row_mask   (attentions.py:60-75 of the reference: drop, add, norm, mask)"""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, lens, p, site, eps):
+        if x.shape != y.shape or x.dtype != y.dtype or not x.is_contiguous() or not y.is_contiguous():
+            raise L.EvtError(f"res_drop_ln: x/y must be contiguous and alike, got {tuple(x.shape)} {x.dtype} / "
+                             f"{tuple(y.shape)} {y.dtype}")
+        Cc = x.size(-1)
+        rows = x.numel() // Cc
+        rps = x.size(-2)
+        out = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        seed = rng_counter(x.device)
+        L.check(L.lib().evt_res_dropout_ln_fwd(L.dt_of(x), L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(beta), L.ptr(lens),
+                                               rps, C.c_float(p), L.ptr(seed), C.c_uint32(site), L.ptr(out), L.ptr(mean),
+                                               L.ptr(rstd), C.c_int64(rows), Cc, C.c_float(eps), L.stream_ptr()),
+                "evt_res_dropout_ln_fwd")
+        ctx.save_for_backward(x, y, gamma, mean, rstd, lens)
+        ctx.cfg = (p, site, rps, rows, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, gamma, mean, rstd, lens = ctx.saved_tensors
+        p, site, rps, rows, Cc = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(x) if p > 0.0 else None
+        dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        seed = rng_counter(x.device)
+        L.check(L.lib().evt_res_dropout_ln_bwd(L.dt_of(x), L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(dout), L.ptr(mean),
+                                               L.ptr(rstd), L.ptr(lens), rps, C.c_float(p), L.ptr(seed),
+                                               C.c_uint32(site), L.ptr(dx), L.ptr(dy), L.ptr(dgamma), L.ptr(dbeta),
+                                               C.c_int64(rows), Cc, L.stream_ptr()), "evt_res_dropout_ln_bwd")
+        return dx, (dy if dy is not None else dx), dgamma, dbeta, None, None, None, None
+
+
+def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
+    return ResDropLNFn.apply(x, y, gamma, beta, lens, float(p), int(site), float(eps))

@@ -15,6 +15,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import EvtConv1d
+from ..hip.enc import new_site, res_drop_ln
 
 
 class LayerNorm(nn.Module):
@@ -133,11 +134,14 @@ class FFN(nn.Module):
         self.conv_2 = EvtConv1d(filter_channels, out_channels, kernel_size, padding=(kernel_size - 1) // 2)
         self.drop = nn.Dropout(p_dropout)
 
-    def forward(self, x, x_mask, cd):
-        x = self.conv_1((x * x_mask).to(cd).contiguous(), out_act=L.ACT_LRELU, out_slope=0.0)
+    def forward(self, x, x_mask, cd, premasked=False):
+        """premasked: x is already x * x_mask in the compute dtype and the caller masks the result (Encoder)"""
+        if not premasked:
+            x = (x * x_mask).to(cd).contiguous()
+        x = self.conv_1(x, out_act=L.ACT_LRELU, out_slope=0.0)
         x = self.drop(x)
         x = self.conv_2((x * x_mask).to(cd).contiguous())
-        return x * x_mask
+        return x if premasked else x * x_mask
 
 
 class Encoder(nn.Module):
@@ -157,14 +161,21 @@ class Encoder(nn.Module):
             self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size,
                                        p_dropout=p_dropout))
             self.norm_layers_2.append(LayerNorm(hidden_channels))
+        self._sites = [new_site() for _ in range(2 * n_layers)]     # dropout stream ids of the fused drop+add+norm launches
 
-    def forward(self, x, x_mask, cd):
-        """x [B, T, C], x_mask [B, T, 1]"""
+    def forward(self, x, x_mask, cd, lengths=None):
+        """x [B, T, C], x_mask [B, T, 1] (1 = live frame), lengths [B] (optional, = x_mask.sum(1)).
+        Returns x * x_mask in the compute dtype.  Per layer: attention, then ONE fused launch for
+        drop -> add -> LayerNorm -> mask (hip/enc.py), FFN, and the same fused launch again."""
         attn_mask = (x_mask.transpose(1, 2).unsqueeze(2) * x_mask.unsqueeze(1))   # [B, 1, T, T]
-        x = x * x_mask
+        lens = (lengths if lengths is not None else x_mask.sum(dim=(1, 2))).to(torch.int32)
+        mask_cd = x_mask.to(cd)
+        x = (x * x_mask).to(cd).contiguous()
+        p = self.drop.p if self.training else 0.0
         for i in range(self.n_layers):
-            y = self.drop(self.attn_layers[i](x, x, attn_mask))
-            x = self.norm_layers_1[i](x + y)
-            y = self.drop(self.ffn_layers[i](x, x_mask, cd))
-            x = self.norm_layers_2[i](x + y)
-        return x * x_mask
+            n1, n2 = self.norm_layers_1[i], self.norm_layers_2[i]
+            y = self.attn_layers[i](x, x, attn_mask).to(cd)
+            x = res_drop_ln(x, y, n1.gamma, n1.beta, lens, p, self._sites[2 * i], n1.eps)
+            y = self.ffn_layers[i](x, mask_cd, cd, premasked=True)
+            x = res_drop_ln(x, y, n2.gamma, n2.beta, lens, p, self._sites[2 * i + 1], n2.eps)
+        return x

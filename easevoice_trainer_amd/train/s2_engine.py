@@ -17,6 +17,7 @@ import torch
 from torch.nn import functional as F
 
 from ..hip import lib as L
+from ..hip.enc import bump_rng
 from ..module import commons
 from ..module.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
 from ..module.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
@@ -83,6 +84,7 @@ class S2Engine:
         d, t = self.hps["data"], self.hps["train"]
         hop, seg = d["hop_length"], t["segment_size"]
         net_g, net_d, rt_g, rt_d = self.net_g, self.net_d, self.rt_g, self.rt_d
+        bump_rng(self.device)     # new dropout masks for this step (device counter: replays advance it too)
         rt_g.zero_grad()
         rt_d.zero_grad()
         rt_g.prepare()

@@ -219,6 +219,27 @@ int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const flo
                           const float* mean, const float* rstd, void* dxr, float* dgamma, float* dbeta,
                           int64_t rows, int32_t C, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * s2 transformer encoder glue (enc_p), src/easevoice/module/attentions.py:60-75.
+ * ------------------------------------------------------------------------------------- */
+/* *counter += inc, a 1-thread launch.  Device-side step / RNG counters: nothing about them is a host argument, so the
+ * launches that read them can be replayed from a captured HIP graph. */
+int evt_counter_inc(uint32_t* counter, uint32_t inc, void* stream);
+
+/* out = LayerNorm(x + dropout(y)) * gamma + beta, rows (b, t) with t >= lens[b] written as zeros (lens may be NULL).
+ * x, y, out [rows][C] in `dtype`; gamma/beta fp32 [C]; mean/rstd fp32 [rows] saved for the backward.
+ * dropout keep(element) = hash(*seed_dev, site, element index) >= p * 2^32, kept values scaled by 1/(1-p); the backward
+ * regenerates the mask from the same (seed, site).  rows_per_seq = T (row = b*T + t). */
+int evt_res_dropout_ln_fwd(int32_t dtype, const void* x, const void* y, const float* gamma, const float* beta,
+                           const int32_t* lens, int32_t rows_per_seq, float p, const uint32_t* seed_dev, uint32_t site,
+                           void* out, float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream);
+/* dx = d(loss)/dx, dy = d(loss)/dy (= dx * dropout multiplier; may be NULL when p == 0: then dy == dx);
+ * dgamma/dbeta fp32 [C] are accumulated (+=). */
+int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const float* gamma, const void* dout,
+                           const float* mean, const float* rstd, const int32_t* lens, int32_t rows_per_seq, float p,
+                           const uint32_t* seed_dev, uint32_t site, void* dx, void* dy, float* dgamma, float* dbeta,
+                           int64_t rows, int32_t C, void* stream);
+
 /* Cross-entropy, reduction="sum" (t2s_model.py:486-489): logits [rows][V] (any dtype), targets int64.
  * loss[0] += sum_r (lse_r - logit[r][t_r]); dlogits = (softmax - onehot) * dloss[0]; top-k hit counts for
  * the accuracy metric are written to hits[0] (+=, rows with target == ignore_index skipped, count in hits[1]). */

@@ -27,7 +27,17 @@ def _conv_forward(self, x, res=None, in_slope=1.0, out_act=0, out_slope=1.0):
 @contextlib.contextmanager
 def cpu_emulation():
     from easevoice_trainer_amd.hip import conv as HC
-    from easevoice_trainer_amd.module import losses as PL, mel_processing as PM, models as PMod
+    from easevoice_trainer_amd.module import attentions as PA, losses as PL, mel_processing as PM, models as PMod
+    from easevoice_trainer_amd.train import s2_engine as PE
+
+    saved_enc = (PA.res_drop_ln, PE.bump_rng)
+
+    def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
+        assert p == 0.0, "the CPU wiring emulation has no dropout stream"
+        live = (torch.arange(x.size(1))[None, :] < lens[:, None]).unsqueeze(-1).to(x.dtype)
+        return F.layer_norm(x + y, (x.size(-1),), gamma, beta, eps) * live
+
+    PA.res_drop_ln, PE.bump_rng = res_drop_ln, (lambda device: None)
 
     saved = (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
              PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch)
@@ -95,6 +105,7 @@ def cpu_emulation():
     finally:
         (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
          PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch) = saved
+        PA.res_drop_ln, PE.bump_rng = saved_enc
 
 
 @contextlib.contextmanager

@@ -1,0 +1,81 @@
+"""GPU parity of the fused encoder glue (csrc/enc_ops.hip) against plain torch fp32:
+out = LayerNorm(x + dropout(y)) * row_mask, its gradients, and the counter-keyed dropout stream."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, y, gamma, beta, lens, eps=1e-5):
+    live = (torch.arange(x.size(1), device=x.device)[None, :] < lens[:, None]).unsqueeze(-1).to(x.dtype)
+    return F.layer_norm(x + y, (x.size(-1),), gamma, beta, eps) * live
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 37, 192), (2, 5, 512), (2, 9, 768)])
+def test_res_ln_no_dropout(gpu, dtype, tol, shape):
+    from easevoice_trainer_amd.hip.enc import res_drop_ln
+
+    B, T, C = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, C, generator=g).to(gpu, dtype)
+    y = torch.randn(B, T, C, generator=g).to(gpu, dtype)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(gpu)
+    beta = torch.randn(C, generator=g).to(gpu)
+    lens = torch.tensor([T, max(1, T // 2), 1][:B], device=gpu, dtype=torch.int32)
+    w = torch.randn(B, T, C, generator=g).to(gpu)
+    xs = [t.detach().float().requires_grad_(True) for t in (x, y, gamma, beta)]
+    (_ref(xs[0], xs[1], xs[2], xs[3], lens) * w).sum().backward()
+    xg, yg = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out = res_drop_ln(xg, yg, gg, bg, lens, 0.0, 1)
+    (out.float() * w).sum().backward()
+    ref = _ref(xs[0], xs[1], xs[2], xs[3], lens)
+
+    def close(a, b, name):
+        err = (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-6)
+        assert err < tol, f"{name}: {err}"
+
+    close(out, ref, "out")
+    close(xg.grad, xs[0].grad, "dx")
+    close(yg.grad, xs[1].grad, "dy")
+    close(gg.grad, xs[2].grad, "dgamma")
+    close(bg.grad, xs[3].grad, "dbeta")
+
+
+def test_res_ln_dropout_stream(gpu):
+    from easevoice_trainer_amd.hip import enc as E
+
+    B, T, C, p = 4, 50, 192, 0.25
+    lens = torch.full((B,), T, device=gpu, dtype=torch.int32)
+    gamma, beta = torch.ones(C, device=gpu), torch.zeros(C, device=gpu)
+    E.seed_rng(gpu, 123)
+    # x = 0, y = 1: x + drop(y) takes two values per row, LayerNorm keeps them apart -> the kept fraction is visible
+    x, y = torch.zeros(B, T, C, device=gpu), torch.ones(B, T, C, device=gpu)
+    o1 = E.res_drop_ln(x, y, gamma, beta, lens, p, 7)
+    o2 = E.res_drop_ln(x, y, gamma, beta, lens, p, 7)
+    assert torch.equal(o1, o2)                                    # same (seed, site): same mask
+    kept = (o1 > 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.02, kept
+    assert not torch.equal(o1, E.res_drop_ln(x, y, gamma, beta, lens, p, 8))    # another site: another stream
+    E.bump_rng(gpu)
+    assert not torch.equal(o1, E.res_drop_ln(x, y, gamma, beta, lens, p, 7))    # next step: another mask
+    # backward regenerates the same mask: directional derivative along a random direction in y (fp32)
+    g = torch.Generator().manual_seed(3)
+    xr = torch.randn(B, T, C, generator=g).to(gpu)
+    yr = torch.randn(B, T, C, generator=g).to(gpu).requires_grad_(True)
+    w = torch.randn(B, T, C, generator=g).to(gpu)
+    v = torch.randn(B, T, C, generator=g).to(gpu)
+    gam = (torch.rand(C, generator=g) + 0.5).to(gpu)
+    out = E.res_drop_ln(xr, yr, gam, beta, lens, p, 9)
+    (out * w).sum().backward()
+    h = 1e-2
+    with torch.no_grad():
+        fp = (E.res_drop_ln(xr, yr + h * v, gam, beta, lens, p, 9) * w).sum()
+        fm = (E.res_drop_ln(xr, yr - h * v, gam, beta, lens, p, 9) * w).sum()
+    num = ((fp - fm) / (2 * h)).item()
+    ana = (yr.grad * v).sum().item()
+    assert abs(num - ana) < 2e-2 * max(1.0, abs(ana)), (num, ana)
+    # dropped elements get no gradient, kept ones are scaled by 1/(1-p): dy == dx * mult with mult in {0, 1/(1-p)}
+    assert ((yr.grad == 0).float().mean().item() - p) < 0.03
