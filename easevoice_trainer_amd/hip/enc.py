@@ -80,3 +80,52 @@ class ResDropLNFn(torch.autograd.Function):
 
 def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
     return ResDropLNFn.apply(x, y, gamma, beta, lens, float(p), int(site), float(eps))
+
+
+class RelAttnFn(torch.autograd.Function):
+    """Fused windowed relative-position self-attention core (csrc/relattn.hip) on a packed projection
+    qkv [B, T, 3*H*D] (bf16): one launch forward, two backward; returns [B, T, H*D]."""
+
+    @staticmethod
+    def forward(ctx, qkv, emb_k, emb_v, lens, n_heads, window, p, site):
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or C3 % 3 or Cc % n_heads:
+            raise L.EvtError(f"relattn: packed bf16 contiguous [B, T, 3*H*D] expected, got {tuple(qkv.shape)} {qkv.dtype}")
+        D = Cc // n_heads
+        ek, ev = emb_k.contiguous(), emb_v.contiguous()
+        out = torch.empty((B, T, Cc), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B * n_heads, T), dtype=torch.float32, device=qkv.device)
+        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), C3, Cc, p, site, rng_counter(qkv.device).data_ptr())
+        base, esz = qkv.data_ptr(), qkv.element_size()
+        L.check(L.lib().evt_relattn_fwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
+                                        C.c_void_p(base + 2 * Cc * esz), L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(out),
+                                        L.ptr(lse), L.stream_ptr()), "evt_relattn_fwd")
+        ctx.save_for_backward(qkv, out, lse, ek, ev, lens)
+        ctx.cfg = (n_heads, window, p, site)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, out, lse, ek, ev, lens = ctx.saved_tensors
+        n_heads, window, p, site = ctx.cfg
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        d_o = d_o.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dek = torch.zeros_like(ek, dtype=torch.float32)
+        dev = torch.zeros_like(ev, dtype=torch.float32)
+        delta = torch.empty_like(lse)
+        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), C3, Cc, p, site,
+                              rng_counter(qkv.device).data_ptr())
+        base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
+        L.check(L.lib().evt_relattn_bwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
+                                        C.c_void_p(base + 2 * Cc * esz), L.ptr(out), L.ptr(d_o), L.ptr(lse), L.ptr(ek),
+                                        L.ptr(ev), L.ptr(lens), C.c_void_p(dbase), C.c_void_p(dbase + Cc * esz),
+                                        C.c_void_p(dbase + 2 * Cc * esz), L.ptr(dek), L.ptr(dev), L.ptr(delta),
+                                        L.stream_ptr()), "evt_relattn_bwd")
+        return dqkv, dek, dev, None, None, None, None, None
+
+
+def rel_attention(qkv, emb_k, emb_v, lens, n_heads, window, p, site):
+    return RelAttnFn.apply(qkv, emb_k, emb_v, lens, int(n_heads), int(window), float(p), int(site))

@@ -75,6 +75,12 @@ class ScaledAdamHP(C.Structure):
                 ("scalar_lr_scale", C.c_float), ("scalar_max", C.c_float), ("step", C.c_int32), ("pad_", C.c_int32)]
 
 
+class RelAttnParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("window", C.c_int32),
+                ("n_heads_rel", C.c_int32), ("ld", C.c_int64), ("ldo", C.c_int64), ("dropout_p", C.c_float),
+                ("site", C.c_uint32), ("seed_dev", C.c_void_p)]
+
+
 _lib = None
 
 

@@ -15,7 +15,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import EvtConv1d
-from ..hip.enc import new_site, res_drop_ln
+from ..hip.enc import new_site, rel_attention, res_drop_ln
 
 
 class LayerNorm(nn.Module):
@@ -64,6 +64,7 @@ class MultiHeadAttention(nn.Module):
         nn.init.xavier_uniform_(self.conv_q.weight)
         nn.init.xavier_uniform_(self.conv_k.weight)
         nn.init.xavier_uniform_(self.conv_v.weight)
+        self._site = new_site()      # dropout stream id of the fused attention launch
 
     @staticmethod
     def _rel_to_abs(x):
@@ -97,8 +98,23 @@ class MultiHeadAttention(nn.Module):
             return full[..., extra: extra + 2 * w + 1]
         return F.pad(full, (-extra, -extra))
 
-    def forward(self, x, c, attn_mask=None):
-        """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend)"""
+    def fused_ok(self, x, c):
+        """self-attention with relative window in bf16 on the GPU -> csrc/relattn.hip"""
+        return (x is c and self.window_size is not None and x.is_cuda and x.dtype == torch.bfloat16
+                and self.k_channels % 32 == 0 and self.k_channels <= 128 and 2 * self.window_size + 1 <= 16)
+
+    def forward(self, x, c, attn_mask=None, lens=None):
+        """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend).
+        With `lens` [B] int32 (live frames, the mask being lens x lens) and bf16 self-attention, the whole core --
+        scores, relative logits, mask, softmax, dropout, values, relative values -- is one fused launch on a packed
+        q|k|v projection (one GEMM instead of three)."""
+        if lens is not None and self.fused_ok(x, c):
+            w = torch.cat([self.conv_q.weight, self.conv_k.weight, self.conv_v.weight], dim=0).squeeze(-1)
+            bias = torch.cat([self.conv_q.bias, self.conv_k.bias, self.conv_v.bias], dim=0)
+            qkv = F.linear(x, w, bias).to(torch.bfloat16).contiguous()
+            p = self.drop.p if self.training else 0.0
+            out = rel_attention(qkv, self.emb_rel_k, self.emb_rel_v, lens, self.n_heads, self.window_size, p, self._site)
+            return self.conv_o(out)
         b, t_t, _ = x.shape
         t_s = c.size(1)
         h, d = self.n_heads, self.k_channels
@@ -167,14 +183,15 @@ class Encoder(nn.Module):
         """x [B, T, C], x_mask [B, T, 1] (1 = live frame), lengths [B] (optional, = x_mask.sum(1)).
         Returns x * x_mask in the compute dtype.  Per layer: attention, then ONE fused launch for
         drop -> add -> LayerNorm -> mask (hip/enc.py), FFN, and the same fused launch again."""
-        attn_mask = (x_mask.transpose(1, 2).unsqueeze(2) * x_mask.unsqueeze(1))   # [B, 1, T, T]
         lens = (lengths if lengths is not None else x_mask.sum(dim=(1, 2))).to(torch.int32)
         mask_cd = x_mask.to(cd)
         x = (x * x_mask).to(cd).contiguous()
+        fused = self.n_layers > 0 and self.attn_layers[0].fused_ok(x, x)
+        attn_mask = None if fused else (x_mask.transpose(1, 2).unsqueeze(2) * x_mask.unsqueeze(1))   # [B, 1, T, T]
         p = self.drop.p if self.training else 0.0
         for i in range(self.n_layers):
             n1, n2 = self.norm_layers_1[i], self.norm_layers_2[i]
-            y = self.attn_layers[i](x, x, attn_mask).to(cd)
+            y = self.attn_layers[i](x, x, attn_mask, lens=lens).to(cd).contiguous()
             x = res_drop_ln(x, y, n1.gamma, n1.beta, lens, p, self._sites[2 * i], n1.eps)
             y = self.ffn_layers[i](x, mask_cd, cd, premasked=True)
             x = res_drop_ln(x, y, n2.gamma, n2.beta, lens, p, self._sites[2 * i + 1], n2.eps)

@@ -240,6 +240,28 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
                            const uint32_t* seed_dev, uint32_t site, void* dx, void* dy, float* dgamma, float* dbeta,
                            int64_t rows, int32_t C, void* stream);
 
+/* Windowed relative-position multi-head SELF-attention core (attentions.py:214-292, window_size = w), bf16:
+ *   scores[i][j] = (q_i . k_j + [|j-i| <= w] q_i . Ek[j-i+w]) / sqrt(D);  keys j >= lens[b] excluded
+ *   p = dropout(softmax_j(scores));   out_i = sum_j p[i][j] (v_j + [|j-i| <= w] Ev[j-i+w])
+ * q, k, v: bf16 rows [B][T][ld] with head h in columns [h*D, (h+1)*D) (three slices of one packed projection are fine);
+ * out [B][T][ldo] likewise; emb_k / emb_v fp32 [n_heads_rel][2w+1][D]; lse fp32 [B*H][T] is saved for the backward.
+ * Query rows i >= lens[b] are written as zeros.  Dropout mask = hash(*seed_dev, site, b, h, i, j). */
+typedef struct evt_relattn_params {
+  int32_t B, T, H, D;      /* D % 32 == 0, D <= 128 */
+  int32_t window;          /* w, 2w+1 <= 16 */
+  int32_t n_heads_rel;     /* 1 (heads share the embeddings) or H */
+  int64_t ld, ldo;         /* row strides in elements, multiples of 8 */
+  float dropout_p;
+  uint32_t site;
+  const uint32_t* seed_dev;
+} evt_relattn_params;
+int evt_relattn_fwd(const evt_relattn_params* p, const void* q, const void* k, const void* v, const float* emb_k,
+                    const float* emb_v, const int32_t* lens, void* out, float* lse, void* stream);
+/* dq, dk, dv: bf16 rows with stride ld; demb_k / demb_v fp32, accumulated (+=); delta_ws fp32 [B*H][T] scratch. */
+int evt_relattn_bwd(const evt_relattn_params* p, const void* q, const void* k, const void* v, const void* o,
+                    const void* d_o, const float* lse, const float* emb_k, const float* emb_v, const int32_t* lens,
+                    void* dq, void* dk, void* dv, float* demb_k, float* demb_v, float* delta_ws, void* stream);
+
 /* Cross-entropy, reduction="sum" (t2s_model.py:486-489): logits [rows][V] (any dtype), targets int64.
  * loss[0] += sum_r (lse_r - logit[r][t_r]); dlogits = (softmax - onehot) * dloss[0]; top-k hit counts for
  * the accuracy metric are written to hits[0] (+=, rows with target == ignore_index skipped, count in hits[1]). */
