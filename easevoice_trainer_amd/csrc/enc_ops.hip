@@ -212,6 +212,78 @@ __global__ __launch_bounds__(256) void res_drop_ln_bwd(const T* x, const T* y, c
   }
 }
 
+
+// ---- WN layer glue (modules.py:199-211 of the reference): res_skip output rs [rows][2H] ->
+//        x_new = (x + rs[:, :H]) * row_mask          acc_new = acc + rs[:, H:]
+//      last layer (rs has H channels):               acc_new = (acc + rs) * row_mask
+//      one launch instead of slice / add / mul / add (and their ~8 backward launches) ----
+template <typename T>
+__global__ void wn_residual_fwd(const T* x, const T* rs, const T* acc, const int* lens, int rows_per_seq, T* x_out,
+                                T* acc_out, long rows, int H, int last) {
+  constexpr int V = 16 / sizeof(T);
+  const int ppr = H / V;
+  const long total = rows * ppr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / ppr;
+    const int c0 = (int)(i - row * ppr) * V;
+    bool live = true;
+    if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+    const int ldr = last ? H : 2 * H;
+    const uint4 r0 = *reinterpret_cast<const uint4*>(rs + row * ldr + c0);
+    uint4 av = make_uint4(0, 0, 0, 0);
+    if (acc) av = *reinterpret_cast<const uint4*>(acc + row * H + c0);
+    const T* pr0 = reinterpret_cast<const T*>(&r0);
+    const T* pa = reinterpret_cast<const T*>(&av);
+    uint4 o1, o2;
+    T* p1 = reinterpret_cast<T*>(&o1);
+    T* p2 = reinterpret_cast<T*>(&o2);
+    if (last) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) p2[e] = live ? from_f<T>(to_f<T>(pa[e]) + to_f<T>(pr0[e])) : from_f<T>(0.f);
+      *reinterpret_cast<uint4*>(acc_out + row * H + c0) = o2;
+    } else {
+      const uint4 xv = *reinterpret_cast<const uint4*>(x + row * H + c0);
+      const uint4 r1 = *reinterpret_cast<const uint4*>(rs + row * ldr + H + c0);
+      const T* px = reinterpret_cast<const T*>(&xv);
+      const T* pr1 = reinterpret_cast<const T*>(&r1);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        p1[e] = live ? from_f<T>(to_f<T>(px[e]) + to_f<T>(pr0[e])) : from_f<T>(0.f);
+        p2[e] = from_f<T>(to_f<T>(pa[e]) + to_f<T>(pr1[e]));
+      }
+      *reinterpret_cast<uint4*>(x_out + row * H + c0) = o1;
+      *reinterpret_cast<uint4*>(acc_out + row * H + c0) = o2;
+    }
+  }
+}
+
+// drs[:, :H] = dx_out * mask (also written to dx), drs[:, H:] = dacc_out;   last: drs = dacc_out * mask
+template <typename T>
+__global__ void wn_residual_bwd(const T* dx_out, const T* dacc_out, const int* lens, int rows_per_seq, T* dx, T* drs,
+                                long rows, int H, int last) {
+  constexpr int V = 16 / sizeof(T);
+  const int ppr = H / V;
+  const long total = rows * ppr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / ppr;
+    const int c0 = (int)(i - row * ppr) * V;
+    bool live = true;
+    if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 da = z;
+    if (dacc_out) da = *reinterpret_cast<const uint4*>(dacc_out + row * H + c0);
+    if (last) {
+      *reinterpret_cast<uint4*>(drs + row * H + c0) = live ? da : z;
+    } else {
+      uint4 dxv = z;
+      if (dx_out && live) dxv = *reinterpret_cast<const uint4*>(dx_out + row * H + c0);
+      *reinterpret_cast<uint4*>(dx + row * H + c0) = dxv;
+      *reinterpret_cast<uint4*>(drs + row * 2 * H + c0) = dxv;
+      *reinterpret_cast<uint4*>(drs + row * 2 * H + H + c0) = da;
+    }
+  }
+}
+
 __global__ void counter_add_kernel(unsigned* c, unsigned inc) { *c += inc; }
 
 }  // namespace
@@ -262,6 +334,47 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
   else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_BWD(float, 2); else RDL_BWD(float, 4); }
   else return EVT_EINVAL;
 #undef RDL_BWD
+  return evt_check_launch();
+}
+
+int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void* acc, const int32_t* lens,
+                        int32_t rows_per_seq, void* x_out, void* acc_out, int64_t rows, int32_t H, int32_t last,
+                        void* stream) {
+  if (!rs || !acc_out || rows <= 0 || H <= 0 || (!last && (!x || !x_out))) return EVT_EINVAL;
+  if (lens && rows_per_seq <= 0) return EVT_EINVAL;
+  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (H % V) return EVT_ENOTSUP;
+  const long total = rows * (H / V);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(wn_residual_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)rs,
+                       (const bf16_t*)acc, lens, rows_per_seq, (bf16_t*)x_out, (bf16_t*)acc_out, (long)rows, H, last);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(wn_residual_fwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (const float*)rs,
+                       (const float*)acc, lens, rows_per_seq, (float*)x_out, (float*)acc_out, (long)rows, H, last);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out, const int32_t* lens,
+                        int32_t rows_per_seq, void* dx, void* drs, int64_t rows, int32_t H, int32_t last, void* stream) {
+  if (!drs || rows <= 0 || H <= 0 || (!last && !dx)) return EVT_EINVAL;
+  if (lens && rows_per_seq <= 0) return EVT_EINVAL;
+  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (H % V) return EVT_ENOTSUP;
+  const long total = rows * (H / V);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(wn_residual_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)dx_out,
+                       (const bf16_t*)dacc_out, lens, rows_per_seq, (bf16_t*)dx, (bf16_t*)drs, (long)rows, H, last);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(wn_residual_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)dx_out,
+                       (const float*)dacc_out, lens, rows_per_seq, (float*)dx, (float*)drs, (long)rows, H, last);
+  else return EVT_EINVAL;
   return evt_check_launch();
 }
 

@@ -129,3 +129,53 @@ class RelAttnFn(torch.autograd.Function):
 
 def rel_attention(qkv, emb_k, emb_v, lens, n_heads, window, p, site):
     return RelAttnFn.apply(qkv, emb_k, emb_v, lens, int(n_heads), int(window), float(p), int(site))
+
+
+class WNResidualFn(torch.autograd.Function):
+    """x_new = (x + rs[..., :H]) * mask, acc_new = acc + rs[..., H:]   (last layer: acc_new = (acc + rs) * mask)"""
+
+    @staticmethod
+    def forward(ctx, x, rs, acc, lens, last):
+        H = rs.size(-1) if last else rs.size(-1) // 2
+        rows = rs.numel() // rs.size(-1)
+        rps = rs.size(-2)
+        for t in (x, rs, acc):
+            if t is not None and not t.is_contiguous():
+                raise L.EvtError("wn_residual: contiguous tensors expected")
+        acc_out = torch.empty(rs.shape[:-1] + (H,), dtype=rs.dtype, device=rs.device)
+        x_out = None if last else torch.empty_like(acc_out)
+        L.check(L.lib().evt_wn_residual_fwd(L.dt_of(rs), L.ptr(x), L.ptr(rs), L.ptr(acc), L.ptr(lens), rps, L.ptr(x_out),
+                                            L.ptr(acc_out), C.c_int64(rows), H, int(last), L.stream_ptr()),
+                "evt_wn_residual_fwd")
+        ctx.save_for_backward(lens)
+        ctx.cfg = (H, rows, rps, last, rs.shape, rs.dtype, acc is not None)
+        if last:
+            return acc_out
+        return x_out, acc_out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (lens,) = ctx.saved_tensors
+        H, rows, rps, last, rs_shape, dtype, has_acc = ctx.cfg
+        if last:
+            dx_out, dacc = None, grads[0]
+        else:
+            dx_out, dacc = grads
+        dx_out = dx_out.contiguous() if dx_out is not None else None
+        dacc = dacc.contiguous() if dacc is not None else None
+        dev = (dacc if dacc is not None else dx_out).device
+        drs = torch.empty(rs_shape, dtype=dtype, device=dev)
+        dx = None if last else torch.empty(rs_shape[:-1] + (H,), dtype=dtype, device=dev)
+        L.check(L.lib().evt_wn_residual_bwd(L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32, L.ptr(dx_out), L.ptr(dacc),
+                                            L.ptr(lens), rps, L.ptr(dx), L.ptr(drs), C.c_int64(rows), H, int(last),
+                                            L.stream_ptr()), "evt_wn_residual_bwd")
+        # d(acc): the skip sum passes through unchanged, except for the last layer where the row mask applies to it too
+        return dx, drs, ((drs if last else dacc) if has_acc else None), None, None
+
+
+def wn_residual(x, rs, acc, lens):
+    return WNResidualFn.apply(x, rs, acc, lens, False)
+
+
+def wn_residual_last(rs, acc, lens):
+    return WNResidualFn.apply(None, rs, acc, lens, True)

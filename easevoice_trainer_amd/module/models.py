@@ -21,6 +21,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
+from ..hip.enc import wn_residual, wn_residual_last
 from . import commons
 from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv
 
@@ -76,24 +77,28 @@ class WN(nn.Module, _ComputeDtype):
             rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
             self.res_skip_layers.append(EvtConv1d(hidden_channels, rs, 1, weight_norm=True))
 
-    def forward(self, x, x_mask, g=None):
-        """x [B, T, H] (compute dtype), x_mask [B, T, 1], g [B, gin] or None"""
+    def forward(self, x, x_mask, g=None, lens=None):
+        """x [B, T, H] (compute dtype), x_mask [B, T, 1], g [B, gin] or None, lens [B] int32 (= x_mask.sum(1)).
+        Per layer: in_layer conv, gated activation, res_skip conv (HIP) and ONE fused launch for the residual / skip
+        bookkeeping  x <- (x + rs[:H]) * mask, out <- out + rs[H:]  (hip/enc.py)."""
         H = self.hidden_channels
-        output = None
+        if lens is None:
+            lens = x_mask.sum(dim=(1, 2)).to(torch.int32)
+        gs = None
         if g is not None:
             g = self.cond_layer(g).to(x.dtype)     # [B, 2*H*n_layers]
+            gs = g.view(g.size(0), self.n_layers, 2 * H).transpose(0, 1).contiguous().unbind(0)
+        output = None
+        x = x.contiguous()
         for i in range(self.n_layers):
             x_in = self.in_layers[i](x)
-            g_l = g[:, i * 2 * H:(i + 1) * 2 * H].contiguous() if g is not None else None
-            acts = self.drop(GatedActFn.apply(x_in, g_l))
+            acts = self.drop(GatedActFn.apply(x_in, gs[i] if gs is not None else None))
             rs = self.res_skip_layers[i](acts)
             if i < self.n_layers - 1:
-                x = ((x + rs[..., :H]) * x_mask).to(x.dtype).contiguous()
-                skip = rs[..., H:]
+                x, output = wn_residual(x, rs, output, lens)
             else:
-                skip = rs
-            output = skip if output is None else output + skip
-        return output * x_mask
+                output = wn_residual_last(rs, output, lens)
+        return output
 
 
 class PosteriorEncoder(nn.Module, _ComputeDtype):
@@ -107,12 +112,12 @@ class PosteriorEncoder(nn.Module, _ComputeDtype):
         self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
         self.proj = PointwiseConv(hidden_channels, out_channels * 2)
 
-    def forward(self, x, x_mask, g=None, eps=None):
+    def forward(self, x, x_mask, g=None, eps=None, lens=None):
         """x [B, T, spec] -> z, m, logs [B, T, out]; eps (the randn_like draw of models.py:358) may be injected"""
         if g is not None:
             g = g.detach()
         h = (self.pre(x) * x_mask).to(self.cd).contiguous()
-        h = self.enc(h, x_mask, g=g)
+        h = self.enc(h, x_mask, g=g, lens=lens)
         stats = self.proj(h) * x_mask
         m, logs = torch.split(stats.float(), self.out_channels, dim=-1)
         if eps is None:
@@ -136,10 +141,10 @@ class ResidualCouplingLayer(nn.Module, _ComputeDtype):
         self.post.weight.data.zero_()
         self.post.bias.data.zero_()
 
-    def forward(self, x, x_mask, g=None, reverse=False):
+    def forward(self, x, x_mask, g=None, reverse=False, lens=None):
         x0, x1 = torch.split(x, [self.half_channels] * 2, dim=-1)
         h = (self.pre(x0) * x_mask).to(self.cd).contiguous()
-        h = self.enc(h, x_mask, g=g)
+        h = self.enc(h, x_mask, g=g, lens=lens)
         stats = (self.post(h) * x_mask).float()
         if not self.mean_only:
             m, logs = torch.split(stats, [self.half_channels] * 2, dim=-1)
@@ -168,10 +173,10 @@ class ResidualCouplingBlock(nn.Module):
                                                     gin_channels=gin_channels, mean_only=True))
             self.flows.append(Flip())
 
-    def forward(self, x, x_mask, g=None, reverse=False):
+    def forward(self, x, x_mask, g=None, reverse=False, lens=None):
         flows = self.flows if not reverse else reversed(self.flows)
         for flow in flows:
-            x = flow(x, x_mask, g=g, reverse=reverse)
+            x = flow(x, x_mask, g=g, reverse=reverse, lens=lens)
         return x
 
 
@@ -214,14 +219,14 @@ class TextEncoder(nn.Module, _ComputeDtype):
         self.encoder2 = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
         self.proj = PointwiseConv(hidden_channels, out_channels * 2)
 
-    def forward(self, y, y_mask, text, text_mask, ge):
-        """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]"""
-        y = self.ssl_proj(y * y_mask) * y_mask
-        y = self.encoder_ssl(y * y_mask, y_mask, self.cd)
+    def forward(self, y, y_mask, text, text_mask, ge, y_lengths=None, text_lengths=None):
+        """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]; the encoders mask their own input / output"""
+        y = self.ssl_proj(y * y_mask)
+        y = self.encoder_ssl(y, y_mask, self.cd, lengths=y_lengths)
         t = self.text_embedding(text)
-        t = self.encoder_text(t * text_mask, text_mask, self.cd)
+        t = self.encoder_text(t, text_mask, self.cd, lengths=text_lengths)
         y = self.mrte(y, y_mask, t, text_mask, ge)
-        y = self.encoder2(y * y_mask, y_mask, self.cd)
+        y = self.encoder2(y, y_mask, self.cd, lengths=y_lengths)
         stats = (self.proj(y) * y_mask).float()
         m, logs = torch.split(stats, self.out_channels, dim=-1)
         return y, m, logs
@@ -597,11 +602,12 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             ref_in = y_cl if self.version == "v1" else y_cl[..., :704]
             ge = self.ref_enc(ref_in * y_mask, y_mask)                                         # [B, gin]
             quantized, _codes = self._quantize(ssl.transpose(1, 2))
-            x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge)
+            x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
             eps_cl = eps.transpose(1, 2) if eps is not None else None
             ym = y_mask.to(self.cd)      # 0/1 mask in the compute dtype: the WN stacks stay in one dtype (no cast kernels)
-            z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge, eps=eps_cl)
-            z_p = self.flow(z, ym, g=ge)
+            lens32 = y_lengths.to(torch.int32)
+            z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge, eps=eps_cl, lens=lens32)
+            z_p = self.flow(z, ym, g=ge, lens=lens32)
             if ids_slice is None:
                 z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
             else:

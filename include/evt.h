@@ -240,6 +240,17 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
                            const uint32_t* seed_dev, uint32_t site, void* dx, void* dy, float* dgamma, float* dbeta,
                            int64_t rows, int32_t C, void* stream);
 
+/* WN layer glue (src/easevoice/module/modules.py:199-211): rs = res_skip_layer(acts), [rows][2H] (H when last):
+ *   last == 0:  x_out = (x + rs[:, :H]) * row_mask ;  acc_out = acc + rs[:, H:]     (acc may be NULL = zeros)
+ *   last == 1:  acc_out = (acc + rs) * row_mask
+ * backward: drs[:, :H] = dx = dx_out * row_mask, drs[:, H:] = dacc_out (last: drs = dacc_out * row_mask); d(acc) is
+ * dacc_out itself and d(x) is dx.  dx_out / dacc_out may be NULL (= zeros). */
+int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void* acc, const int32_t* lens,
+                        int32_t rows_per_seq, void* x_out, void* acc_out, int64_t rows, int32_t H, int32_t last,
+                        void* stream);
+int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out, const int32_t* lens,
+                        int32_t rows_per_seq, void* dx, void* drs, int64_t rows, int32_t H, int32_t last, void* stream);
+
 /* Windowed relative-position multi-head SELF-attention core (attentions.py:214-292, window_size = w), bf16:
  *   scores[i][j] = (q_i . k_j + [|j-i| <= w] q_i . Ek[j-i+w]) / sqrt(D);  keys j >= lens[b] excluded
  *   p = dropout(softmax_j(scores));   out_i = sum_j p[i][j] (v_j + [|j-i| <= w] Ev[j-i+w])

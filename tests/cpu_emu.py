@@ -37,6 +37,19 @@ def cpu_emulation():
         live = (torch.arange(x.size(1))[None, :] < lens[:, None]).unsqueeze(-1).to(x.dtype)
         return F.layer_norm(x + y, (x.size(-1),), gamma, beta, eps) * live
 
+    def _live(t, lens):
+        return (torch.arange(t.size(1))[None, :] < lens[:, None]).unsqueeze(-1).to(t.dtype)
+
+    def wn_residual(x, rs, acc, lens):
+        H = rs.size(-1) // 2
+        skip = rs[..., H:]
+        return (x + rs[..., :H]) * _live(x, lens), (skip if acc is None else acc + skip)
+
+    def wn_residual_last(rs, acc, lens):
+        return (rs if acc is None else acc + rs) * _live(rs, lens)
+
+    saved_wn = (PMod.wn_residual, PMod.wn_residual_last)
+    PMod.wn_residual, PMod.wn_residual_last = wn_residual, wn_residual_last
     PA.res_drop_ln, PE.bump_rng = res_drop_ln, (lambda device: None)
 
     saved = (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
@@ -106,6 +119,7 @@ def cpu_emulation():
         (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
          PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch) = saved
         PA.res_drop_ln, PE.bump_rng = saved_enc
+        PMod.wn_residual, PMod.wn_residual_last = saved_wn
 
 
 @contextlib.contextmanager

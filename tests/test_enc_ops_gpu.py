@@ -79,3 +79,32 @@ def test_res_ln_dropout_stream(gpu):
     assert abs(num - ana) < 2e-2 * max(1.0, abs(ana)), (num, ana)
     # dropped elements get no gradient, kept ones are scaled by 1/(1-p): dy == dx * mult with mult in {0, 1/(1-p)}
     assert ((yr.grad == 0).float().mean().item() - p) < 0.03
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_wn_residual(gpu, dtype):
+    from easevoice_trainer_amd.hip.enc import wn_residual, wn_residual_last
+
+    B, T, H = 3, 41, 192
+    g = torch.Generator().manual_seed(2)
+    lens = torch.tensor([T, 20, 1], device=gpu, dtype=torch.int32)
+    live = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).unsqueeze(-1).float()
+    mk = lambda *s: torch.randn(*s, generator=g).to(gpu, dtype)
+    x, rs, acc, rs_l = mk(B, T, H), mk(B, T, 2 * H), mk(B, T, H), mk(B, T, H)
+    w1, w2, w3 = mk(B, T, H).float(), mk(B, T, H).float(), mk(B, T, H).float()
+    ins = [t.clone().requires_grad_(True) for t in (x, rs, acc, rs_l)]
+    xo, ao = wn_residual(ins[0], ins[1], ins[2], lens)
+    lo = wn_residual_last(ins[3], ao, lens)
+    ((xo.float() * w1).sum() + (lo.float() * w3).sum()).backward()
+    ref = [t.detach().float().requires_grad_(True) for t in (x, rs, acc, rs_l)]
+    xr = (ref[0] + ref[1][..., :H]) * live
+    ar = ref[2] + ref[1][..., H:]
+    lr = (ar + ref[3]) * live
+    ((xr * w1).sum() + (lr * w3).sum()).backward()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    for a, b, name in [(xo, xr, "x"), (lo, lr, "last")] + [(i.grad, r.grad, f"grad{k}") for k, (i, r) in enumerate(zip(ins, ref))]:
+        err = (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-6)
+        assert err < tol, (name, err)
+    # first layer: no accumulator yet
+    xo2, ao2 = wn_residual(x, rs, None, lens)
+    assert torch.equal(ao2, rs[..., H:].contiguous())
