@@ -68,8 +68,8 @@ class ResDropLNFn(torch.autograd.Function):
         dout = dout.contiguous()
         dx = torch.empty_like(x)
         dy = torch.empty_like(x) if p > 0.0 else None
-        dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)
-        dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        dgb = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)     # one fill for both accumulators
+        dgamma, dbeta = dgb[0], dgb[1]
         seed = rng_counter(x.device)
         L.check(L.lib().evt_res_dropout_ln_bwd(L.dt_of(x), L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(dout), L.ptr(mean),
                                                L.ptr(rstd), L.ptr(lens), rps, C.c_float(p), L.ptr(seed),
@@ -113,8 +113,8 @@ class RelAttnFn(torch.autograd.Function):
         Cc = C3 // 3
         d_o = d_o.contiguous()
         dqkv = torch.empty_like(qkv)
-        dek = torch.zeros_like(ek, dtype=torch.float32)
-        dev = torch.zeros_like(ev, dtype=torch.float32)
+        demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=qkv.device)   # one fill for both
+        dek, dev = demb[0], demb[1]
         delta = torch.empty_like(lse)
         prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), C3, Cc, p, site,
                               rng_counter(qkv.device).data_ptr())
@@ -179,3 +179,21 @@ def wn_residual(x, rs, acc, lens):
 
 def wn_residual_last(rs, acc, lens):
     return WNResidualFn.apply(None, rs, acc, lens, True)
+
+
+class UnbindRowsFn(torch.autograd.Function):
+    """t [L, ...] -> L views; the backward stacks the L gradients with ONE concatenation (torch's unbind backward
+    zero-fills and copies per slice)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.n = t.size(0)
+        return tuple(t.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.stack([g.contiguous() for g in grads], dim=0)
+
+
+def unbind_rows(t):
+    return UnbindRowsFn.apply(t)

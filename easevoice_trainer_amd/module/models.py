@@ -21,7 +21,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
-from ..hip.enc import wn_residual, wn_residual_last
+from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
 from . import commons
 from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv
 
@@ -87,7 +87,7 @@ class WN(nn.Module, _ComputeDtype):
         gs = None
         if g is not None:
             g = self.cond_layer(g).to(x.dtype)     # [B, 2*H*n_layers]
-            gs = g.view(g.size(0), self.n_layers, 2 * H).transpose(0, 1).contiguous().unbind(0)
+            gs = unbind_rows(g.view(g.size(0), self.n_layers, 2 * H).transpose(0, 1).contiguous())
         output = None
         x = x.contiguous()
         for i in range(self.n_layers):

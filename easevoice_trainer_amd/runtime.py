@@ -161,16 +161,35 @@ class ModelRuntime:
             if hasattr(m, "cd"):
                 m.cd = dtype
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # Parameters whose gradient comes from autograd (linears, norms, embeddings -- everything that is not a fused
+        # conv): autograd's AccumulateGrad would run one `grad += new` launch per parameter per backward (~420 tiny
+        # launches in the s2 generator).  Instead their .grad is detached from the arena during the backward (autograd
+        # then just keeps the produced tensor) and finish_grads() gathers all of them with one multi-tensor copy.
+        conv_owned = set()
+        for m in model.modules():
+            if hasattr(m, "_slot"):
+                conv_owned.update(id(p) for p in m.parameters(recurse=False))
+        self._free = [(p, p.grad) for p in model.parameters() if id(p) not in conv_owned]
 
     def zero_grad(self):
         self.arena.zero_grad()
         self.bank.zero_dw()
+        for p, _view in self._free:
+            p.grad = None
 
     def prepare(self):
         self.bank.fold()
 
     def finish_grads(self):
         self.bank.grads()
+        dst, src = [], []
+        for p, view in self._free:
+            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                dst.append(view)
+                src.append(p.grad if p.grad.dtype == view.dtype else p.grad.to(view.dtype))
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def grad_sumsq(self):
         """sum of squares of all gradients, as a device scalar (no host sync)"""
