@@ -15,6 +15,7 @@
 // zero page.  Two LDS stages (64 KiB): the DMA of stage s+1 is issued right after the barrier that publishes stage s
 // and flies under its 32 MFMAs per wave; one barrier per stage.
 #include "conv_p.h"
+#include <cstdlib>
 
 namespace evt_conv {
 namespace {
@@ -149,6 +150,153 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
         if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
         else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
         if (G) v *= (bf2f(G[off + r]) > 0.f ? 1.f : p.gate_slope);
+        if (R) v += bf2f(R[off + r]);
+        outv[r] = f2bf(v);
+      }
+      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// conv_ring<MT, NT, NS>: the same LDS-DMA implicit GEMM with a smaller block tile (32*MT x 32*NT, 2 x 2 waves of
+// 16*MT x 16*NT) and an NS-deep ring of K stages for the LATENCY-bound layers: WN in/res_skip convs and the FFN convs of
+// the encoders are 3200-position problems with 6..24 K stages -- with one stage in flight every stage costs a full
+// HBM/L2 round trip (~2 us) for ~0.1 us of MFMA work.  Here NS-1 stages are in flight: the DMA of stage s+NS-1 is issued
+// when stage s is published, waits are counted (s_waitcnt vmcnt(N), never a drain in steady state) and the block meets
+// at ONE raw s_barrier per stage:
+//     wait for MY pieces of stage s  ->  s_barrier (everyone's pieces landed; stage s-1 is free)  ->  issue stage s+NS-1
+//     into the freed buffer  ->  fragment reads + MFMAs of stage s
+// -----------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MT, int NT, int NS>
+__global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
+  constexpr int RM = 32 * MT, RN = 32 * NT;               // block tile
+  constexpr int RSTAGE = (RM + RN) * 128;                  // bytes per stage
+  constexpr int G = MT + NT;                               // DMA instructions per wave per stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int yi = slot % p.Y;
+  const int pb = xcd + 8 * (slot / p.Y);
+  if (pb >= p.P) return;
+  const int phase = blockIdx.y;
+
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const int total_units = p.nseq * p.Q;
+
+  // wave w stages rows [w*RM/4, (w+1)*RM/4) of A and [w*RN/4, ...) of B, 8 rows per instruction
+  const int rsub = lane >> 3, pslot = lane & 7;
+  long aoff[MT], boff[NT];
+  int brow[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wave * (RM / 4) + i * 8 + rsub;
+    const int c = pslot ^ (row & 7);
+    aoff[i] = ((long)(yi * RM + row) * p.nchunk + (c >> 2)) * p.KHp * 32 + (c & 3) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int row = wave * (RN / 4) + i * 8 + rsub;
+    const int c = pslot ^ (row & 7);
+    const int u = pb * RN + row;
+    const bool ok = u < total_units;
+    const int seq = ok ? u / p.Q : 0;
+    const int q = ok ? u - seq * p.Q : 0;
+    brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
+    boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
+  }
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  unsigned char* my_a = smem + wave * (RM / 4) * 128;
+  unsigned char* my_b = smem + RM * 128 + wave * (RN / 4) * 128;
+  const int nst = (p.nchunk >> 1) * p.KHp;
+
+  auto issue = [&](int st) {
+    const int buf = st % NS;
+    const int ch2 = st / p.KHp, tap = st - ch2 * p.KHp;
+    const long wsoff = ((long)(2 * ch2) * p.KHp + tap) * 32;
+    const int rshift = tap * p.dil;
+    const long xsoff = (long)rshift * p.Cin + ch2 * 64;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) glds16(W + aoff[i] + wsoff, my_a + buf * RSTAGE + i * 1024);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bool ok = (unsigned)(brow[i] + rshift) < (unsigned)p.Lin;
+      glds16(ok ? X + boff[i] + xsoff : zsrc, my_b + buf * RSTAGE + i * 1024);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int sw = n & 7;
+  const int a_base = (wr * 16 * MT + n) * 128;
+  const int b_base = RM * 128 + (wc * 16 * NT + n) * 128;
+  const int so0 = ((0 + g) ^ sw) * 16, so1 = ((4 + g) ^ sw) * 16;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nst) issue(s);
+  for (int st = 0; st < nst; ++st) {
+    // groups still allowed in flight after stage st has landed: stages st+1 .. st+NS-2 that exist
+    const int ahead = min(NS - 2, nst - 1 - st);
+    if (ahead >= 2) wait_vmcnt<2 * G>();
+    else if (ahead == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + NS - 1 < nst) issue(st + NS - 1);
+    const unsigned char* sa = smem + (st % NS) * RSTAGE + a_base;
+    const unsigned char* sb = smem + (st % NS) * RSTAGE + b_base;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ks ? so1 : so0;
+      bf16x8 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + so);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + so);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+
+  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
+  const bf16_t* Gt = reinterpret_cast<const bf16_t*>(p.gate);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int u = pb * RN + wc * 16 * NT + j * 16 + n;
+    if (u >= total_units) continue;
+    const int seq = u / p.Q;
+    const int q = u - seq * p.Q;
+    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
+    if (orow < 0 || orow >= p.Lout) continue;
+    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int co = yi * RM + wr * 16 * MT + i * 16 + g * 4;
+      const long off = rbase + co;
+      bf16_t outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co + r];
+        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
+        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
+        if (Gt) v *= (bf2f(Gt[off + r]) > 0.f ? 1.f : p.gate_slope);
         if (R) v += bf2f(R[off + r]);
         outv[r] = f2bf(v);
       }
@@ -360,19 +508,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 
 }  // namespace
 
+static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase);
+
 bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
-  if (dtype != EVT_DT_BF16) return false;
-  if (out_ch % BM || k_ch % BK) return false;
-  if (p.xact || p.in_slope != 1.f) return false;          // no load-side fusion on the DMA path
-  if (p.nchunk * 32 != k_ch) return false;                 // prepared image must be the ck = 32 layout
-  if ((long)p.nseq * p.Q >= (1L << 31) - BN) return false;
-  const long tiles = (((long)p.nseq * p.Q + BN - 1) / BN) * (out_ch / BM) * nphase;
-  return tiles >= 192;                                     // enough blocks to cover the chip once
+  return deep_kind(p, dtype, out_ch, k_ch, nphase) != 0;
+}
+
+// which tile: 2 = 128 x 128 (conv_deep), 1 = 64 x 64 ring (conv_ring<2,2,4>), 0 = not eligible
+static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
+  if (dtype != EVT_DT_BF16) return 0;
+  if (k_ch % BK || out_ch % 64) return 0;
+  if (p.xact || p.in_slope != 1.f) return 0;              // no load-side fusion on the DMA path
+  if (p.nchunk * 32 != k_ch) return 0;                     // prepared image must be the ck = 32 layout
+  if ((long)p.nseq * p.Q >= (1L << 31) - BN) return 0;
+  const long units = (long)p.nseq * p.Q;
+  if (out_ch % BM == 0 && ((units + BN - 1) / BN) * (out_ch / BM) * nphase >= 192) return 2;
+  static const bool no_ring = getenv("EVT_NO_RING") != nullptr;   // A/B switch for measurements
+  if (!no_ring && ((units + 63) / 64) * (out_ch / 64) * nphase >= 32) return 1;
+  return 0;
 }
 
 int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStream_t st) {
   ConvP p = p_in;
-  if (!deep_eligible(p, EVT_DT_BF16, out_ch, k_ch, nphase)) return EVT_ENOTSUP;
+  const int kind = deep_kind(p, EVT_DT_BF16, out_ch, k_ch, nphase);
+  if (kind == 0) return EVT_ENOTSUP;
+  if (kind == 1) {
+    constexpr int NS = 4;
+    p.Y = out_ch / 64;
+    p.P = (int)(((long)p.nseq * p.Q + 63) / 64);
+    p.U = 0;
+    static bool attr1 = false;
+    const size_t lds1 = (size_t)NS * (64 + 64) * 128;
+    if (!attr1) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring<2, 2, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess)
+        return EVT_ELAUNCH;
+      attr1 = true;
+    }
+    evt_set_last_tag("conv_ring<bf16, 64, 64, 64, x4>");
+    hipLaunchKernelGGL((conv_ring<2, 2, NS>), dim3(8 * ((p.P + 7) / 8) * p.Y, nphase), dim3(256), lds1, st, p);
+    return evt_check_launch();
+  }
   p.Y = out_ch / BM;
   p.P = (int)(((long)p.nseq * p.Q + BN - 1) / BN);
   p.U = 0;

@@ -138,6 +138,33 @@ DEEP_CASES = [
 ]
 
 
+# latency-bound mid-size layers (WN in/res_skip, FFN) -> the 64 x 64 ring-pipelined variant
+RING_CASES = [
+    (192, 384, 5, 1, 2, 1, 1, False, True, 200, 16),
+    (192, 384, 1, 1, 0, 1, 1, False, True, 200, 16),
+    (192, 768, 3, 1, 1, 1, 1, False, False, 61, 16),     # ragged last position tile
+    (768, 192, 3, 1, 1, 1, 1, False, False, 60, 16),
+    (128, 64, 5, 3, 2, 1, 1, False, True, 310, 24),       # strided forward, polyphase backward-data
+]
+
+
+@pytest.mark.parametrize("ci", range(len(RING_CASES)))
+def test_conv_ring_parity(gpu, ci):
+    from easevoice_trainer_amd.hip import conv as HC
+
+    case = RING_CASES[ci]
+    for fusion in (FUSIONS[2], FUSIONS[0]):
+        HC.TRACE = []
+        try:
+            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            tags = {(r[1], r[0]) for r in HC.TRACE}
+        finally:
+            HC.TRACE = None
+        assert ("fwd", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
+        if case[0] % 64 == 0 and case[1] % 64 == 0:
+            assert ("bwd_data", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
+
+
 @pytest.mark.parametrize("ci", range(len(DEEP_CASES)))
 def test_conv_deep_parity(gpu, ci):
     from easevoice_trainer_amd.hip import conv as HC

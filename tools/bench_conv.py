@@ -62,6 +62,11 @@ def main():
     shapes.append(("dS grouped 16->64 k41 s4 g4", 2 * B, 20480, 16, 64, 41, 4, 20, 1, 4, False, 1.0, 1))
     shapes.append(("dS grouped 256->1024 k41 s4 g64", 2 * B, 1280, 256, 1024, 41, 4, 20, 1, 64, False, 1.0, 1))
     shapes.append(("WN in 192->384 k5 T200", B, 200, 192, 384, 5, 1, 2, 1, 1, False, 1.0, 0))
+    shapes.append(("WN rs 192->384 k1 T200", B, 200, 192, 384, 1, 1, 0, 1, 1, False, 1.0, 0))
+    shapes.append(("FFN 192->768 k3 T200", B, 200, 192, 768, 3, 1, 1, 1, 1, False, 1.0, 1))
+    shapes.append(("FFN 768->192 k3 T200", B, 200, 768, 192, 3, 1, 1, 1, 1, False, 1.0, 0))
+    shapes.append(("FFN 192->768 k3 T60", B, 60, 192, 768, 3, 1, 1, 1, 1, False, 1.0, 1))
+    shapes.append(("FFN 768->192 k3 T60", B, 60, 768, 192, 3, 1, 1, 1, 1, False, 1.0, 0))
     shapes.append(("conv_post 16->1 k7", B, 20480, 16, 1, 7, 1, 3, 1, 1, False, 0.01, 2))
 
     if a.only:
