@@ -1332,6 +1332,8 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   p.dbias = nullptr;
   // wide layers with plain operands: LDS-DMA GEMM kernel (conv_deep.hip); its dbias comes from the column-sum kernel
   const bool deep_w = igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
+  // latency-bound mid-size layers: ring-pipelined LDS-DMA kernel (fuses dbias when A is dy)
+  const bool ring_w = !deep_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
   const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
   const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed && !deep_w) || cin1);
@@ -1386,6 +1388,10 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     return evt_check_launch();
   }
   if (deep_w) return evt_conv::launch_wgrad_deep(p, st);
+  if (ring_w) {
+    p.dbias = fuse_bias ? dbias : nullptr;
+    return evt_conv::launch_wgrad_ring(p, st);
+  }
   if (c->dtype == EVT_DT_BF16) {
     p.dbias = fuse_bias ? dbias : nullptr;
     rc = launch_wgrad_tr(p, st);

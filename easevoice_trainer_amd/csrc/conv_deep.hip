@@ -506,6 +506,442 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// wgrad_ring<MA, KT, NS>: wgrad_deep's GEMM with a block tile of 32*MA A-channels x (KT taps x 32 B-channels) and an
+// NS-deep ring of 64-position K stages with counted waits and one raw barrier per stage (see conv_ring): the weight
+// gradients of the WN / FFN / mid-width vocoder layers are 3200..20000-position reductions that were bound by one
+// HBM round trip per stage.  TrStep<MA, KT>: all transpose reads of one K = 32 step behind one wait (generated per
+// shape because the row / tap / k-step displacements are instruction offsets).
+// A-tile swizzle (16-byte slots, applied on the DMA source and undone on the read):
+//   MA = 4 (256-byte rows): slot ^= 2*((row&3) | ((row>>3)&1)<<2)      MA = 2 (128-byte rows): slot ^= 2*(((row>>1)&1) | ((row>>3)&1)<<1)
+// -----------------------------------------------------------------------------------------------------------------
+template <int MA, int KT> struct TrStep;
+template <> struct TrStep<2, 1> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[1]) {
+    uint2 al[2], ah[2], bl[1], bh[1];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %6 offset:0\n\t"
+        "ds_read_b64_tr_b16 %2, %6 offset:512\n\t"
+        "ds_read_b64_tr_b16 %1, %7 offset:0\n\t"
+        "ds_read_b64_tr_b16 %3, %7 offset:512\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:256\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bh[0])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %6 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %2, %6 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %1, %7 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %3, %7 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:2304\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bh[0])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 1; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+template <> struct TrStep<2, 3> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[3]) {
+    uint2 al[2], ah[2], bl[3], bh[3];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %10 offset:0\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:512\n\t"
+        "ds_read_b64_tr_b16 %1, %11 offset:0\n\t"
+        "ds_read_b64_tr_b16 %3, %11 offset:512\n\t"
+        "ds_read_b64_tr_b16 %4, %12 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %12 offset:256\n\t"
+        "ds_read_b64_tr_b16 %5, %12 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %8, %12 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %6, %12 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %9, %12 offset:8448\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %10 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %1, %11 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %3, %11 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %4, %12 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %7, %12 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %5, %12 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %8, %12 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %6, %12 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %9, %12 offset:10496\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+template <> struct TrStep<2, 5> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[5]) {
+    uint2 al[2], ah[2], bl[5], bh[5];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %14 offset:0\n\t"
+        "ds_read_b64_tr_b16 %2, %14 offset:512\n\t"
+        "ds_read_b64_tr_b16 %1, %15 offset:0\n\t"
+        "ds_read_b64_tr_b16 %3, %15 offset:512\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:0\n\t"
+        "ds_read_b64_tr_b16 %9, %16 offset:256\n\t"
+        "ds_read_b64_tr_b16 %5, %16 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %10, %16 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %11, %16 offset:8448\n\t"
+        "ds_read_b64_tr_b16 %7, %16 offset:12288\n\t"
+        "ds_read_b64_tr_b16 %12, %16 offset:12544\n\t"
+        "ds_read_b64_tr_b16 %8, %16 offset:16384\n\t"
+        "ds_read_b64_tr_b16 %13, %16 offset:16640\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %14 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %2, %14 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %1, %15 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %3, %15 offset:4608\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %9, %16 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %5, %16 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %10, %16 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %11, %16 offset:10496\n\t"
+        "ds_read_b64_tr_b16 %7, %16 offset:14336\n\t"
+        "ds_read_b64_tr_b16 %12, %16 offset:14592\n\t"
+        "ds_read_b64_tr_b16 %8, %16 offset:18432\n\t"
+        "ds_read_b64_tr_b16 %13, %16 offset:18688\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+template <> struct TrStep<4, 1> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[1]) {
+    uint2 al[4], ah[4], bl[1], bh[1];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %10 offset:0\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %11 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %11 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %12 offset:0\n\t"
+        "ds_read_b64_tr_b16 %6, %12 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %13 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %13 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %8, %14 offset:0\n\t"
+        "ds_read_b64_tr_b16 %9, %14 offset:256\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bh[0])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %10 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %1, %11 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %5, %11 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %2, %12 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %6, %12 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %3, %13 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %7, %13 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %8, %14 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %9, %14 offset:2304\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bh[0])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 1; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+template <> struct TrStep<4, 3> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[3]) {
+    uint2 al[4], ah[4], bl[3], bh[3];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %14 offset:0\n\t"
+        "ds_read_b64_tr_b16 %4, %14 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %15 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %15 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:0\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %17 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %17 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %8, %18 offset:0\n\t"
+        "ds_read_b64_tr_b16 %11, %18 offset:256\n\t"
+        "ds_read_b64_tr_b16 %9, %18 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %12, %18 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %10, %18 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %13, %18 offset:8448\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %14 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %4, %14 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %1, %15 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %5, %15 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %3, %17 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %7, %17 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %8, %18 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %11, %18 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %9, %18 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %12, %18 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %10, %18 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %13, %18 offset:10496\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+template <> struct TrStep<4, 5> {
+  template <int KS>
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[5]) {
+    uint2 al[4], ah[4], bl[5], bh[5];
+    if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %18 offset:0\n\t"
+        "ds_read_b64_tr_b16 %4, %18 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %19 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %19 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %20 offset:0\n\t"
+        "ds_read_b64_tr_b16 %6, %20 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %21 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %21 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %8, %22 offset:0\n\t"
+        "ds_read_b64_tr_b16 %13, %22 offset:256\n\t"
+        "ds_read_b64_tr_b16 %9, %22 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %14, %22 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %10, %22 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %15, %22 offset:8448\n\t"
+        "ds_read_b64_tr_b16 %11, %22 offset:12288\n\t"
+        "ds_read_b64_tr_b16 %16, %22 offset:12544\n\t"
+        "ds_read_b64_tr_b16 %12, %22 offset:16384\n\t"
+        "ds_read_b64_tr_b16 %17, %22 offset:16640\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %18 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %4, %18 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %1, %19 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %5, %19 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %2, %20 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %6, %20 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %3, %21 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %7, %21 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %8, %22 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %13, %22 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %9, %22 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %14, %22 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %10, %22 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %15, %22 offset:10496\n\t"
+        "ds_read_b64_tr_b16 %11, %22 offset:14336\n\t"
+        "ds_read_b64_tr_b16 %16, %22 offset:14592\n\t"
+        "ds_read_b64_tr_b16 %12, %22 offset:18432\n\t"
+        "ds_read_b64_tr_b16 %17, %22 offset:18688\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]), "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bl[4]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3]), "=&v"(bh[4])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+    }
+    union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+  }
+};
+
+template <int MA> __device__ __forceinline__ int a_swz(int row) {
+  return MA == 4 ? 2 * ((row & 3) | (((row >> 3) & 1) << 2)) : 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+
+template <int MA, int KT, int NS>
+__global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
+  constexpr int AROW = 64 * MA;                     // bytes per A-tile row (32*MA channels)
+  constexpr int ABYTES = WPOS * AROW;
+  constexpr int STAGE = ABYTES + KT * WB_BYTES;
+  constexpr int G = MA + KT;                        // DMA instructions per wave per stage
+  constexpr int RPI = 16 / MA;                      // A rows per DMA instruction
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j16 = lane & 15, g8 = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  int bx = blockIdx.x;
+  const int ch = bx % p.nchunk; bx /= p.nchunk;
+  const int tgi = bx % p.ntapgrp;
+  const int atile = bx / p.ntapgrp;
+  const int t0 = tgi * KT;
+  const int ntap = min(KT, p.KHp - t0);
+  const int a0 = atile * 32 * MA;
+
+  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const int total_units = p.nseq * p.Q;
+  const int nstages = (total_units + WPOS - 1) / WPOS;
+  const int st_begin = blockIdx.y * stages_per_split;
+  const int nst = min(nstages, st_begin + stages_per_split) - st_begin;
+  if (nst <= 0) return;
+
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  int arow[MA], acol[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) {
+    arow[i] = wave * 16 + i * RPI + lane / (4 * MA);
+    acol[i] = a0 + (((lane % (4 * MA)) ^ a_swz<MA>(arow[i])) * 8);
+  }
+  const int brow = wave * 16 + (lane >> 2);
+  const int bcol = ch * 32 + (((lane & 3) ^ (2 * ((brow >> 3) & 1))) * 8);
+
+  auto issue = [&](int s) {
+    unsigned char* base = smem + (s % NS) * STAGE;
+    const int u0 = (st_begin + s) * WPOS;
+#pragma unroll
+    for (int i = 0; i < MA; ++i) {
+      const int u = u0 + arow[i];
+      glds16(u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc, base + wave * (16 * AROW) + i * 1024);
+    }
+    const int u = u0 + brow;
+    const bool uok = u < total_units;
+    const int seq = uok ? u / p.Q : 0;
+    const int q = u - seq * p.Q;
+    const int r0 = q * p.s + t0 * p.dil + p.off;
+    const bf16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int r = r0 + t * p.dil;
+      const bool ok = uok && (unsigned)r < (unsigned)p.LB;
+      glds16(ok ? rsrc + (long)t * p.dil * p.CB : zsrc, base + ABYTES + t * WB_BYTES + wave * 1024);
+    }
+  };
+
+  f32x4 acc[MA][KT];
+#pragma unroll
+  for (int i = 0; i < MA; ++i)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dbias (column sums of the A operand = dy) by the (chunk 0, tap group 0) blocks, from the staged tiles
+  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0 && tid < 32 * MA;
+  float bsum = 0.f;
+
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int frow = g8 * 8 + (j16 >> 2);
+  const int fa = a_swz<MA>(frow);                   // unchanged by +4 and +32 rows
+  const int fb = 2 * ((frow >> 3) & 1);
+  const int half = (j16 & 1) * 8;
+  int a_off[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) a_off[i] = frow * AROW + (((wr * 2 * MA + i * 2 + ((j16 & 3) >> 1)) ^ fa) * 16) + half;
+  const int b_off = ABYTES + frow * 64 + (((wc * 2 + ((j16 & 3) >> 1)) ^ fb) * 16) + half;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nst) issue(s);
+  for (int s = 0; s < nst; ++s) {
+    const int ahead = min(NS - 2, nst - 1 - s);
+    if (ahead >= 2) wait_vmcnt<2 * G>();
+    else if (ahead == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NS - 1 < nst) issue(s + NS - 1);
+    const unsigned sbase = lds0 + (s % NS) * STAGE;
+    unsigned aa[MA];
+#pragma unroll
+    for (int i = 0; i < MA; ++i) aa[i] = sbase + a_off[i];
+    const unsigned ba = sbase + b_off;
+    bf16x8 a[MA], b[KT];
+    TrStep<MA, KT>::template load<0>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+      if (t < ntap)
+#pragma unroll
+        for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    TrStep<MA, KT>::template load<1>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+      if (t < ntap)
+#pragma unroll
+        for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    if (do_bias) {
+      const unsigned char* at = smem + (s % NS) * STAGE;
+      const int slot = tid >> 3, sub = (tid & 7) * 2;
+      for (int r = 0; r < WPOS; ++r)
+        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * AROW + ((slot ^ a_swz<MA>(r)) * 16) + sub));
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
+
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (t >= ntap) continue;
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wr * 16 * MA + i * 16 + g8 * 4 + r;
+        const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * 32 + wc * 16 + j16;
+        atomicAdd(p.dw + off, acc[i][t][r]);
+      }
+  }
+}
+
 }  // namespace
 
 static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase);
@@ -605,6 +1041,57 @@ int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
   evt_set_last_tag("wgrad_deep<bf16, 128, 5x32, 64>");
   hipLaunchKernelGGL(wgrad_deep, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
   return evt_check_launch();
+}
+
+// ---- wgrad_ring dispatch ----
+template <int MA, int KT, int NS>
+static int launch_ring_inst(const WgP& p, int per, hipStream_t st) {
+  constexpr size_t lds = (size_t)NS * (WPOS * 64 * MA + KT * WB_BYTES);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring<MA, KT, NS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  const long tiles = (long)(p.CA / (32 * MA)) * p.nchunk * p.ntapgrp;
+  evt_set_last_tag("wgrad_ring<bf16, %d, %dx32, 64, x%d>", 32 * MA, KT, NS);
+  hipLaunchKernelGGL((wgrad_ring<MA, KT, NS>), dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
+  return evt_check_launch();
+}
+
+bool wgrad_ring_eligible(const WgP& p, int dtype) {
+  static const bool no_ring = getenv("EVT_NO_RING") != nullptr;
+  if (no_ring || dtype != EVT_DT_BF16) return false;
+  if (p.CA % 64 || p.CB % 32) return false;
+  if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
+  if (p.LA != p.Q) return false;
+  const long units = (long)p.nseq * p.Q;
+  if (units >= (1L << 31) - WPOS || units < 512) return false;
+  return true;
+}
+
+int launch_wgrad_ring(const WgP& p_in, hipStream_t st) {
+  WgP p = p_in;
+  if (!wgrad_ring_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  const int KT = p.KHp <= 1 ? 1 : (p.KHp <= 3 ? 3 : 5);
+  p.nchunk = p.CB / 32;
+  p.ntapgrp = (p.KHp + KT - 1) / KT;
+  const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
+  // 128-channel tiles when that still yields enough blocks, else 64
+  const long tiles128 = p.CA % 128 == 0 ? (long)(p.CA / 128) * p.nchunk * p.ntapgrp : 0;
+  const int MA = (tiles128 >= 128 || (tiles128 > 0 && tiles128 * (nstages / 4) >= 512)) ? 4 : 2;
+  const long tiles = (long)(p.CA / (32 * MA)) * p.nchunk * p.ntapgrp;
+  static const long target = getenv("EVT_RING_BLOCKS") ? atol(getenv("EVT_RING_BLOCKS")) : 256;   // tuning knob (measured: 256 best)
+  long split = (target + tiles - 1) / tiles;      // ~1 block per CU: more splits only add fp32 atomics
+  if (split > nstages / 3) split = nstages / 3;   // >= 3 K stages per block
+  if (split < 1) split = 1;
+  const int per = (int)((nstages + split - 1) / split);
+  p.nsplit = (int)((nstages + per - 1) / per);
+#define RING(MA_, KT_) (MA_ == 4 && KT_ == 5 ? launch_ring_inst<MA_, KT_, 3>(p, per, st) : launch_ring_inst<MA_, KT_, 4>(p, per, st))
+  if (MA == 4) return KT == 1 ? RING(4, 1) : (KT == 3 ? RING(4, 3) : RING(4, 5));
+  return KT == 1 ? RING(2, 1) : (KT == 3 ? RING(2, 3) : RING(2, 5));
+#undef RING
 }
 
 }  // namespace evt_conv

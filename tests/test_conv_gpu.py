@@ -163,6 +163,7 @@ def test_conv_ring_parity(gpu, ci):
         assert ("fwd", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
         if case[0] % 64 == 0 and case[1] % 64 == 0:
             assert ("bwd_data", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
+        assert any(k == "bwd_weight" and t.startswith("wgrad_ring<") for k, t in tags), tags
 
 
 @pytest.mark.parametrize("ci", range(len(DEEP_CASES)))
