@@ -121,6 +121,24 @@ __global__ void dact_mul_kernel(const T* dy, const T* y, int kind, float slope, 
   }
 }
 
+// out = leaky_relu(x): the activated copy the HiFi-GAN residual units feed to their convolutions (16 bytes per lane)
+template <typename T>
+__global__ void lrelu_kernel(const T* x, float slope, T* out, long n) {
+  constexpr int V = 16 / sizeof(T);
+  const long nv = n / V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    T* h = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) h[e] = from_f<T>(lrelu_f(to_f<T>(h[e]), slope));
+    reinterpret_cast<uint4*>(out)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - nv * V) {
+    const long i = nv * V + threadIdx.x;
+    out[i] = from_f<T>(lrelu_f(to_f<T>(x[i]), slope));
+  }
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <typename T>
@@ -289,6 +307,20 @@ int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, f
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(add3_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b,
                        (const float*)c, scale, (float*)out, (long)n);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_leaky_relu(int32_t dtype, const void* x, float slope, void* out, int64_t n, void* stream) {
+  if (!x || !out || n <= 0) return EVT_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(lrelu_kernel<bf16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const bf16_t*)x, slope,
+                       (bf16_t*)out, (long)n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(lrelu_kernel<float>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (const float*)x, slope,
+                       (float*)out, (long)n);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

@@ -306,33 +306,44 @@ class ConvFn(torch.autograd.Function):
         return dx, None, dres, None, None, None, None
 
 
+def _lrelu(x, slope):
+    out = torch.empty_like(x)
+    L.check(L.lib().evt_leaky_relu(L.dt_of(x), L.ptr(x), C.c_float(slope), L.ptr(out), C.c_int64(x.numel()),
+                                   L.stream_ptr()), "evt_leaky_relu")
+    return out
+
+
 class ResUnitFn(torch.autograd.Function):
-    """HiFi-GAN ResBlock1 inner step  y = x + c2(lrelu(c1(lrelu(x))))  (modules.py:299-308) as
-    2 launches forward and 4 backward, with the residual add and both leaky-relu derivatives fused
-    into the conv epilogues."""
+    """HiFi-GAN ResBlock1 inner step  y = x + c2(lrelu(c1(lrelu(x))))  (modules.py:299-308).
+    Forward: xa = lrelu(x) (one element-wise launch), mid_a = lrelu(c1(xa)) (activation = c1's epilogue),
+    y = c2(mid_a) + x (residual = c2's epilogue).  Every convolution and weight gradient therefore sees PLAIN operands
+    and runs on the LDS-DMA kernels; the two leaky-relu derivatives are the gate epilogues of the backward-data
+    launches (the sign of lrelu(v) is the sign of v), the residual gradient is the second one's add epilogue."""
 
     @staticmethod
     def forward(ctx, x, anchor, s1, s2, slope):
-        mid = _fwd(s1, x, None, slope, L.ACT_NONE, 1.0)
-        y = _fwd(s2, mid, x, slope, L.ACT_NONE, 1.0)
+        xa = _lrelu(x, slope)
+        mid_a = _fwd(s1, xa, None, 1.0, L.ACT_LRELU, slope)
+        y = _fwd(s2, mid_a, x, 1.0, L.ACT_NONE, 1.0)
         ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
-        ctx.save_for_backward(x, mid)
+        ctx.save_for_backward(xa, mid_a)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mid = ctx.saved_tensors
+        xa, mid_a = ctx.saved_tensors
         s1, s2, slope = ctx.s1, ctx.s2, ctx.slope
         dy = dy.contiguous()
-        nseq, lin = x.size(0), x.size(1)
+        nseq, lin = xa.size(0), xa.size(1)
         if s2.bank.weight_grads:
-            _bwd_weight(s2, mid, dy, None, nseq, lin, slope, L.ACT_NONE, 1.0)
-        dmid = _bwd_data(s2, dy, None, mid, None, nseq, lin, slope, L.ACT_NONE, 1.0)
+            _bwd_weight(s2, mid_a, dy, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+        # d(c1 output before its activation) = (W2^T dy) * lrelu'(mid): gate epilogue on mid_a
+        dmid = _bwd_data(s2, dy, None, mid_a, None, nseq, lin, slope, L.ACT_NONE, 1.0)
         if s1.bank.weight_grads:
-            _bwd_weight(s1, x, dmid, None, nseq, lin, slope, L.ACT_NONE, 1.0)
+            _bwd_weight(s1, xa, dmid, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _bwd_data(s1, dmid, None, x, dy, nseq, lin, slope, L.ACT_NONE, 1.0)
+            dx = _bwd_data(s1, dmid, None, xa, dy, nseq, lin, slope, L.ACT_NONE, 1.0)
         return dx, None, None, None, None
 
 

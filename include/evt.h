@@ -130,6 +130,10 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* p, const void* x, const void*
 int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, float scale, void* out,
                    int64_t n, void* stream);
 
+/* out = leaky_relu(x, slope).  The HiFi-GAN residual unit (modules.py:299-308) keeps an activated copy of its input
+ * so that its convolutions and weight gradients take plain operands (LDS-DMA kernels).  16-byte aligned. */
+int evt_leaky_relu(int32_t dtype, const void* x, float slope, void* out, int64_t n, void* stream);
+
 /* out = dy * act'(y), the activation derivative taken through the activation OUTPUT y (leaky-relu keeps the sign,
  * tanh' = 1 - y^2).  Replaces the autograd node of F.leaky_relu after a wide DiscriminatorP conv
  * (models.py:527-531) when evt_conv1d_wants_plain_dy() says the GEMM-grade path will consume dy: both backward
