@@ -34,10 +34,21 @@ __device__ __forceinline__ long alt_idx(const evt_wlayout& L, int d0, int d1, in
   return ((((long)ph * L.d1 + d1) * L.alt_nchunk + chunk) * L.alt_kp + jp) * L.alt_ck + cc;
 }
 
-__global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* items, const int32_t* rows) {
+// Workgroup -> table row: consecutive blockIdx values round-robin over the 8 XCDs, so a plain row = blockIdx mapping
+// would spread the 32 rows that complete one 64-byte ALT run (cc = d0 % 32) over 8 different L2s.  Rows are handed out
+// to an XCD in runs of 32 instead, so those partial-line stores meet in one L2 and leave it as whole lines.
+__device__ __forceinline__ int fold_row_of_block(int b, int nrows) {
+  const int xcd = b & 7, slot = b >> 3;
+  const int row = ((slot >> 5) * 8 + xcd) * 32 + (slot & 31);
+  return row < nrows ? row : -1;
+}
+
+__global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* items, const int32_t* rows, int nrows) {
   __shared__ float red[4];
-  const evt_wprep_item it = items[rows[2 * blockIdx.x]];
-  const int d0 = rows[2 * blockIdx.x + 1];
+  const int trow = fold_row_of_block(blockIdx.x, nrows);
+  if (trow < 0) return;
+  const evt_wprep_item it = items[rows[2 * trow]];
+  const int d0 = rows[2 * trow + 1];
   const evt_wlayout& L = it.lay;
   const int n = L.d1 * L.k;
   const float* v = it.v + (long)d0 * n;
@@ -287,7 +298,8 @@ const char* evt_version(void) { return "evt-hip 0.1 (gfx950)"; }
 
 int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream) {
   if (!items || !row_index || nrows <= 0) return EVT_EINVAL;
-  hipLaunchKernelGGL(wn_fold_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, items, row_index);
+  const int nblocks = ((nrows + 255) / 256) * 256;        // whole 8 x 32 row groups (fold_row_of_block)
+  hipLaunchKernelGGL(wn_fold_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, items, row_index, nrows);
   return evt_check_launch();
 }
 
