@@ -1336,7 +1336,7 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   const bool ring_w = !deep_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
   const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
-  const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed && !deep_w) || cin1);
+  const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed) || cin1);
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
@@ -1387,7 +1387,10 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
       hipLaunchKernelGGL(conv_naive_bwd_weight<float>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
     return evt_check_launch();
   }
-  if (deep_w) return evt_conv::launch_wgrad_deep(p, st);
+  if (deep_w) {
+    p.dbias = fuse_bias ? dbias : nullptr;
+    return evt_conv::launch_wgrad_deep(p, st);
+  }
   if (ring_w) {
     p.dbias = fuse_bias ? dbias : nullptr;
     return evt_conv::launch_wgrad_ring(p, st);

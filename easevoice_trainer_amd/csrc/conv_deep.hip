@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int t = 0; t < WKT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dbias (column sums of A = dy) by the (chunk 0, tap group 0) blocks, read back from the staged tiles
+  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0 && tid < 128;
+  float bsum = 0.f;
 
   // fragment read addresses (bytes, relative to the stage base) for ks = 0; ks = 1 adds 32 rows
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -489,7 +492,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
       if (t < ntap)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    if (do_bias) {
+      const unsigned char* at = smem + buf * WSTAGE;
+      const int slot = tid >> 3, sub = (tid & 7) * 2;
+      for (int r = 0; r < WPOS; ++r) {
+        const int f = 2 * ((r & 3) | (((r >> 3) & 1) << 2));
+        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * 256 + ((slot ^ f) * 16) + sub));
+      }
+    }
   }
+  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
 
   // lane holds A channels g8*4..+3 (rows) x B channel j16 (column) of each tile
 #pragma unroll
@@ -1005,7 +1017,7 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
 bool wgrad_deep_eligible(const WgP& p, int dtype) {
   if (dtype != EVT_DT_BF16) return false;
   if (p.CA % 128 || p.CB % 32) return false;
-  if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f || p.dbias) return false;
+  if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
   if (p.LA != p.Q) return false;                            // A rows are addressed by the flat position
   if ((long)p.nseq * p.Q >= (1L << 31) - WPOS) return false;
   // worth it only for GEMM-sized problems: enough (A tile, chunk) pairs and enough positions
