@@ -985,6 +985,7 @@ int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, bool split, hipS
 int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st, bool allow_deep) {
   if (A % 16 || B % 16) return EVT_ENOTSUP;
   if (allow_deep && evt_conv::deep_eligible(p, dtype, A, B, nphase)) return evt_conv::launch_conv_deep(p, A, B, nphase, st);
+  if (allow_deep && evt_conv::narrow_eligible(p, dtype, A, B, nphase)) return evt_conv::launch_conv_narrow(p, A, B, nphase, st);
   const int CK = (B % 32 == 0) ? 32 : 16;
   const int MT = (A % 64 == 0) ? 4 : (A % 32 == 0 ? 2 : 1);
   p.Y = A / (16 * MT);
@@ -1149,6 +1150,12 @@ int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c) {
   if (c->stride == 1) p.Q = c->lin;
   else { nphase = c->stride; p.Q = (c->lin - 1 + c->pad) / c->stride + 1; }
   if (evt_conv::deep_eligible(p, c->dtype, c->cin, c->cout, nphase)) return 1;
+  {  // the stride-1 narrow kernel takes plain operands too
+    evt_wlayout l; evt_conv1d_layout(c, &l);
+    ConvP q = p;
+    q.s_in = q.s_out = 1; q.off_out = 0; q.KHp = l.alt_kp; q.nchunk = l.alt_nchunk;
+    if (c->stride == 1 && evt_conv::narrow_eligible(q, c->dtype, c->cin, c->cout, 1)) return 1;
+  }
   // ... or the weight gradient does (A = dy [nseq][lout][cout], B = x)
   WgP w{};
   w.nseq = c->nseq; w.KHp = c->k; w.Q = w.LA = evt_conv1d_lout(c); w.CA = c->cout; w.CB = c->cin;

@@ -1,6 +1,7 @@
 // Launch descriptor of the implicit-GEMM conv kernels (conv1d.hip: conv_igemm, conv_deep.hip: conv_deep).
 #pragma once
 #include "evt_common.h"
+#include <cstdlib>
 
 namespace evt_conv {
 
@@ -50,6 +51,9 @@ struct WgP {
 // load-side fusion).  Returns EVT_ENOTSUP when the descriptor does not qualify.
 bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase);
 int launch_conv_deep(const ConvP& p, int out_ch, int k_ch, int nphase, hipStream_t st);
+// conv_narrow.hip: weights-in-registers kernel for the stride-1 C = 16 / 32 vocoder layers (plain operands)
+bool narrow_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase);
+int launch_conv_narrow(const ConvP& p, int out_ch, int k_ch, int nphase, hipStream_t st);
 // weight gradient on the same LDS-DMA structure (A channels % 128 == 0, B channels % 32 == 0, plain operands, no dbias)
 bool wgrad_deep_eligible(const WgP& p, int dtype);
 int launch_wgrad_deep(const WgP& p, hipStream_t st);

@@ -148,6 +148,33 @@ RING_CASES = [
 ]
 
 
+# late vocoder stages (C = 16 / 32, stride 1, dilated): the weights-in-registers persistent kernel
+NARROW_CASES = [
+    (16, 16, 11, 1, 25, 5, 1, False, True, 700, 8),
+    (16, 16, 3, 1, 1, 1, 1, False, True, 1100, 4),
+    (16, 16, 7, 1, 9, 3, 1, False, True, 333, 14),        # ragged tiles, several sequences
+    (32, 32, 7, 1, 9, 3, 1, False, True, 600, 8),
+    (32, 32, 3, 1, 1, 1, 1, False, True, 2100, 2),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(NARROW_CASES)))
+def test_conv_narrow_parity(gpu, ci):
+    from easevoice_trainer_amd.hip import conv as HC
+
+    case = NARROW_CASES[ci]
+    for fusion in (FUSIONS[0], FUSIONS[2], FUSIONS[1]):
+        HC.TRACE = []
+        try:
+            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            tags = {(r[1], r[0].split(",")[0]) for r in HC.TRACE}
+        finally:
+            HC.TRACE = None
+        if fusion["in_slope"] == 1.0:
+            assert ("fwd", "conv_narrow<bf16") in tags, tags
+        assert ("bwd_data", "conv_narrow<bf16") in tags, tags
+
+
 @pytest.mark.parametrize("ci", range(len(RING_CASES)))
 def test_conv_ring_parity(gpu, ci):
     from easevoice_trainer_amd.hip import conv as HC
