@@ -970,7 +970,8 @@ static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
   if (p.nchunk * 32 != k_ch) return 0;                     // prepared image must be the ck = 32 layout
   if ((long)p.nseq * p.Q >= (1L << 31) - BN) return 0;
   const long units = (long)p.nseq * p.Q;
-  if (out_ch % BM == 0 && ((units + BN - 1) / BN) * (out_ch / BM) * nphase >= 192) return 2;
+  static const long min128 = getenv("EVT_DEEP_MIN_TILES") ? atol(getenv("EVT_DEEP_MIN_TILES")) : 192;   // tuning knob
+  if (out_ch % BM == 0 && ((units + BN - 1) / BN) * (out_ch / BM) * nphase >= min128) return 2;
   static const bool no_ring = getenv("EVT_NO_RING") != nullptr;   // A/B switch for measurements
   if (!no_ring && ((units + 63) / 64) * (out_ch / 64) * nphase >= 32) return 1;
   return 0;

@@ -182,7 +182,7 @@ class WeightBank:
                 "evt_wn_grad_multi")
 
 
-TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1, shape) per launch
+TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch
 
 
 def _t0():
@@ -204,7 +204,7 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
     L.lib().evt_last_kernel_tag.restype = C.c_char_p
     shape = (f"{'T' if m.transposed else ''}{m.cin}>{m.cout} k{m.k} s{m.stride} d{m.dil} g{m.groups} "
              f"n{nseq} L{lin}")
-    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape))
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape, m))
 
 
 def _fwd(slot, x, res, in_slope, out_act, out_slope):

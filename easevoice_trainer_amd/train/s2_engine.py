@@ -185,7 +185,17 @@ class S2Engine:
                     return self.step(*inputs)
                 finally:
                     self.graphs_enabled = True
-            self._capture(ent, inputs)
+            counts = (self.optim_d.step_count, self.optim_g.step_count)
+            try:
+                self._capture(ent, inputs)
+            except Exception as e:   # capture is an optimisation: never let it take the run down
+                import warnings
+
+                warnings.warn(f"HIP-graph capture of the s2 step failed ({e!r}); continuing with eager launches")
+                self.optim_d.step_count, self.optim_g.step_count = counts
+                torch.cuda.synchronize()
+                self.graphs_enabled = False
+                return self.step(*inputs)
         for dst, src in zip(ent["static"], inputs):
             if dst is not None:
                 dst.copy_(src, non_blocking=True)

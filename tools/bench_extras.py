@@ -37,7 +37,14 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         HC.TRACE = None
         eng.graphs_enabled = graphs
     agg = {}
-    for tag, kind, flops, nbytes, e0, e1, _shape in rec:
+    dec_mods = {id(m) for m in eng.net_g.dec.modules()}
+    voc = dict(ms=0.0, bytes=0.0, flops=0.0, calls=0)
+    for tag, kind, flops, nbytes, e0, e1, _shape, mod in rec:
+        if id(mod) in dec_mods:
+            voc["ms"] += e0.elapsed_time(e1)
+            voc["bytes"] += nbytes
+            voc["flops"] += flops
+            voc["calls"] += 1
         a = agg.setdefault(tag, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
         a["ms"] += e0.elapsed_time(e1)
         a["calls"] += 1
@@ -56,7 +63,18 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         r = dict(bound="mfma", achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf)
     else:
         r = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
-    r.update(traffic=None, kernel=tag, launches_per_step=a["calls"] / n_steps,
+    # the HiFi-GAN vocoder (`dec`) convolutions forward + backward against the HBM roofline, with the
+    # per-launch algorithmic bytes (every operand tensor once) summed over its 91 convs x (fwd, bwd-data, bwd-weight)
+    if voc["calls"]:
+        vsec = voc["ms"] / 1e3
+        r_voc = dict(bound="hbm", achieved=voc["bytes"] / vsec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=voc["bytes"] / vsec / 1e9 / HBM_PEAK_GBS, ms_per_step=voc["ms"] / n_steps,
+                     launches_per_step=voc["calls"] / n_steps, algorithmic_gb_per_step=voc["bytes"] / n_steps / 1e9,
+                     tflops=voc["flops"] / vsec / 1e12,
+                     note="late stages (C <= 64) are HBM/launch-bound, the k=7/11 convs at C >= 64 are MFMA-bound")
+    else:
+        r_voc = None
+    r.update(traffic=None, kernel=tag, hifigan_dec=r_voc, launches_per_step=a["calls"] / n_steps,
              avg_launch_us=a["ms"] * 1e3 / a["calls"], ms_per_step=a["ms"] / n_steps,
              algorithmic_gflop_per_launch=a["flops"] / a["calls"] / 1e9,
              algorithmic_mb_per_launch=a["bytes"] / a["calls"] / 1e6, intensity_flop_per_byte=intensity,

@@ -35,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     rec, HC.TRACE = HC.TRACE, None
     agg = {}
-    for tag, kind, flops, nbytes, e0, e1, shape in rec:
+    for tag, kind, flops, nbytes, e0, e1, shape, _m in rec:
         a = agg.setdefault((tag, kind, shape), [0.0, 0, 0.0, 0.0])
         a[0] += e0.elapsed_time(e1)
         a[1] += 1
