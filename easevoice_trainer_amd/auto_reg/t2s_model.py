@@ -18,6 +18,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..hip import lib as L
+from ..hip.enc import bump_rng, new_site, relu_dropout, res_drop_ln
 from .ops import AddLayerNormFn, CrossEntropySumFn, PrefixLMAttentionFn
 
 
@@ -104,9 +105,19 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.norm1 = LayerNorm(d_model)
         self.norm2 = LayerNorm(d_model)
+        self._sites = [new_site() for _ in range(3)]
 
     def forward(self, x, x_lens, y_lens, x_len, seed):
-        sa = self.dropout1(self.self_attn(x, x_lens, y_lens, x_len, seed))
+        p = self.dropout.p if self.training else 0.0
+        sa = self.self_attn(x, x_lens, y_lens, x_len, seed)
+        if p > 0.0 and x.is_cuda:
+            # training: dropout1 / dropout2 ride in the residual+LayerNorm launch, the inner dropout in the relu launch
+            # (masks from the device-counter hash stream of hip/enc.py, one stream id per site)
+            x = res_drop_ln(x, sa.contiguous(), self.norm1.weight, self.norm1.bias, None, p, self._sites[0], self.norm1.eps)
+            h = relu_dropout(F.linear(x, self.linear1.weight.to(x.dtype), self.linear1.bias.to(x.dtype)), p, self._sites[1])
+            ff = F.linear(h, self.linear2.weight.to(x.dtype), self.linear2.bias.to(x.dtype))
+            return res_drop_ln(x, ff.contiguous(), self.norm2.weight, self.norm2.bias, None, p, self._sites[2], self.norm2.eps)
+        sa = self.dropout1(sa)
         x = AddLayerNormFn.apply(x, sa, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = F.relu(F.linear(x, self.linear1.weight.to(x.dtype), self.linear1.bias.to(x.dtype)))
         ff = self.dropout2(F.linear(self.dropout(h), self.linear2.weight.to(x.dtype), self.linear2.bias.to(x.dtype)))
@@ -170,6 +181,8 @@ class Text2SemanticDecoder(nn.Module):
         y_pos = self.ar_audio_position(self.ar_audio_embedding(y_in))
         xy = torch.cat([xe, y_pos], dim=1).to(cd).contiguous()
         self._seed = (self._seed * 1664525 + 1013904223) & 0x7FFFFFFF
+        if xy.is_cuda:
+            bump_rng(xy.device)      # new dropout masks for the fused residual/LayerNorm and relu launches
         xy_dec = self.h(xy, x_lens.to(torch.int32).contiguous(), y_lens.to(torch.int32).contiguous(), x_len, self._seed)
         logits = F.linear(xy_dec[:, x_len:], self.ar_predict_layer.weight.to(cd))        # [B, Ty, V]
         loss, hits = CrossEntropySumFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k,

@@ -284,6 +284,39 @@ __global__ void wn_residual_bwd(const T* dx_out, const T* dacc_out, const int* l
   }
 }
 
+// ---- y = dropout(relu(x)) and its backward dx = dy * mult * (x > 0): the FFN inner activation of the s1 blocks
+//      (transformer.py:330-334 of the reference: linear2(dropout(relu(linear1(x))))), one pass each way ----
+template <typename T>
+__global__ void relu_dropout_fwd(const T* x, float p, const unsigned* seed_dev, unsigned site, T* y, long n) {
+  constexpr int V = 16 / sizeof(T);
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  const long nv = n / V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    T* h = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) h[e] = from_f<T>(fmaxf(to_f<T>(h[e]), 0.f) * drop_mult(dc, (unsigned long)(i * V + e)));
+    reinterpret_cast<uint4*>(y)[i] = v;
+  }
+}
+
+template <typename T>
+__global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigned* seed_dev, unsigned site, T* dx, long n) {
+  constexpr int V = 16 / sizeof(T);
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  const long nv = n / V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const uint4 xv = reinterpret_cast<const uint4*>(x)[i];
+    uint4 dv = reinterpret_cast<const uint4*>(dy)[i];
+    const T* px = reinterpret_cast<const T*>(&xv);
+    T* pd = reinterpret_cast<T*>(&dv);
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      pd[e] = from_f<T>(to_f<T>(px[e]) > 0.f ? to_f<T>(pd[e]) * drop_mult(dc, (unsigned long)(i * V + e)) : 0.f);
+    reinterpret_cast<uint4*>(dx)[i] = dv;
+  }
+}
+
 __global__ void counter_add_kernel(unsigned* c, unsigned inc) { *c += inc; }
 
 }  // namespace
@@ -374,6 +407,42 @@ int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out,
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(wn_residual_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)dx_out,
                        (const float*)dacc_out, lens, rows_per_seq, (float*)dx, (float*)drs, (long)rows, H, last);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site, void* y,
+                         int64_t n, void* stream) {
+  if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (n % V || (((uintptr_t)x | (uintptr_t)y) & 15)) return EVT_EINVAL;
+  long blocks = (n / V + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(relu_dropout_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, p, seed_dev, site,
+                       (bf16_t*)y, (long)n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(relu_dropout_fwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, p, seed_dev, site,
+                       (float*)y, (long)n);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev, uint32_t site,
+                         void* dx, int64_t n, void* stream) {
+  if (!x || !dy || !dx || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (n % V || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return EVT_EINVAL;
+  long blocks = (n / V + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(relu_dropout_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       p, seed_dev, site, (bf16_t*)dx, (long)n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(relu_dropout_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, p,
+                       seed_dev, site, (float*)dx, (long)n);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

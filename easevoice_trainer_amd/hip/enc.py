@@ -197,3 +197,33 @@ class UnbindRowsFn(torch.autograd.Function):
 
 def unbind_rows(t):
     return UnbindRowsFn.apply(t)
+
+
+class ReluDropoutFn(torch.autograd.Function):
+    """y = dropout(relu(x)) in one pass; the backward regenerates the mask and applies the relu gate in one pass"""
+
+    @staticmethod
+    def forward(ctx, x, p, site):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().evt_relu_dropout_fwd(L.dt_of(x), L.ptr(x), C.c_float(p), L.ptr(rng_counter(x.device)),
+                                             C.c_uint32(site), L.ptr(y), C.c_int64(x.numel()), L.stream_ptr()),
+                "evt_relu_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (p, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, site = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().evt_relu_dropout_bwd(L.dt_of(x), L.ptr(x), L.ptr(dy), C.c_float(p), L.ptr(rng_counter(x.device)),
+                                             C.c_uint32(site), L.ptr(dx), C.c_int64(x.numel()), L.stream_ptr()),
+                "evt_relu_dropout_bwd")
+        return dx, None, None
+
+
+def relu_dropout(x, p, site):
+    return ReluDropoutFn.apply(x, float(p), int(site))

@@ -108,3 +108,24 @@ def test_wn_residual(gpu, dtype):
     # first layer: no accumulator yet
     xo2, ao2 = wn_residual(x, rs, None, lens)
     assert torch.equal(ao2, rs[..., H:].contiguous())
+
+
+def test_relu_dropout(gpu):
+    from easevoice_trainer_amd.hip import enc as E
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 64, 256, generator=g).bfloat16().to(gpu)
+    assert torch.equal(E.relu_dropout(x, 0.0, 3), torch.relu(x))
+    E.seed_rng(gpu, 5)
+    p = 0.1
+    xr = x.clone().requires_grad_(True)
+    y = E.relu_dropout(xr, p, 3)
+    pos = x > 0
+    kept = (y[pos] != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.01, kept
+    assert torch.allclose(y[pos & (y != 0)].float(), (x[pos & (y != 0)].float() / (1 - p)), rtol=1e-2)
+    assert (y[~pos] == 0).all()
+    y.backward(torch.ones_like(y))
+    # the gradient is non-zero exactly where the output is: same mask both ways
+    assert torch.equal(xr.grad != 0, y != 0)
+    assert torch.allclose(xr.grad[y != 0].float(), torch.full_like(xr.grad[y != 0].float(), 1 / (1 - p)), rtol=1e-2)
