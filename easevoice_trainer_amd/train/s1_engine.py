@@ -25,12 +25,25 @@ class S1Engine:
                                                 end_lr=o["lr_end"], warmup_steps=o["warmup_steps"],
                                                 total_steps=o["decay_steps"])
         self.arena.zero_grad()
+        self._views = [(p, p.grad) for p in self.model.parameters()]
 
     def micro_step(self, batch: dict, batch_idx: int):
         """one micro-batch: forward_old + backward (+ optimiser step on the reference's schedule)"""
         loss, acc = self.model.forward_old(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
                                            batch["semantic_ids_len"], batch["bert_feature"])
+        # autograd keeps the produced gradient tensors (no per-parameter `grad += new` launch); they are accumulated
+        # into the flat arena with one multi-tensor add
+        for p, _v in self._views:
+            p.grad = None
         loss.backward()
+        dst, src = [], []
+        for p, v in self._views:
+            if p.grad is not None:
+                dst.append(v)
+                src.append(p.grad if p.grad.dtype == v.dtype else p.grad.to(v.dtype))
+            p.grad = v
+        if dst:
+            torch._foreach_add_(dst, src)
         stepped = False
         if batch_idx > 0 and batch_idx % 4 == 0:
             if self.reducer is not None:
