@@ -74,7 +74,18 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
                      note="late stages (C <= 64) are HBM/launch-bound, the k=7/11 convs at C >= 64 are MFMA-bound")
     else:
         r_voc = None
-    r.update(traffic=None, kernel=tag, hifigan_dec=r_voc, launches_per_step=a["calls"] / n_steps,
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; they come from the
+    # separate rocprofv3 --pmc passes recorded in profiles/r01_pmc_traffic.json (same command, same shapes)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                          "r01_pmc_traffic.json")))
+        if tag in pmc:
+            traffic = pmc[tag]["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    r.update(traffic=traffic, traffic_unit="bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate pass)",
+             kernel=tag, hifigan_dec=r_voc, launches_per_step=a["calls"] / n_steps,
              avg_launch_us=a["ms"] * 1e3 / a["calls"], ms_per_step=a["ms"] / n_steps,
              algorithmic_gflop_per_launch=a["flops"] / a["calls"] / 1e9,
              algorithmic_mb_per_launch=a["bytes"] / a["calls"] / 1e6, intensity_flop_per_byte=intensity,
