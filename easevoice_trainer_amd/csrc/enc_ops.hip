@@ -286,22 +286,34 @@ __global__ void wn_residual_bwd(const T* dx_out, const T* dacc_out, const int* l
 
 // ---- y = dropout(relu(x)) and its backward dx = dy * mult * (x > 0): the FFN inner activation of the s1 blocks
 //      (transformer.py:330-334 of the reference: linear2(dropout(relu(linear1(x))))), one pass each way ----
+// optional row mask: element index -> row = idx / C, live iff (row % rows_per_seq) < lens[row / rows_per_seq]
+__device__ __forceinline__ bool row_live(const int* lens, int rows_per_seq, int C, long elem) {
+  if (!lens) return true;
+  const long row = elem / C;
+  const long b = row / rows_per_seq;
+  return (int)(row - b * rows_per_seq) < lens[b];
+}
+
 template <typename T>
-__global__ void relu_dropout_fwd(const T* x, float p, const unsigned* seed_dev, unsigned site, T* y, long n) {
+__global__ void relu_dropout_fwd(const T* x, float p, const unsigned* seed_dev, unsigned site, const int* lens,
+                                 int rows_per_seq, int C, T* y, long n) {
   constexpr int V = 16 / sizeof(T);
   const DropCfg dc = drop_cfg(p, seed_dev, site);
   const long nv = n / V;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
     uint4 v = reinterpret_cast<const uint4*>(x)[i];
     T* h = reinterpret_cast<T*>(&v);
+    const bool live = row_live(lens, rows_per_seq, C, i * V);     // C % V == 0: a piece never straddles rows
 #pragma unroll
-    for (int e = 0; e < V; ++e) h[e] = from_f<T>(fmaxf(to_f<T>(h[e]), 0.f) * drop_mult(dc, (unsigned long)(i * V + e)));
+    for (int e = 0; e < V; ++e)
+      h[e] = from_f<T>(live ? fmaxf(to_f<T>(h[e]), 0.f) * drop_mult(dc, (unsigned long)(i * V + e)) : 0.f);
     reinterpret_cast<uint4*>(y)[i] = v;
   }
 }
 
 template <typename T>
-__global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigned* seed_dev, unsigned site, T* dx, long n) {
+__global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigned* seed_dev, unsigned site, const int* lens,
+                                 int rows_per_seq, int C, T* dx, long n) {
   constexpr int V = 16 / sizeof(T);
   const DropCfg dc = drop_cfg(p, seed_dev, site);
   const long nv = n / V;
@@ -310,9 +322,10 @@ __global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigne
     uint4 dv = reinterpret_cast<const uint4*>(dy)[i];
     const T* px = reinterpret_cast<const T*>(&xv);
     T* pd = reinterpret_cast<T*>(&dv);
+    const bool live = row_live(lens, rows_per_seq, C, i * V);
 #pragma unroll
     for (int e = 0; e < V; ++e)
-      pd[e] = from_f<T>(to_f<T>(px[e]) > 0.f ? to_f<T>(pd[e]) * drop_mult(dc, (unsigned long)(i * V + e)) : 0.f);
+      pd[e] = from_f<T>(live && to_f<T>(px[e]) > 0.f ? to_f<T>(pd[e]) * drop_mult(dc, (unsigned long)(i * V + e)) : 0.f);
     reinterpret_cast<uint4*>(dx)[i] = dv;
   }
 }
@@ -411,38 +424,40 @@ int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out,
   return evt_check_launch();
 }
 
-int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site, void* y,
-                         int64_t n, void* stream) {
+int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site,
+                         const int32_t* lens, int32_t rows_per_seq, int32_t C, void* y, int64_t n, void* stream) {
   if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
   const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (lens && (rows_per_seq <= 0 || C <= 0 || C % V)) return EVT_EINVAL;
   if (n % V || (((uintptr_t)x | (uintptr_t)y) & 15)) return EVT_EINVAL;
   long blocks = (n / V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL(relu_dropout_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, p, seed_dev, site,
-                       (bf16_t*)y, (long)n);
+                       lens, rows_per_seq, C, (bf16_t*)y, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(relu_dropout_fwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, p, seed_dev, site,
-                       (float*)y, (long)n);
+                       lens, rows_per_seq, C, (float*)y, (long)n);
   else return EVT_EINVAL;
   return evt_check_launch();
 }
 
 int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev, uint32_t site,
-                         void* dx, int64_t n, void* stream) {
+                         const int32_t* lens, int32_t rows_per_seq, int32_t C, void* dx, int64_t n, void* stream) {
   if (!x || !dy || !dx || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
   const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  if (lens && (rows_per_seq <= 0 || C <= 0 || C % V)) return EVT_EINVAL;
   if (n % V || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return EVT_EINVAL;
   long blocks = (n / V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL(relu_dropout_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       p, seed_dev, site, (bf16_t*)dx, (long)n);
+                       p, seed_dev, site, lens, rows_per_seq, C, (bf16_t*)dx, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(relu_dropout_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, p,
-                       seed_dev, site, (float*)dx, (long)n);
+                       seed_dev, site, lens, rows_per_seq, C, (float*)dx, (long)n);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

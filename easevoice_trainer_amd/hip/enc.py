@@ -200,30 +200,32 @@ def unbind_rows(t):
 
 
 class ReluDropoutFn(torch.autograd.Function):
-    """y = dropout(relu(x)) in one pass; the backward regenerates the mask and applies the relu gate in one pass"""
+    """y = dropout(relu(x)) * row_mask in one pass; the backward regenerates the mask and applies the relu gate in one
+    pass.  lens [B] int32 (or None): rows t >= lens[b] of x [B, T, C] are zeroed."""
 
     @staticmethod
-    def forward(ctx, x, p, site):
+    def forward(ctx, x, p, site, lens):
         x = x.contiguous()
         y = torch.empty_like(x)
+        rps, Cc = (x.size(-2), x.size(-1)) if lens is not None else (0, 0)
         L.check(L.lib().evt_relu_dropout_fwd(L.dt_of(x), L.ptr(x), C.c_float(p), L.ptr(rng_counter(x.device)),
-                                             C.c_uint32(site), L.ptr(y), C.c_int64(x.numel()), L.stream_ptr()),
-                "evt_relu_dropout_fwd")
-        ctx.save_for_backward(x)
-        ctx.cfg = (p, site)
+                                             C.c_uint32(site), L.ptr(lens), rps, Cc, L.ptr(y), C.c_int64(x.numel()),
+                                             L.stream_ptr()), "evt_relu_dropout_fwd")
+        ctx.save_for_backward(x, lens)
+        ctx.cfg = (p, site, rps, Cc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        p, site = ctx.cfg
+        x, lens = ctx.saved_tensors
+        p, site, rps, Cc = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         L.check(L.lib().evt_relu_dropout_bwd(L.dt_of(x), L.ptr(x), L.ptr(dy), C.c_float(p), L.ptr(rng_counter(x.device)),
-                                             C.c_uint32(site), L.ptr(dx), C.c_int64(x.numel()), L.stream_ptr()),
-                "evt_relu_dropout_bwd")
-        return dx, None, None
+                                             C.c_uint32(site), L.ptr(lens), rps, Cc, L.ptr(dx), C.c_int64(x.numel()),
+                                             L.stream_ptr()), "evt_relu_dropout_bwd")
+        return dx, None, None, None
 
 
-def relu_dropout(x, p, site):
-    return ReluDropoutFn.apply(x, float(p), int(site))
+def relu_dropout(x, p, site, lens=None):
+    return ReluDropoutFn.apply(x, float(p), int(site), lens)

@@ -15,7 +15,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import EvtConv1d
-from ..hip.enc import new_site, rel_attention, res_drop_ln
+from ..hip.enc import new_site, rel_attention, relu_dropout, res_drop_ln
 
 
 class LayerNorm(nn.Module):
@@ -44,6 +44,27 @@ class PointwiseConv(nn.Module):
         return F.linear(x, self.weight.squeeze(-1), self.bias)
 
 
+class PointwiseEvtConv(EvtConv1d):
+    """the same nn.Conv1d(cin, cout, 1) parameters (`weight` [cout, cin, 1], `bias`) on the fused HIP conv path: a
+    3200-row x 192..768-column GEMM is launch/latency-bound, the ring-pipelined k = 1 conv does it in ~10 us and its
+    weight-gradient launch also produces the bias gradient (F.linear needs dgrad + wgrad + a column-sum launch)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1)
+
+    def forward(self, x):
+        if self._slot is not None:
+            cd = self._slot.bank.dtype
+            if x.dtype != cd or not x.is_contiguous():
+                x = x.to(cd).contiguous()
+        return super().forward(x)
+
+
+def pointwise(cin, cout):
+    """1x1 conv on [B, T, C]: HIP conv when both widths are multiples of 64, a library GEMM otherwise"""
+    return PointwiseEvtConv(cin, cout) if cin % 64 == 0 and cout % 64 == 0 else PointwiseConv(cin, cout)
+
+
 class MultiHeadAttention(nn.Module):
     def __init__(self, channels, out_channels, n_heads, p_dropout=0.0, window_size=None, heads_share=True):
         super().__init__()
@@ -54,7 +75,7 @@ class MultiHeadAttention(nn.Module):
         self.conv_q = PointwiseConv(channels, channels)
         self.conv_k = PointwiseConv(channels, channels)
         self.conv_v = PointwiseConv(channels, channels)
-        self.conv_o = PointwiseConv(channels, out_channels)
+        self.conv_o = pointwise(channels, out_channels)
         self.drop = nn.Dropout(p_dropout)
         if window_size is not None:
             n_heads_rel = 1 if heads_share else n_heads
@@ -149,9 +170,15 @@ class FFN(nn.Module):
         self.conv_1 = EvtConv1d(in_channels, filter_channels, kernel_size, padding=(kernel_size - 1) // 2)
         self.conv_2 = EvtConv1d(filter_channels, out_channels, kernel_size, padding=(kernel_size - 1) // 2)
         self.drop = nn.Dropout(p_dropout)
+        self._site = new_site()
 
-    def forward(self, x, x_mask, cd, premasked=False):
-        """premasked: x is already x * x_mask in the compute dtype and the caller masks the result (Encoder)"""
+    def forward(self, x, x_mask, cd, premasked=False, lens=None):
+        """premasked: x is already x * x_mask in the compute dtype and the caller masks the result (Encoder).
+        With `lens` on the GPU the relu, the dropout and the `* x_mask` between the convs are ONE launch."""
+        if premasked and lens is not None and x.is_cuda:
+            p = self.drop.p if self.training else 0.0
+            h = relu_dropout(self.conv_1(x), p, self._site, lens)
+            return self.conv_2(h)
         if not premasked:
             x = (x * x_mask).to(cd).contiguous()
         x = self.conv_1(x, out_act=L.ACT_LRELU, out_slope=0.0)
@@ -193,6 +220,6 @@ class Encoder(nn.Module):
             n1, n2 = self.norm_layers_1[i], self.norm_layers_2[i]
             y = self.attn_layers[i](x, x, attn_mask, lens=lens).to(cd).contiguous()
             x = res_drop_ln(x, y, n1.gamma, n1.beta, lens, p, self._sites[2 * i], n1.eps)
-            y = self.ffn_layers[i](x, mask_cd, cd, premasked=True)
+            y = self.ffn_layers[i](x, mask_cd, cd, premasked=True, lens=lens)
             x = res_drop_ln(x, y, n2.gamma, n2.beta, lens, p, self._sites[2 * i + 1], n2.eps)
         return x

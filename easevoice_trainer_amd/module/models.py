@@ -23,7 +23,7 @@ from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
 from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
 from . import commons
-from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv
+from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv, pointwise
 
 LRELU_SLOPE = 0.1
 N_SYMBOLS = 732  # len(SYMBOLS), src/easevoice/text/symbols.py:410-412 (pinned by tests/easevoice/text_test.py)
@@ -189,9 +189,9 @@ class MRTE(nn.Module):
     def __init__(self, content_enc_channels=192, hidden_size=512, out_channels=192, n_heads=4):
         super().__init__()
         self.cross_attention = MultiHeadAttention(hidden_size, hidden_size, n_heads)
-        self.c_pre = PointwiseConv(content_enc_channels, hidden_size)
-        self.text_pre = PointwiseConv(content_enc_channels, hidden_size)
-        self.c_post = PointwiseConv(hidden_size, out_channels)
+        self.c_pre = pointwise(content_enc_channels, hidden_size)
+        self.text_pre = pointwise(content_enc_channels, hidden_size)
+        self.c_post = pointwise(hidden_size, out_channels)
 
     def forward(self, ssl_enc, ssl_mask, text, text_mask, ge):
         """ssl_enc [B, T, C], text [B, Tt, C], ge [B, 512] or None"""
@@ -211,13 +211,13 @@ class TextEncoder(nn.Module, _ComputeDtype):
                  latent_channels=192, version="v2"):
         super().__init__()
         self.out_channels = out_channels
-        self.ssl_proj = PointwiseConv(768, hidden_channels)
+        self.ssl_proj = pointwise(768, hidden_channels)
         self.encoder_ssl = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
         self.encoder_text = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.text_embedding = nn.Embedding(N_SYMBOLS, hidden_channels)
         self.mrte = MRTE()
         self.encoder2 = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
-        self.proj = PointwiseConv(hidden_channels, out_channels * 2)
+        self.proj = pointwise(hidden_channels, out_channels * 2)
 
     def forward(self, y, y_mask, text, text_mask, ge, y_lengths=None, text_lengths=None):
         """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]; the encoders mask their own input / output"""

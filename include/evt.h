@@ -246,11 +246,13 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
 
 /* y = dropout(relu(x)) / dx = dy * dropout multiplier * (x > 0): the FFN inner activation of the s1 transformer blocks
  * (src/easevoice/soundstorm/auto_reg/modules/transformer.py:330-334), one pass each way; mask from the counter hash
- * (seed_dev, site, element index) as in evt_res_dropout_ln_*.  n % 8 == 0 (bf16) / % 4 (fp32), 16-byte aligned. */
-int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site, void* y,
-                         int64_t n, void* stream);
+ * (seed_dev, site, element index) as in evt_res_dropout_ln_*.  n % 8 == 0 (bf16) / % 4 (fp32), 16-byte aligned.
+ * With lens != NULL the tensor is [.., rows_per_seq, C] and rows t >= lens[b] are zeroed (the `* x_mask` of the s2
+ * encoder FFN, attentions.py:408-416); lens == NULL: no mask. */
+int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site,
+                         const int32_t* lens, int32_t rows_per_seq, int32_t C, void* y, int64_t n, void* stream);
 int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev, uint32_t site,
-                         void* dx, int64_t n, void* stream);
+                         const int32_t* lens, int32_t rows_per_seq, int32_t C, void* dx, int64_t n, void* stream);
 
 /* WN layer glue (src/easevoice/module/modules.py:199-211): rs = res_skip_layer(acts), [rows][2H] (H when last):
  *   last == 0:  x_out = (x + rs[:, :H]) * row_mask ;  acc_out = acc + rs[:, H:]     (acc may be NULL = zeros)
