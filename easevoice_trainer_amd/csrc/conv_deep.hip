@@ -159,6 +159,124 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// conv_deep32: the same 128 x 128 LDS-DMA GEMM with K stages of ONE tap x 32 channels (64-byte tile rows).  Half the LDS
+// per stage (2 x 16 KiB per block) doubles the resident blocks per CU: the PMC profile of conv_deep showed a third of the
+// wave cycles parked at the stage barrier waiting for the DMA -- more resident waves cover that, and K-side widths that
+// are multiples of 32 but not of 64 (32, 96) become eligible.  Swizzle for 64-byte rows: slot ^= 2*((row>>3)&1).
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int STAGE32 = (BM + BN) * 64;   // 16 KiB
+
+__global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int yi = slot % p.Y;
+  const int pb = xcd + 8 * (slot / p.Y);
+  if (pb >= p.P) return;
+  const int phase = blockIdx.y;
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const int total_units = p.nseq * p.Q;
+
+  // wave w stages rows [32w, 32w+32) of both tiles, 16 rows x 4 slots per instruction
+  const int rsub = lane >> 2, pslot = lane & 3;
+  long aoff[2], boff[2];
+  int brow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 32 + i * 16 + rsub;
+    const int c = pslot ^ (2 * ((row >> 3) & 1));
+    aoff[i] = (long)(yi * BM + row) * p.nchunk * p.KHp * 32 + c * 8;
+    const int u = pb * BN + row;
+    const bool ok = u < total_units;
+    const int seq = ok ? u / p.Q : 0;
+    const int q = ok ? u - seq * p.Q : 0;
+    brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
+    boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
+  }
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  unsigned char* my_a = smem + wave * 32 * 64;
+  unsigned char* my_b = smem + BM * 64 + wave * 32 * 64;
+  const int nst = p.nchunk * p.KHp;
+
+  auto issue = [&](int st, int buf) {
+    const int ch = st / p.KHp, tap = st - ch * p.KHp;
+    const long wsoff = ((long)ch * p.KHp + tap) * 32;
+    const int rshift = tap * p.dil;
+    const long xsoff = (long)rshift * p.Cin + ch * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(W + aoff[i] + wsoff, my_a + buf * STAGE32 + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (unsigned)(brow[i] + rshift) < (unsigned)p.Lin;
+      glds16(ok ? X + boff[i] + xsoff : zsrc, my_b + buf * STAGE32 + i * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int so = ((g ^ (2 * ((n >> 3) & 1))) * 16);
+  const int a_base = (wr * 64 + n) * 64 + so;
+  const int b_base = BM * 64 + (wc * 64 + n) * 64 + so;
+
+  issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    __syncthreads();
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    const unsigned char* sa = smem + buf * STAGE32 + a_base;
+    const unsigned char* sb = smem + buf * STAGE32 + b_base;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+
+  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
+  const bf16_t* Gt = reinterpret_cast<const bf16_t*>(p.gate);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int u = pb * BN + wc * 64 + j * 16 + n;
+    if (u >= total_units) continue;
+    const int seq = u / p.Q;
+    const int q = u - seq * p.Q;
+    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
+    if (orow < 0 || orow >= p.Lout) continue;
+    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = yi * BM + wr * 64 + i * 16 + g * 4;
+      const long off = rbase + co;
+      bf16_t outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co + r];
+        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
+        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
+        if (Gt) v *= (bf2f(Gt[off + r]) > 0.f ? 1.f : p.gate_slope);
+        if (R) v += bf2f(R[off + r]);
+        outv[r] = f2bf(v);
+      }
+      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // conv_ring<MT, NT, NS>: the same LDS-DMA implicit GEMM with a smaller block tile (32*MT x 32*NT, 2 x 2 waves of
 // 16*MT x 16*NT) and an NS-deep ring of K stages for the LATENCY-bound layers: WN in/res_skip convs and the FFN convs of
 // the encoders are 3200-position problems with 6..24 K stages -- with one stage in flight every stage costs a full
@@ -965,7 +1083,7 @@ bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) 
 // which tile: 2 = 128 x 128 (conv_deep), 1 = 64 x 64 ring (conv_ring<2,2,4>), 0 = not eligible
 static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
   if (dtype != EVT_DT_BF16) return 0;
-  if (k_ch % BK || out_ch % 64) return 0;
+  if (k_ch % 32 || out_ch % 64) return 0;
   if (p.xact || p.in_slope != 1.f) return 0;              // no load-side fusion on the DMA path
   if (p.nchunk * 32 != k_ch) return 0;                     // prepared image must be the ck = 32 layout
   if ((long)p.nseq * p.Q >= (1L << 31) - BN) return 0;
@@ -973,7 +1091,7 @@ static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
   static const long min128 = getenv("EVT_DEEP_MIN_TILES") ? atol(getenv("EVT_DEEP_MIN_TILES")) : 192;   // tuning knob
   if (out_ch % BM == 0 && ((units + BN - 1) / BN) * (out_ch / BM) * nphase >= min128) return 2;
   static const bool no_ring = getenv("EVT_NO_RING") != nullptr;   // A/B switch for measurements
-  if (!no_ring && ((units + 63) / 64) * (out_ch / 64) * nphase >= 32) return 1;
+  if (!no_ring && k_ch % BK == 0 && ((units + 63) / 64) * (out_ch / 64) * nphase >= 32) return 1;
   return 0;
 }
 
@@ -1001,6 +1119,23 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
   p.Y = out_ch / BM;
   p.P = (int)(((long)p.nseq * p.Q + BN - 1) / BN);
   p.U = 0;
+  // short reductions (<= 12 stages of 64) and K-side widths that are not multiples of 64: 32-channel stages, twice the
+  // resident blocks (measured: 128->512 k5 s3 49 -> 37 us; the 40-80-stage 1024-wide layers are better with 64)
+  static const int deep32 = getenv("EVT_DEEP32") ? atoi(getenv("EVT_DEEP32")) : -1;   // A/B switch: 0 never, 1 always
+  const bool short_k = (k_ch / 64) * p.KHp <= 12;
+  if (deep32 == 1 || k_ch % 64 || (deep32 != 0 && short_k)) {
+    static bool attr32 = false;
+    const size_t lds32 = 2 * STAGE32;
+    if (!attr32) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_deep32), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds32) != hipSuccess)
+        return EVT_ELAUNCH;
+      attr32 = true;
+    }
+    evt_set_last_tag("conv_deep<bf16, 128, 128, 32>");
+    hipLaunchKernelGGL(conv_deep32, dim3(8 * ((p.P + 7) / 8) * p.Y, nphase), dim3(256), lds32, st, p);
+    return evt_check_launch();
+  }
   static bool attr = false;
   const size_t lds = 2 * STAGE_BYTES;
   if (!attr) {
