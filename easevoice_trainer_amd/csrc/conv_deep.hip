@@ -287,6 +287,15 @@ __global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
 //     into the freed buffer  ->  fragment reads + MFMAs of stage s
 // -----------------------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `ahead` groups of G DMA instructions are still in flight (ahead <= MAXA, wave-uniform)
+template <int G, int MAXA>
+__device__ __forceinline__ void wait_groups(int ahead) {
+  if constexpr (MAXA <= 0) { wait_vmcnt<0>(); }
+  else {
+    if (ahead >= MAXA) wait_vmcnt<(MAXA * G > 63 ? 63 : MAXA * G)>();
+    else wait_groups<G, MAXA - 1>(ahead);
+  }
+}
 
 template <int MT, int NT, int NS>
 __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
@@ -367,9 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
   for (int st = 0; st < nst; ++st) {
     // groups still allowed in flight after stage st has landed: stages st+1 .. st+NS-2 that exist
     const int ahead = min(NS - 2, nst - 1 - st);
-    if (ahead >= 2) wait_vmcnt<2 * G>();
-    else if (ahead == 1) wait_vmcnt<G>();
-    else wait_vmcnt<0>();
+    wait_groups<G, NS - 2>(ahead);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (st + NS - 1 < nst) issue(st + NS - 1);
@@ -1024,9 +1031,7 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
     if (s < nst) issue(s);
   for (int s = 0; s < nst; ++s) {
     const int ahead = min(NS - 2, nst - 1 - s);
-    if (ahead >= 2) wait_vmcnt<2 * G>();
-    else if (ahead == 1) wait_vmcnt<G>();
-    else wait_vmcnt<0>();
+    wait_groups<G, NS - 2>(ahead);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + NS - 1 < nst) issue(s + NS - 1);
@@ -1100,10 +1105,12 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
   const int kind = deep_kind(p, EVT_DT_BF16, out_ch, k_ch, nphase);
   if (kind == 0) return EVT_ENOTSUP;
   if (kind == 1) {
-    constexpr int NS = 4;
     p.Y = out_ch / 64;
     p.P = (int)(((long)p.nseq * p.Q + 63) / 64);
     p.U = 0;
+    // 4 stages: 6 / 8 stages were measured no faster (the 3-36-stage chains cost 0.25-0.5 us per stage; ~10 us of every
+    // launch is fixed cost) and leave room for only one block per CU
+    constexpr int NS = 4;
     static bool attr1 = false;
     const size_t lds1 = (size_t)NS * (64 + 64) * 128;
     if (!attr1) {
