@@ -984,8 +984,15 @@ int launch_igemm_mt(const ConvP& p, int MT, int NT, int nphase, bool split, hipS
 // Generic igemm launch.  A = output channels, B = K-side channels.
 int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st, bool allow_deep) {
   if (A % 16 || B % 16) return EVT_ENOTSUP;
-  if (allow_deep && evt_conv::deep_eligible(p, dtype, A, B, nphase)) return evt_conv::launch_conv_deep(p, A, B, nphase, st);
-  if (allow_deep && evt_conv::narrow_eligible(p, dtype, A, B, nphase)) return evt_conv::launch_conv_narrow(p, A, B, nphase, st);
+  // specialised paths first; EVT_ENOTSUP from one of them means "not this shape after all": fall through to the generic kernel
+  if (allow_deep && evt_conv::deep_eligible(p, dtype, A, B, nphase)) {
+    const int rc = evt_conv::launch_conv_deep(p, A, B, nphase, st);
+    if (rc != EVT_ENOTSUP) return rc;
+  }
+  if (allow_deep && evt_conv::narrow_eligible(p, dtype, A, B, nphase)) {
+    const int rc = evt_conv::launch_conv_narrow(p, A, B, nphase, st);
+    if (rc != EVT_ENOTSUP) return rc;
+  }
   const int CK = (B % 32 == 0) ? 32 : 16;
   const int MT = (A % 64 == 0) ? 4 : (A % 32 == 0 ? 2 : 1);
   p.Y = A / (16 * MT);

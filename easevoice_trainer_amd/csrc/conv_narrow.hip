@@ -168,6 +168,8 @@ bool narrow_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
   const int nk = (p.KHp * k_ch + 31) / 32;
   if (k_ch == 16 && nk != 2 && nk != 4 && nk != 6) return false;   // k = 3(4) / 7(8) / 11(12) taps
   if (k_ch == 32 && nk != 3 && nk != 7) return false;              // k = 11 at C = 32 (88 fragment registers) measured slower
+  const int region_rows = 63 + (nk * 32 / k_ch - 1) * p.dil + 1;
+  if (region_rows * (k_ch * 2 / 16) > 64 * 8) return false;       // prefetch registers of one wave
   return (long)p.nseq * p.Q >= 4096;
 }
 
