@@ -184,34 +184,89 @@ __global__ void gated_bwd_kernel(const T* xin, const T* g, const T* dacts, T* dx
 }
 
 // ---- fused loss reductions over a table of segments ------------------------------------------------
-template <typename T, int MODE>  // MODE 0: |a-b| ; 1: (target-a)^2
-__global__ __launch_bounds__(256) void seg_reduce_fwd(const evt_seg* segs, float target, float* out) {
-  __shared__ float red[4];
-  const evt_seg s = segs[blockIdx.y];
-  const T* a = reinterpret_cast<const T*>(s.a);
-  const T* b = reinterpret_cast<const T*>(s.b);
-  float acc = 0.f;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < s.n; i += (long)gridDim.x * 256) {
-    if (MODE == 0) acc += fabsf(to_f<T>(a[i]) - to_f<T>(b[i]));
-    else { const float d = target - to_f<T>(a[i]); acc += d * d; }
-  }
-  acc = block_reduce_sum_256(acc, red);
-  if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc * s.scale);
-}
+// The segments (37 feature maps from 10 K to 21 M elements) are treated as ONE flat index space split evenly over the
+// blocks: a block walks the part of each segment that falls into its range with 16-byte loads and finishes with a
+// single atomic (the first version launched 64 blocks per segment and paid ~2400 same-address atomics, ~46 ns each).
+constexpr int SEG_MAX = 64;
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void seg_reduce_bwd(const evt_seg* segs, float target, const float* dloss) {
-  const evt_seg s = segs[blockIdx.y];
-  if (!s.da) return;
-  const T* a = reinterpret_cast<const T*>(s.a);
-  const T* b = reinterpret_cast<const T*>(s.b);
-  T* da = reinterpret_cast<T*>(s.da);
-  const float dl = dloss[0] * s.scale;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < s.n; i += (long)gridDim.x * 256) {
-    float gv;
-    if (MODE == 0) { const float d = to_f<T>(a[i]) - to_f<T>(b[i]); gv = d > 0.f ? dl : (d < 0.f ? -dl : 0.f); }
-    else gv = -2.f * (target - to_f<T>(a[i])) * dl;
-    da[i] = from_f<T>(gv);
+__device__ __forceinline__ float seg_term(float a, float b, float target) {
+  if (MODE == 0) return fabsf(a - b);
+  const float d = target - a;
+  return d * d;
+}
+template <typename T, int MODE>
+__device__ __forceinline__ float seg_grad(float a, float b, float target, float dl) {
+  if (MODE == 0) { const float d = a - b; return d > 0.f ? dl : (d < 0.f ? -dl : 0.f); }
+  return -2.f * (target - a) * dl;
+}
+
+template <typename T, int MODE, bool BWD>
+__global__ __launch_bounds__(256) void seg_flat_kernel(const evt_seg* segs, int nseg, float target, float* out,
+                                                       const float* dloss) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ float red[4];
+  __shared__ long pre[SEG_MAX + 1];
+  if (threadIdx.x == 0) {
+    long acc = 0;
+    for (int i = 0; i < nseg; ++i) { pre[i] = acc; acc += segs[i].n; }
+    pre[nseg] = acc;
+  }
+  __syncthreads();
+  const long total = pre[nseg];
+  long chunk = (total + gridDim.x - 1) / gridDim.x;
+  chunk = (chunk + 2047) / 2048 * 2048;
+  const long lo = (long)blockIdx.x * chunk, hi = min(total, lo + chunk);
+  float acc = 0.f;
+  for (int si = 0; si < nseg; ++si) {
+    const long s0 = pre[si], s1 = pre[si + 1];
+    if (s1 <= lo || s0 >= hi) continue;
+    const evt_seg s = segs[si];
+    if (BWD && !s.da) continue;
+    const T* a = reinterpret_cast<const T*>(s.a);
+    const T* b = reinterpret_cast<const T*>(s.b);
+    T* da = reinterpret_cast<T*>(s.da);
+    const long i0 = max(lo, s0) - s0, i1 = min(hi, s1) - s0;      // element range inside this segment
+    const float dl = BWD ? dloss[0] * s.scale : 0.f;
+    float part = 0.f;
+    // head up to the next multiple of V, vector body, tail
+    const long v0 = min(i1, (i0 + V - 1) / V * V), v1 = v0 + (i1 - v0) / V * V;
+    const bool vec_ok = ((((uintptr_t)a) | (MODE == 0 ? (uintptr_t)b : 0) | (BWD ? (uintptr_t)da : 0)) & 15) == 0;
+    if (vec_ok) {
+      for (long i = i0 + threadIdx.x; i < v0; i += 256) {
+        const float av = to_f<T>(a[i]), bv = MODE == 0 ? to_f<T>(b[i]) : 0.f;
+        if (BWD) da[i] = from_f<T>(seg_grad<T, MODE>(av, bv, target, dl)); else part += seg_term<T, MODE>(av, bv, target);
+      }
+      for (long i = v0 + (long)threadIdx.x * V; i < v1; i += 256L * V) {
+        const uint4 va = *reinterpret_cast<const uint4*>(a + i);
+        uint4 vb = make_uint4(0, 0, 0, 0);
+        if (MODE == 0) vb = *reinterpret_cast<const uint4*>(b + i);
+        const T* pa = reinterpret_cast<const T*>(&va);
+        const T* pb = reinterpret_cast<const T*>(&vb);
+        uint4 vo;
+        T* po = reinterpret_cast<T*>(&vo);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float av = to_f<T>(pa[e]), bv = MODE == 0 ? to_f<T>(pb[e]) : 0.f;
+          if (BWD) po[e] = from_f<T>(seg_grad<T, MODE>(av, bv, target, dl)); else part += seg_term<T, MODE>(av, bv, target);
+        }
+        if (BWD) *reinterpret_cast<uint4*>(da + i) = vo;
+      }
+      for (long i = v1 + threadIdx.x; i < i1; i += 256) {
+        const float av = to_f<T>(a[i]), bv = MODE == 0 ? to_f<T>(b[i]) : 0.f;
+        if (BWD) da[i] = from_f<T>(seg_grad<T, MODE>(av, bv, target, dl)); else part += seg_term<T, MODE>(av, bv, target);
+      }
+    } else {
+      for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float av = to_f<T>(a[i]), bv = MODE == 0 ? to_f<T>(b[i]) : 0.f;
+        if (BWD) da[i] = from_f<T>(seg_grad<T, MODE>(av, bv, target, dl)); else part += seg_term<T, MODE>(av, bv, target);
+      }
+    }
+    acc += part * s.scale;
+  }
+  if (!BWD) {
+    acc = block_reduce_sum_256(acc, red);
+    if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc);
   }
 }
 
@@ -382,36 +437,39 @@ int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void*
   return evt_check_launch();
 }
 
-#define SEG_LAUNCH(KERN, MODE, ...)                                                                              \
-  do {                                                                                                           \
-    if (dtype == EVT_DT_BF16) hipLaunchKernelGGL((KERN<bf16_t, MODE>), dim3(64, nseg), dim3(256), 0, st, __VA_ARGS__); \
-    else if (dtype == EVT_DT_F32) hipLaunchKernelGGL((KERN<float, MODE>), dim3(64, nseg), dim3(256), 0, st, __VA_ARGS__); \
-    else return EVT_EINVAL;                                                                                      \
+#define SEG_LAUNCH(MODE, BWD, TARGET, OUT, DLOSS)                                                                   \
+  do {                                                                                                             \
+    if (nseg > SEG_MAX) return EVT_ENOTSUP;                                                                        \
+    if (dtype == EVT_DT_BF16)                                                                                      \
+      hipLaunchKernelGGL((seg_flat_kernel<bf16_t, MODE, BWD>), dim3(512), dim3(256), 0, st, segs, nseg, TARGET, OUT, DLOSS); \
+    else if (dtype == EVT_DT_F32)                                                                                  \
+      hipLaunchKernelGGL((seg_flat_kernel<float, MODE, BWD>), dim3(512), dim3(256), 0, st, segs, nseg, TARGET, OUT, DLOSS);  \
+    else return EVT_EINVAL;                                                                                        \
   } while (0)
 
 int evt_l1_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float* out, void* stream) {
   if (!segs || nseg <= 0 || !out) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  SEG_LAUNCH(seg_reduce_fwd, 0, segs, 0.f, out);
+  SEG_LAUNCH(0, false, 0.f, out, (const float*)nullptr);
   return evt_check_launch();
 }
 int evt_l1_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, const float* dloss, void* stream) {
   if (!segs || nseg <= 0 || !dloss) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  SEG_LAUNCH(seg_reduce_bwd, 0, segs, 0.f, dloss);
+  SEG_LAUNCH(0, true, 0.f, (float*)nullptr, dloss);
   return evt_check_launch();
 }
 int evt_lsgan_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, float* out, void* stream) {
   if (!segs || nseg <= 0 || !out) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  SEG_LAUNCH(seg_reduce_fwd, 1, segs, target, out);
+  SEG_LAUNCH(1, false, target, out, (const float*)nullptr);
   return evt_check_launch();
 }
 int evt_lsgan_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, const float* dloss,
                         void* stream) {
   if (!segs || nseg <= 0 || !dloss) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  SEG_LAUNCH(seg_reduce_bwd, 1, segs, target, dloss);
+  SEG_LAUNCH(1, true, target, (float*)nullptr, dloss);
   return evt_check_launch();
 }
 
