@@ -30,6 +30,7 @@ class ParamArena:
             offs[n] = total
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = total
+        self.updates = 0          # bumped by every optimiser launch on this arena (raw-pointer writes torch cannot see)
         self.param = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.offsets = offs
@@ -104,6 +105,7 @@ class FlatAdamW:
         self.step_count += 1
         tab, nseg = self._segments()
         a = self.arena
+        a.updates += 1
         L.check(L.lib().evt_adamw_flat_dev(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                            C.c_int64(a.numel), L.ptr(tab), nseg, C.c_float(self.betas[0]),
                                            C.c_float(self.betas[1]), C.c_float(self.eps), L.ptr(self._step_dev),
@@ -112,6 +114,7 @@ class FlatAdamW:
     def note_replayed_step(self):
         """a captured graph ran the update: keep the python-side counter (checkpoints) in step with the device one"""
         self.step_count += 1
+        self.arena.updates += 1
 
     # ---- torch.optim-compatible checkpoint surface (src/utils/path/ckpt.py:78-93 stores optimizer.state_dict()) ----
     def state_dict(self):
@@ -161,6 +164,7 @@ class ModelRuntime:
             if hasattr(m, "cd"):
                 m.cd = dtype
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._fold_stamp = None
         # Parameters whose gradient comes from autograd (linears, norms, embeddings -- everything that is not a fused
         # conv): autograd's AccumulateGrad would run one `grad += new` launch per parameter per backward (~420 tiny
         # launches in the s2 generator).  Instead their .grad is detached from the arena during the backward (autograd
@@ -177,8 +181,16 @@ class ModelRuntime:
         for p, _view in self._free:
             p.grad = None
 
-    def prepare(self):
-        self.bank.fold()
+    def prepare(self, force: bool = False):
+        """fold the prepared conv weight images -- only when the parameters changed since the last fold: an optimiser
+        step of this arena (FlatAdamW bumps `arena.updates`) or an in-place write that torch versions (load_state_dict,
+        broadcast).  The discriminator is refolded right after its update for the generator step, so the fold at the
+        top of the next step would rebuild identical images."""
+        a = self.arena
+        stamp = (a.updates, a.param._version)
+        if force or stamp != self._fold_stamp:
+            self.bank.fold()
+            self._fold_stamp = stamp
 
     def finish_grads(self):
         self.bank.grads()
