@@ -67,6 +67,9 @@ def main():
     shapes.append(("FFN 768->192 k3 T200", B, 200, 768, 192, 3, 1, 1, 1, 1, False, 1.0, 0))
     shapes.append(("FFN 192->768 k3 T60", B, 60, 192, 768, 3, 1, 1, 1, 1, False, 1.0, 1))
     shapes.append(("FFN 768->192 k3 T60", B, 60, 768, 192, 3, 1, 1, 1, 1, False, 1.0, 0))
+    # the s1 transformer's Linear layers as k = 1 convolutions over [32, 1024, C] (what-if: GEMMs on the conv kernels)
+    for ci, co in [(512, 1536), (512, 512), (512, 2048), (2048, 512)]:
+        shapes.append((f"s1 lin {ci}->{co}", 32, 1024, ci, co, 1, 1, 0, 1, 1, False, 1.0, 0))
     shapes.append(("conv_post 16->1 k7", B, 20480, 16, 1, 7, 1, 3, 1, 1, False, 0.01, 2))
 
     if a.only:

@@ -1,0 +1,40 @@
+"""Summarise a rocprofv3 --pmc counter_collection.csv per kernel: sums of every counter, dispatch count and the MFMA
+utilisation the way rocprof's derived MfmaUtil defines it:  sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) * 1024 SIMDs).
+
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES \
+              --kernel-trace --output-format csv -d DIR -- python bench.py ...
+    python tools/pmc_summary.py DIR/.../*_counter_collection.csv [substring ...]
+"""
+import collections
+import csv
+import sys
+
+
+def main():
+    path, pats = sys.argv[1], sys.argv[2:]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if pats and not any(p in k for p in pats):
+            continue
+        k = k[:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+    order = sorted(agg, key=lambda k: -agg[k].get("GRBM_GUI_ACTIVE", 0.0))
+    for k in order[:30]:
+        v = agg[k]
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        line = f"{k:70s} dispatches {len(disp[k]):5d}"
+        if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            line += f"  MfmaUtil {100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024):5.1f}%"
+        if gui and "SQ_ACTIVE_INST_VALU" in v:
+            line += f"  VALU-issue {100 * v['SQ_ACTIVE_INST_VALU'] / (gui * 1024):5.1f}%"
+        if "SQ_WAVE_CYCLES" in v and gui:
+            line += f"  waves/SIMD {v['SQ_WAVE_CYCLES'] / (gui * 1024):4.2f}"
+        print(line)
+        print("      " + "  ".join(f"{c}={x:.3g}" for c, x in sorted(v.items())))
+
+
+if __name__ == "__main__":
+    main()
