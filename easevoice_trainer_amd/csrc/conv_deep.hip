@@ -1162,6 +1162,7 @@ bool wgrad_deep_eligible(const WgP& p, int dtype) {
   if (p.CA % 128 || p.CB % 32) return false;
   if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
   if (p.LA != p.Q) return false;                            // A rows are addressed by the flat position
+  if (p.KHp < 3) return false;                              // 5-tap tiles: k = 1 / 2 layers go to wgrad_ring<., 1, .>
   if ((long)p.nseq * p.Q >= (1L << 31) - WPOS) return false;
   // worth it only for GEMM-sized problems: enough (A tile, chunk) pairs and enough positions
   const long tiles = (long)(p.CA / 128) * (p.CB / 32) * ((p.KHp + WKT - 1) / WKT);
