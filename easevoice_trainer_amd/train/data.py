@@ -1,9 +1,8 @@
 """Batch sources for the trainers.
 
-The reference's on-disk readers (src/easevoice/module/data_utils.py, soundstorm/auto_reg/data/*) depend on the text
-front-end and ffmpeg and are SURVEY §8(f) N1 ("next").  The trainers here take any iterable of batches with the
-reference's collate layout; two sources ship: fixed-shape synthetic batches and a tensor bundle
-(`torch.save` of a list of batch tuples) for pre-extracted features."""
+The trainers take any iterable of batches with the reference's collate layout.  Three sources ship: the readers of the
+reference's feature directories (dataset.py), fixed-shape synthetic batches and a
+tensor bundle (`torch.save` of a list of batch tuples) for pre-collated features."""
 import os
 
 import torch
@@ -83,13 +82,21 @@ class TensorBundle:
                 yield tuple(t.to(self.device) for t in b)
 
 
-def open_source(kind, train_input_dir, device, synthetic_factory):
+def open_source(kind, train_input_dir, device, synthetic_factory, batch_size=None, cfg=None, rank=0, world=1):
+    """Batch source of a trainer, in this order: a tensor bundle `evt_<kind>_batches.pt`, fixed-shape synthetic batches
+    when EVT_SYNTHETIC_STEPS is set, else the reference's feature directory (dataset.py: 2-name2text.txt with
+    4-cnhubert + 5-wav32k for s2, with 6-name2semantic.tsv + 3-bert for s1)."""
     bundle = os.path.join(train_input_dir or "", f"evt_{kind}_batches.pt")
     if train_input_dir and os.path.isfile(bundle):
         return TensorBundle(bundle, device)
     if os.environ.get("EVT_SYNTHETIC_STEPS"):
         return synthetic_factory(int(os.environ["EVT_SYNTHETIC_STEPS"]))
+    marker = os.path.join(train_input_dir or "", "5-wav32k" if kind == "s2" else "6-name2semantic.tsv")
+    if train_input_dir and os.path.exists(marker):
+        from .dataset import S1Reader, S2Reader
+
+        reader = S2Reader if kind == "s2" else S1Reader
+        return reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world)
     raise FileNotFoundError(
-        f"{bundle} not found.  The reader of the reference's raw feature directories (2-name2text.txt, 4-cnhubert, "
-        "5-wav32k, 6-name2semantic.tsv) is SURVEY §8(f) N1 and not part of this round; provide a tensor bundle or set "
-        "EVT_SYNTHETIC_STEPS=<n> for fixed-shape synthetic batches.")
+        f"no training input under {train_input_dir!r}: expected the reference's feature directory ({marker}), a tensor "
+        f"bundle {bundle}, or EVT_SYNTHETIC_STEPS=<n> for fixed-shape synthetic batches")

@@ -1,0 +1,544 @@
+"""Readers of the reference's on-disk training features: the two callers that feed the hot path.
+
+  s2: <exp_dir>/2-name2text.txt + 4-cnhubert/<name>.pt + 5-wav32k/<name>   src/easevoice/module/data_utils.py:14-323
+  s1: <exp_dir>/2-name2text.txt + 6-name2semantic.tsv + 3-bert/<name>.pt  soundstorm/auto_reg/data/dataset.py:38-271,
+                                                                           bucket_sampler.py:29-170, data_module.py:42-54
+
+What is kept bit-for-bit: the item filters, the <100-item repetition rule, the seeded shuffles, the bucket samplers'
+batch composition for every (epoch, rank, world), the collate layouts and padding rules, the placeholder item on a read
+failure.  What is laid out differently: files are read and collated by a host thread into pinned buffers a few batches
+ahead of the step, and the per-item linear spectrogram runs on the GPU through the HIP STFT (`spectrogram_torch`) after
+the copy instead of in DataLoader workers -- the 5-wav32k files are 16-bit PCM at the training rate, so the reference's
+ffmpeg subprocess (src/utils/audio/__init__.py:13-32) reduces to a RIFF parse and a scale by 1/32768.
+
+The phoneme table is data of the reference's text front-end (src/easevoice/text/symbols.py) and is not restated here:
+it is read from `symbols.json` (see tools/dump_symbols.py) or imported from a reference checkout on sys.path."""
+import json
+import math
+import os
+import queue
+import random
+import struct
+import threading
+import traceback
+
+import numpy as np
+import torch
+
+S2_BUCKET_BOUNDARIES = [32] + list(range(300, 2000, 100))  # src/train/sovits.py:233-253
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# phoneme table
+# ---------------------------------------------------------------------------------------------------------------------
+def load_symbol_table(exp_dir=None):
+    """symbol -> id map of `cleaned_text_to_sequence` (src/easevoice/text/__init__.py:4-13).
+
+    Looked up in: $EVT_SYMBOLS_JSON, <exp_dir>/symbols.json (a JSON list, index == id), then the reference package
+    itself when this runs inside a reference checkout."""
+    for path in (os.environ.get("EVT_SYMBOLS_JSON"), os.path.join(exp_dir, "symbols.json") if exp_dir else None):
+        if path and os.path.isfile(path):
+            with open(path, "r", encoding="utf8") as f:
+                symbols = json.load(f)
+            return {s: i for i, s in enumerate(symbols)}
+    try:
+        from src.easevoice.text.symbols import SYMBOLS_TO_ID  # noqa: reference checkout on sys.path (drop-in use)
+
+        return dict(SYMBOLS_TO_ID)
+    except Exception as e:
+        raise FileNotFoundError(
+            "phoneme table not found: set EVT_SYMBOLS_JSON or put symbols.json (tools/dump_symbols.py) next to the "
+            "feature directories, or run inside a reference checkout where src.easevoice.text is importable") from e
+
+
+def read_name2text(path):
+    """{name: [phones, word2ph, text]} from 2-name2text.txt; lines without exactly 4 tab fields are dropped
+    (data_utils.py:31-39, dataset.py:67-75)."""
+    with open(path, "r", encoding="utf8") as f:
+        lines = f.read().strip("\n").split("\n")
+    table = {}
+    for line in lines:
+        tmp = line.split("\t")
+        if len(tmp) != 4:
+            continue
+        table[tmp[0]] = [tmp[1], tmp[2], tmp[3]]
+    return table
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 5-wav32k reader
+# ---------------------------------------------------------------------------------------------------------------------
+def read_wav_pcm16(path, sampling_rate):
+    """float32 mono samples in [-1, 1) of a RIFF/WAVE PCM16 file whose rate is already `sampling_rate`.
+
+    Equals what load_audio (src/utils/audio/__init__.py:13-32: ffmpeg -> f32le, ac=1, ar=sr) returns for the files the
+    reference's normalisation step writes into 5-wav32k: no resampling happens there and s16 -> f32 is x/32768.  Other
+    encodings or rates raise (the caller turns that into the reference's placeholder item)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        cid, size = blob[pos:pos + 4], struct.unpack_from("<I", blob, pos + 4)[0]
+        body = blob[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack_from("<HHIIHH", body, 0)
+        elif cid == b"data":
+            data = body
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, channels, rate, _, _, bits = fmt
+    if tag not in (1, 0xFFFE) or bits != 16:
+        raise ValueError(f"{path}: only 16-bit PCM is supported (format {tag}, {bits} bits)")
+    if rate != sampling_rate:
+        raise ValueError(f"{path}: sample rate {rate} != {sampling_rate} (5-wav32k is written at the training rate)")
+    pcm = np.frombuffer(data[:len(data) // (2 * channels) * 2 * channels], dtype="<i2")
+    x = pcm.astype(np.float32) * np.float32(1.0 / 32768.0)
+    if channels > 1:
+        x = x.reshape(-1, channels).mean(axis=1, dtype=np.float32)
+    return x
+
+
+def spec_frames(wav_len, n_fft, hop):
+    """frame count of spectrogram_torch(center=False) with its (n_fft-hop)/2 reflect pad, mel_processing.py:50-66"""
+    return (wav_len + 2 * ((n_fft - hop) // 2) - n_fft) // hop + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# s2: TextAudioSpeakerLoader / TextAudioSpeakerCollate / DistributedBucketSampler
+# ---------------------------------------------------------------------------------------------------------------------
+class S2FeatureDir:
+    """Item index of an s2 feature directory, data_utils.py:21-99.
+
+    The reference lists the usable names as `list(set & set & set)`, whose order changes with the interpreter's string
+    hash seed; here the names are sorted first, so the seeded shuffle that follows gives one order on every rank and
+    every run.  `items` = [name, phoneme_ids], `lengths` = file_size // (2*hop) (header bytes included, as there)."""
+
+    def __init__(self, exp_dir, data_cfg, val=False, symbol_to_id=None):
+        self.path2 = "%s/2-name2text.txt" % exp_dir
+        self.path4 = "%s/4-cnhubert" % exp_dir
+        self.path5 = "%s/5-wav32k" % exp_dir
+        for p in (self.path2, self.path4, self.path5):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        self.sampling_rate, self.filter_length = data_cfg["sampling_rate"], data_cfg["filter_length"]
+        self.hop_length, self.win_length = data_cfg["hop_length"], data_cfg["win_length"]
+        self.val = val
+        sym = symbol_to_id if symbol_to_id is not None else load_symbol_table(exp_dir)
+        names4 = {n[:-3] for n in os.listdir(self.path4)}
+        names5 = set(os.listdir(self.path5))
+        phoneme_data = read_name2text(self.path2)
+        names = sorted(set(phoneme_data) & names4 & names5)
+        if len(names) == 0:
+            raise ValueError(f"data in {exp_dir} is all skipped, please check the data")
+        if len(names) < 100:
+            names = names * max(2, int(100 / len(names)))
+        random.Random(1234).shuffle(names)
+        self.items, self.lengths = [], []
+        self.skipped_phone = self.skipped_dur = 0
+        for name in names:
+            try:
+                ids = [sym[p] for p in phoneme_data[name][0].split(" ")]
+            except KeyError:
+                self.skipped_phone += 1
+                continue
+            size = os.path.getsize("%s/%s" % (self.path5, name))
+            duration = size / self.sampling_rate / 2
+            if duration == 0:
+                self.skipped_dur += 1
+                continue
+            if 54 > duration > 0.6 or val:
+                self.items.append([name, ids])
+                self.lengths.append(size // (2 * self.hop_length))
+            else:
+                self.skipped_dur += 1
+        if len(self.items) <= 1:
+            raise ValueError(f"data in {exp_dir} is all skipped, please check the data")
+
+    def __len__(self):
+        return len(self.items)
+
+    def load(self, index):
+        """(ssl [1,768,T'], wav [1,L], text float [n], frames, ok) of one item, data_utils.py:101-121 minus the
+        spectrogram (computed on the GPU by S2Reader); a failed read gives the reference's all-zero placeholder item
+        (ok=False: its spectrogram stays exactly zero, as there)."""
+        name, ids = self.items[index]
+        text, ok = torch.tensor(ids, dtype=torch.float32), True
+        try:
+            wav = torch.from_numpy(read_wav_pcm16("%s/%s" % (self.path5, name), self.sampling_rate)).unsqueeze(0)
+            pad = (self.filter_length - self.hop_length) // 2
+            if wav.size(1) <= pad:
+                raise ValueError(f"{name}: {wav.size(1)} samples cannot be reflect-padded by {pad}")
+            frames = spec_frames(wav.size(1), self.filter_length, self.hop_length)
+            ssl = torch.load("%s/%s.pt" % (self.path4, name), map_location="cpu")
+            if ssl.shape[-1] != frames:
+                ssl = torch.nn.functional.pad(ssl.float(), (0, 1), mode="replicate").to(ssl.dtype)
+            ssl.requires_grad = False
+        except Exception:
+            traceback.print_exc()
+            frames = 100
+            wav = torch.zeros(1, 100 * self.hop_length)
+            ssl = torch.zeros(1, 768, 100)
+            text, ok = text[-1:], False
+            print("load audio or ssl error!!!!!!", name)
+        return ssl, wav, text, frames, ok
+
+
+class S2BucketSampler:
+    """Length-bucketed batches of one rank, data_utils.py:229-323 (same batches for the same lengths, boundaries,
+    batch size, epoch, rank and replica count; items outside (boundaries[0], boundaries[-1]] are dropped, each bucket
+    is padded by repetition to a multiple of world*batch_size)."""
+
+    def __init__(self, lengths, batch_size, boundaries=None, num_replicas=1, rank=0, shuffle=True):
+        self.lengths, self.batch_size = list(lengths), batch_size
+        self.boundaries = list(S2_BUCKET_BOUNDARIES if boundaries is None else boundaries)
+        self.num_replicas, self.rank, self.shuffle, self.epoch = num_replicas, rank, shuffle, 0
+        buckets = [[] for _ in range(len(self.boundaries) - 1)]
+        for i, length in enumerate(self.lengths):
+            b = self._bucket_of(length)
+            if b != -1:
+                buckets[b].append(i)
+        keep = [i for i, b in enumerate(buckets) if len(b) > 0]
+        self.boundaries = [self.boundaries[0]] + [self.boundaries[i + 1] for i in keep] if keep else self.boundaries[:1]
+        self.buckets = [buckets[i] for i in keep]
+        total = self.num_replicas * self.batch_size
+        self.num_samples_per_bucket = [len(b) + (total - len(b) % total) % total for b in self.buckets]
+        self.total_size = sum(self.num_samples_per_bucket)
+        self.num_samples = self.total_size // self.num_replicas
+
+    def _bucket_of(self, x):
+        # the reference bisects (data_utils.py:304-318); with increasing boundaries that is the unique i with
+        # boundaries[i] < x <= boundaries[i+1]
+        for i in range(len(self.boundaries) - 1):
+            if self.boundaries[i] < x <= self.boundaries[i + 1]:
+                return i
+        return -1
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples // self.batch_size
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.epoch)
+        if self.shuffle:
+            orders = [torch.randperm(len(b), generator=g).tolist() for b in self.buckets]
+        else:
+            orders = [list(range(len(b))) for b in self.buckets]
+        batches = []
+        for bucket, ids, padded in zip(self.buckets, orders, self.num_samples_per_bucket):
+            rem = padded - len(bucket)
+            ids = ids + ids * (rem // len(bucket)) + ids[:rem % len(bucket)]
+            ids = ids[self.rank::self.num_replicas]
+            for j in range(len(ids) // self.batch_size):
+                batches.append([bucket[k] for k in ids[j * self.batch_size:(j + 1) * self.batch_size]])
+        if self.shuffle:
+            batches = [batches[i] for i in torch.randperm(len(batches), generator=g).tolist()]
+        assert len(batches) * self.batch_size == self.num_samples
+        return iter(batches)
+
+
+def _even_pad(n):
+    return int(2 * ((n // 2) + 1))
+
+
+def collate_s2(items, spec_bins, pin=False):
+    """TextAudioSpeakerCollate (data_utils.py:167-226) for items (ssl, wav, text, frames, ...): rows sorted by spectrogram
+    length, longest first; ssl and spec time axes padded to 2*(max//2+1); everything else to the batch maximum.
+    Returns the reference's 8-tuple with `spec_padded` zero-filled plus `order` (source index of each row): the caller
+    writes row i's spectrogram into spec_padded[i, :, :spec_lengths[i]]."""
+    n = len(items)
+    _, order = torch.sort(torch.tensor([it[3] for it in items], dtype=torch.long), dim=0, descending=True)
+    order = order.tolist()
+    max_ssl = _even_pad(max(it[0].size(2) for it in items))
+    max_spec = _even_pad(max(it[3] for it in items))
+    max_wav = max(it[1].size(1) for it in items)
+    max_text = max(it[2].size(0) for it in items)
+
+    def buf(shape, dtype):
+        return torch.zeros(shape, dtype=dtype, pin_memory=pin)
+
+    ssl_p = buf((n, items[0][0].size(1), max_ssl), torch.float32)
+    spec_p = buf((n, spec_bins, max_spec), torch.float32)
+    wav_p = buf((n, 1, max_wav), torch.float32)
+    text_p = buf((n, max_text), torch.long)
+    ssl_l, spec_l, wav_l, text_l = (torch.zeros(n, dtype=torch.long) for _ in range(4))
+    for i, src in enumerate(order):
+        ssl, wav, text, frames = items[src][:4]
+        ssl_p[i, :, :ssl.size(2)] = ssl[0]
+        ssl_l[i] = ssl.size(2)
+        spec_l[i] = frames
+        wav_p[i, :, :wav.size(1)] = wav
+        wav_l[i] = wav.size(1)
+        text_p[i, :text.size(0)] = text
+        text_l[i] = text.size(0)
+    return (ssl_p, ssl_l, spec_p, spec_l, wav_p, wav_l, text_p, text_l), order
+
+
+class _Prefetch:
+    """host-side read+collate of the next batches on one thread while the GPU runs the current step"""
+
+    def __init__(self, make, keys, depth):
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.stop = threading.Event()
+
+        def run():
+            try:
+                for k in keys:
+                    if self.stop.is_set():
+                        return
+                    self.q.put(("ok", make(k)))
+                self.q.put(("end", None))
+            except BaseException as e:  # surfaced on the consumer side
+                self.q.put(("err", e))
+
+        self.t = threading.Thread(target=run, daemon=True)
+        self.t.start()
+
+    def __iter__(self):
+        try:
+            while True:
+                kind, val = self.q.get()
+                if kind == "end":
+                    return
+                if kind == "err":
+                    raise val
+                yield val
+        finally:
+            self.stop.set()
+            while self.t.is_alive():
+                try:
+                    self.q.get_nowait()
+                except queue.Empty:
+                    self.t.join(0.01)
+
+
+class S2Reader:
+    """Iterable of device batches with the layout of the reference's s2 DataLoader (src/train/sovits.py:229-267)."""
+
+    def __init__(self, exp_dir, data_cfg, batch_size, device, rank=0, world=1, boundaries=None, prefetch=4,
+                 symbol_to_id=None, spec_fn=None):
+        self.ds = S2FeatureDir(exp_dir, data_cfg, symbol_to_id=symbol_to_id)
+        self.sampler = S2BucketSampler(self.ds.lengths, batch_size, boundaries, num_replicas=world, rank=rank)
+        self.device, self.prefetch = torch.device(device), prefetch
+        self.spec_bins = self.ds.filter_length // 2 + 1
+        if spec_fn is None:
+            from ..module.mel_processing import spectrogram_torch as spec_fn
+        self.spec_fn = spec_fn
+
+    def set_epoch(self, epoch):
+        self.sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def _host_batch(self, indices):
+        items = [self.ds.load(i) for i in indices]
+        batch, order = collate_s2(items, self.spec_bins, pin=self.device.type == "cuda")
+        return batch, [items[src][4] for src in order]
+
+    def __iter__(self):
+        ds, dev = self.ds, self.device
+        for (ssl, ssl_l, spec, spec_l, wav, wav_l, text, text_l), ok in _Prefetch(self._host_batch, iter(self.sampler),
+                                                                                 self.prefetch):
+            ssl, spec, wav, text = (t.to(dev, non_blocking=True) for t in (ssl, spec, wav, text))
+            for i in range(wav.size(0)):
+                if not ok[i]:
+                    continue
+                n, frames = int(wav_l[i]), int(spec_l[i])
+                s = self.spec_fn(wav[i, :, :n], ds.filter_length, ds.sampling_rate, ds.hop_length, ds.win_length,
+                                 center=False)
+                spec[i, :, :frames] = s[0]
+            yield (ssl, ssl_l.to(dev), spec, spec_l.to(dev), wav, wav_l.to(dev), text, text_l.to(dev))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# s1: Text2SemanticDataset / DistributedBucketSampler / collate
+# ---------------------------------------------------------------------------------------------------------------------
+class S1SemanticTable:
+    """(semantic_ids, phoneme_ids) pairs of 6-name2semantic.tsv x 2-name2text.txt, dataset.py:38-183.
+
+    Filters: more than max_sec*hz semantic tokens; more than max_sec*hz/2.5 phonemes; phonemes per second outside
+    [min_ps_ratio, max_ps_ratio]; unknown names/phonemes.  Fewer than 100 survivors are repeated max(2, 100//n)
+    times.  The tsv's first line is a header (the reference reads it with pandas.read_csv)."""
+
+    def __init__(self, phoneme_path, semantic_path, max_sec=100, pad_val=1024, min_ps_ratio=3, max_ps_ratio=25,
+                 max_sample=None, symbol_to_id=None):
+        for p in (phoneme_path, semantic_path):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        self.path3 = "%s/3-bert" % os.path.dirname(phoneme_path)
+        self.PAD = pad_val
+        self.hz = int(os.environ.get("hz", "25hz")[:-2])
+        sym = symbol_to_id if symbol_to_id is not None else load_symbol_table(os.path.dirname(phoneme_path))
+        phoneme_data = read_name2text(phoneme_path)
+        with open(semantic_path, "r", encoding="utf-8") as f:
+            rows = [ln.split("\t") for ln in f.read().split("\n")[1:] if ln.strip() != ""]
+        if max_sample is not None:
+            rows = rows[:max_sample]
+        self.semantic_phoneme, self.item_names = [], []
+        self.num_not_in = self.num_deleted_bigger = self.num_deleted_ps = 0
+        for row in rows:
+            name = row[0]
+            if name not in phoneme_data:
+                self.num_not_in += 1
+                continue
+            semantic_ids = [int(v) for v in row[1].split(" ")]
+            if len(semantic_ids) > max_sec * self.hz:
+                self.num_deleted_bigger += 1
+                continue
+            try:
+                phoneme_ids = [sym[p] for p in phoneme_data[name][0].split(" ")]
+            except KeyError:
+                self.num_not_in += 1
+                continue
+            if len(phoneme_ids) > max_sec * self.hz / 2.5:
+                self.num_deleted_ps += 1
+                continue
+            ps_ratio = len(phoneme_ids) / (len(semantic_ids) / self.hz)
+            if ps_ratio > max_ps_ratio or ps_ratio < min_ps_ratio:
+                self.num_deleted_ps += 1
+                continue
+            self.semantic_phoneme.append((semantic_ids, phoneme_ids))
+            self.item_names.append(name)
+        n = len(self.semantic_phoneme)
+        if n == 0:
+            raise ValueError(f"no valid data in {semantic_path}, please check the data and try again")
+        if n < 100:
+            rep = max(2, int(100 / n))
+            self.semantic_phoneme, self.item_names = self.semantic_phoneme * rep, self.item_names * rep
+
+    def __len__(self):
+        return len(self.semantic_phoneme)
+
+    def get_sample_length(self, idx):
+        return 1.0 * len(self.semantic_phoneme[idx][0]) / self.hz
+
+    def load(self, idx):
+        semantic_ids, phoneme_ids = self.semantic_phoneme[idx]
+        path_bert = "%s/%s.pt" % (self.path3, self.item_names[idx])
+        bert = None
+        if os.path.exists(path_bert):
+            bert = torch.load(path_bert, map_location="cpu")
+            assert bert.shape[-1] == len(phoneme_ids), (self.item_names[idx], tuple(bert.shape), len(phoneme_ids))
+        return dict(idx=idx, phoneme_ids=phoneme_ids, phoneme_ids_len=len(phoneme_ids), semantic_ids=semantic_ids,
+                    semantic_ids_len=len(semantic_ids), bert_feature=bert)
+
+    def collate(self, examples, pin=False):
+        """dataset.py:222-271: phonemes padded with 0, semantic tokens with PAD, bert features [B,1024,max_phones]
+        zero-filled where an item has none"""
+        n = len(examples)
+        max_ph = max(e["phoneme_ids_len"] for e in examples)
+        max_se = max(e["semantic_ids_len"] for e in examples)
+        ph = torch.zeros((n, max_ph), dtype=torch.long, pin_memory=pin)
+        se = torch.full((n, max_se), self.PAD, dtype=torch.long, pin_memory=pin)
+        bert = torch.zeros((n, 1024, max_ph), dtype=torch.float32, pin_memory=pin)
+        for i, e in enumerate(examples):
+            ph[i, :e["phoneme_ids_len"]] = torch.tensor(e["phoneme_ids"], dtype=torch.long)
+            se[i, :e["semantic_ids_len"]] = torch.tensor(e["semantic_ids"], dtype=torch.long)
+            if e["bert_feature"] is not None:
+                bert[i, :, :e["bert_feature"].shape[-1]] = e["bert_feature"]
+        return dict(ids=[e["idx"] for e in examples], phoneme_ids=ph,
+                    phoneme_ids_len=torch.tensor([e["phoneme_ids_len"] for e in examples]),
+                    semantic_ids=se, semantic_ids_len=torch.tensor([e["semantic_ids_len"] for e in examples]),
+                    bert_feature=bert)
+
+
+class S1BucketSampler:
+    """Index stream of one rank, bucket_sampler.py:29-170: items sorted by duration into 2-second buckets, shuffled
+    inside each bucket and then as world*batch_size groups with Python's Mersenne Twister seeded by seed+epoch, padded
+    by repetition to a multiple of the replica count and strided by rank.  `batches()` cuts it the way the reference's
+    DataLoader(batch_size=..., drop_last=False) does."""
+
+    def __init__(self, table, batch_size, num_replicas=1, rank=0, shuffle=True, seed=0, drop_last=False):
+        if rank >= num_replicas or rank < 0:
+            raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}]")
+        self.n, self.batch_size = len(table), batch_size
+        self.num_replicas, self.rank, self.shuffle, self.seed, self.drop_last, self.epoch = \
+            num_replicas, rank, shuffle, seed, drop_last, 0
+        if drop_last and self.n % num_replicas != 0:
+            self.num_samples = math.ceil((self.n - num_replicas) / num_replicas)
+        else:
+            self.num_samples = math.ceil(self.n / num_replicas)
+        self.total_size = self.num_samples * num_replicas
+        by_len = sorted(((i, table.get_sample_length(i)) for i in range(self.n)), key=lambda x: x[1])
+        self.id_buckets, cur, max_sec = [], [], 2.0
+        for i, sec in by_len:
+            if sec < max_sec:
+                cur.append(i)
+            else:
+                self.id_buckets.append(cur)
+                cur = [i]
+                max_sec += 2.0
+        if len(cur) > 0:
+            self.id_buckets.append(cur)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        if self.shuffle:
+            rng = random.Random(self.epoch + self.seed)
+            flat = []
+            for buc in self.id_buckets:
+                buc = buc.copy()
+                rng.shuffle(buc)
+                flat += buc
+            group = self.batch_size * self.num_replicas
+            groups = [flat[b * group:(b + 1) * group] for b in range(int(math.ceil(len(flat) / group)))]
+            rng.shuffle(groups)
+            indices = [i for g in groups for i in g]
+        else:
+            indices = list(range(self.n))
+        if not self.drop_last:
+            pad = self.total_size - len(indices)
+            if pad <= len(indices):
+                indices += indices[:pad]
+            else:
+                indices += (indices * math.ceil(pad / len(indices)))[:pad]
+        else:
+            indices = indices[:self.total_size]
+        assert len(indices) == self.total_size
+        indices = indices[self.rank:self.total_size:self.num_replicas]
+        assert len(indices) == self.num_samples
+        return iter(indices)
+
+    def batches(self):
+        idx = list(iter(self))
+        return [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)]
+
+
+class S1Reader:
+    """Iterable of device batches with the layout of Text2SemanticDataModule.train_dataloader (data_module.py:42-54)."""
+
+    def __init__(self, exp_dir, data_cfg, batch_size, device, rank=0, world=1, prefetch=8, symbol_to_id=None,
+                 phoneme_name="2-name2text.txt", semantic_name="6-name2semantic.tsv", if_dpo=False):
+        self.table = S1SemanticTable(os.path.join(exp_dir, phoneme_name), os.path.join(exp_dir, semantic_name),
+                                     max_sec=data_cfg.get("max_sec", 100), pad_val=data_cfg.get("pad_val", 1024),
+                                     symbol_to_id=symbol_to_id)
+        if if_dpo or data_cfg.get("if_dpo", False):
+            batch_size = batch_size // 2
+        self.batch_size = max(min(batch_size, len(self.table) // 4), 1)
+        self.sampler = S1BucketSampler(self.table, self.batch_size, num_replicas=world, rank=rank)
+        self.device, self.prefetch = torch.device(device), prefetch
+
+    def set_epoch(self, epoch):
+        self.sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return math.ceil(len(self.sampler) / self.batch_size)
+
+    def _host_batch(self, indices):
+        return self.table.collate([self.table.load(i) for i in indices], pin=self.device.type == "cuda")
+
+    def __iter__(self):
+        for b in _Prefetch(self._host_batch, self.sampler.batches(), self.prefetch):
+            yield {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}

@@ -94,7 +94,9 @@ class GPTTrain:
         if reducer is not None:
             reducer.broadcast_params(eng.arena.param)
         source = open_source("s1", self.params.train_input_dir, device,
-                             lambda n: SyntheticS1Batches(c["batch_size"], 256, 768, n, device, seed=c["seed"], rank=rank))
+                             lambda n: SyntheticS1Batches(c["batch_size"], 256, 768, n, device, seed=c["seed"], rank=rank),
+                             batch_size=c["batch_size"], cfg=dict(cfg["data"], if_dpo=c.get("if_dpo", False)),
+                             rank=rank, world=world)
         connector = MultiProcessOutputConnector()
         step_no = 0
         for epoch in range(start_epoch, c["epochs"]):

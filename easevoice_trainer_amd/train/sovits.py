@@ -84,7 +84,8 @@ class SovitsTrain:
             # steps of that shape; other shapes keep running eagerly
             eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "16")))
         source = open_source("s2", hps["data"]["exp_dir"], device,
-                             lambda n: SyntheticS2Batches(t["batch_size"], 4, n, device, seed=t["seed"], rank=rank, world=world))
+                             lambda n: SyntheticS2Batches(t["batch_size"], 4, n, device, seed=t["seed"], rank=rank, world=world),
+                             batch_size=t["batch_size"], cfg=hps["data"], rank=rank, world=world)
         # resume, else pretrained (sovits.py:327-366)
         try:
             _, _, _, epoch_str = ckpt.load_checkpoint(ckpt.latest_checkpoint_path(t["train_logs_dir"], "D_*.pth"),
