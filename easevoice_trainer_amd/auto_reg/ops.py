@@ -1,4 +1,5 @@
-"""autograd wrappers of the s1 HIP kernels (C ABI: evt_attn_prefixlm_*, evt_add_layernorm_*, evt_ce_sum_fwd_bwd)."""
+"""autograd wrappers of the s1 HIP kernels (C ABI: evt_attn_prefixlm_*, evt_add_layernorm_*, evt_ce_sum_fwd_bwd,
+evt_ce_rows_fwd_bwd)."""
 import ctypes as C
 
 import torch
@@ -104,3 +105,28 @@ class CrossEntropySumFn(torch.autograd.Function):
     def backward(ctx, dloss, _):
         (dlogits,) = ctx.saved_tensors
         return dlogits * dloss.to(dlogits.dtype), None, None, None
+
+
+class CrossEntropyRowsFn(torch.autograd.Function):
+    """Per-row -log p(target) over [rows, V] logits, with softmax-onehot saved by the same pass: the DPO branch needs
+    both the summed cross-entropy and per-sequence target log-probabilities of the same logits (t2s_model.py:420-427,
+    get_batch_logps models/utils.py:176-183).  Returns (row_loss fp32 [rows], hits int32[2])."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, topk, ignore_index):
+        logits = logits.contiguous()
+        rows, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        hits = torch.zeros(2, dtype=torch.int32, device=logits.device)
+        L.check(L.lib().evt_ce_rows_fwd_bwd(L.dt_of(logits), L.ptr(logits), L.ptr(targets.contiguous()), L.ptr(dlogits),
+                                            L.ptr(row_loss), L.ptr(hits), C.c_int64(rows), V, int(topk),
+                                            C.c_int64(int(ignore_index)), L.stream_ptr()), "evt_ce_rows_fwd_bwd")
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(hits)
+        return row_loss, hits
+
+    @staticmethod
+    def backward(ctx, drow, _):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * drow.to(dlogits.dtype).unsqueeze(1), None, None, None

@@ -9,7 +9,8 @@ TransformerEncoder / TransformerEncoderLayer (modules/transformer.py:106-339), M
     (x_len, x_lens, y_lens);
   * post-LN residuals, cross-entropy(sum) + top-3 accuracy are single fused HIP launches;
   * Linear layers are plain GEMMs (hipBLASLt via F.linear) in the compute dtype.
-There is no inference path here and no DPO branch (N4).
+`forward` is the DPO branch (t2s_model.py:393-429), `forward_old` the plain one the default config trains with.
+There is no inference path here.
 """
 import math
 
@@ -19,7 +20,8 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.enc import bump_rng, new_site, relu_dropout, res_drop_ln
-from .ops import AddLayerNormFn, CrossEntropySumFn, PrefixLMAttentionFn
+from .ops import AddLayerNormFn, CrossEntropyRowsFn, CrossEntropySumFn, PrefixLMAttentionFn
+from .utils import dpo_loss, make_reject_y
 
 
 class TokenEmbedding(nn.Module):
@@ -167,8 +169,8 @@ class Text2SemanticDecoder(nn.Module):
         targets = F.pad(y, (0, 1), value=0) + eos_id * F.pad(y_mask_int, (0, 1), value=1)
         return targets[:, :-1], targets[:, 1:]
 
-    def forward_old(self, x, x_lens, y, y_lens, bert_feature):
-        """x phoneme ids [B, Tx], y semantic ids [B, Ty], bert_feature [B, 1024, Tx] -> (loss sum, top-3 acc)"""
+    def _logits(self, x, x_lens, y, y_lens, bert_feature):
+        """embeddings -> 24 post-LN blocks -> predict layer over the y positions; returns (logits [B, Ty, V], targets)"""
         cd = self.cd
         xe = self.ar_text_embedding(x)
         xe = xe + F.linear(bert_feature.transpose(1, 2).to(cd), self.bert_proj.weight.to(cd), self.bert_proj.bias.to(cd)
@@ -177,17 +179,37 @@ class Text2SemanticDecoder(nn.Module):
         y_mask_int = make_pad_mask(y_lens, y.size(1)).to(torch.int64)
         codes = y.to(torch.int64) * (1 - y_mask_int)
         y_in, targets = self.pad_y_eos(codes, y_mask_int, eos_id=self.EOS)
-        x_len, y_len = x.size(1), y.size(1)
+        x_len = x.size(1)
         y_pos = self.ar_audio_position(self.ar_audio_embedding(y_in))
         xy = torch.cat([xe, y_pos], dim=1).to(cd).contiguous()
         self._seed = (self._seed * 1664525 + 1013904223) & 0x7FFFFFFF
         if xy.is_cuda:
             bump_rng(xy.device)      # new dropout masks for the fused residual/LayerNorm and relu launches
         xy_dec = self.h(xy, x_lens.to(torch.int32).contiguous(), y_lens.to(torch.int32).contiguous(), x_len, self._seed)
-        logits = F.linear(xy_dec[:, x_len:], self.ar_predict_layer.weight.to(cd))        # [B, Ty, V]
+        return F.linear(xy_dec[:, x_len:], self.ar_predict_layer.weight.to(cd)), targets
+
+    def forward_old(self, x, x_lens, y, y_lens, bert_feature):
+        """x phoneme ids [B, Tx], y semantic ids [B, Ty], bert_feature [B, 1024, Tx] -> (loss sum, top-3 acc)"""
+        logits, targets = self._logits(x, x_lens, y, y_lens, bert_feature)
         loss, hits = CrossEntropySumFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k,
                                              self.EOS)
         acc = hits[0].float() / hits[1].clamp(min=1).float()
         return loss, acc
 
-    forward = forward_old
+    def forward(self, x, x_lens, y, y_lens, bert_feature):
+        """DPO branch (t2s_model.py:393-429): cross-entropy(sum) of the chosen pass plus the reference-free DPO term
+        between the summed target log-probabilities of the chosen sequences and of `make_reject_y`'s corrupted copies.
+        As in the reference the log-probabilities are summed over every position of the padded batch (padded positions
+        have target EOS).  One fused per-row cross-entropy launch per pass gives the summed loss, the per-sequence
+        log-probabilities and the saved softmax-onehot for both gradients; the accuracy stays a device scalar."""
+        reject_y, reject_y_lens = make_reject_y(y, y_lens)
+        B = x.size(0)
+        logits, targets = self._logits(x, x_lens, y, y_lens, bert_feature)
+        row, hits = CrossEntropyRowsFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k, self.EOS)
+        r_logits, r_targets = self._logits(x, x_lens, reject_y, reject_y_lens, bert_feature)
+        r_row, _ = CrossEntropyRowsFn.apply(r_logits.reshape(-1, self.vocab_size), r_targets.reshape(-1), self.top_k,
+                                            self.EOS)
+        chosen_logps, rejected_logps = -row.view(B, -1).sum(-1), -r_row.view(B, -1).sum(-1)
+        loss = row.sum() + dpo_loss(chosen_logps, rejected_logps, 0.2)
+        acc = hits[0].float() / hits[1].clamp(min=1).float()
+        return loss, acc

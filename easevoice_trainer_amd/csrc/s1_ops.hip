@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const T* x, const T* r, const 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_sum_kernel(const T* logits, const long* targets, T* dlogits, float* loss,
                                                      int* hits, long rows, int V, int topk, long ignore_index,
-                                                     float dloss) {
+                                                     float dloss, float* row_loss) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void ce_sum_kernel(const T* logits, const long
     }
   }
   if (lane == 0) {
-    atomicAdd(loss, lse - lt);
+    if (loss) atomicAdd(loss, lse - lt);
+    if (row_loss) row_loss[row] = lse - lt;
     if (hits && tgt != ignore_index) {
       atomicAdd(hits + 1, 1);
       if (gt < (float)topk) atomicAdd(hits, 1);
@@ -270,20 +271,34 @@ int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const flo
   return evt_check_launch();
 }
 
-int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
-                       int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, float dloss,
-                       void* stream) {
-  if (!logits || !targets || !loss || rows <= 0 || V <= 0) return EVT_EINVAL;
+static int launch_ce(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
+                     float* row_loss, int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index,
+                     float dloss, void* stream) {
+  if (!logits || !targets || (!loss && !row_loss) || rows <= 0 || V <= 0) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)((rows + 3) / 4);
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL(ce_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)logits,
-                       (const long*)targets, (bf16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss);
+                       (const long*)targets, (bf16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
+                       row_loss);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(ce_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)logits, (const long*)targets,
-                       (float*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss);
+                       (float*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss, row_loss);
   else return EVT_EINVAL;
   return evt_check_launch();
+}
+
+int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
+                       int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, float dloss,
+                       void* stream) {
+  if (!loss) return EVT_EINVAL;
+  return launch_ce(dtype, logits, targets, dlogits, loss, nullptr, hits, rows, V, topk, ignore_index, dloss, stream);
+}
+
+int evt_ce_rows_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
+                        int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, void* stream) {
+  if (!row_loss) return EVT_EINVAL;
+  return launch_ce(dtype, logits, targets, dlogits, nullptr, row_loss, hits, rows, V, topk, ignore_index, 1.0f, stream);
 }
 
 int evt_scaled_adam_stats(const float* param, const float* grad, const evt_sa_chunk* chunks, int32_t nchunks,

@@ -37,8 +37,6 @@ class GPTTrainParams:
 
 class GPTTrain:
     def __init__(self, params: GPTTrainParams, dtype=torch.bfloat16, config_path=None):
-        if params.if_dpo:
-            raise NotImplementedError("the DPO branch (t2s_model.py:393-429) is SURVEY §8(f) N4")
         self.config = yaml.safe_load(open(config_path or os.path.join(repo_root(), "configs", "gpt.yaml")))
         self.params, self.dtype = params, dtype
         self.train_output = get_gpt_train_dir(params.project_dir, params.output_model_name)

@@ -28,9 +28,11 @@ class S1Engine:
         self._views = [(p, p.grad) for p in self.model.parameters()]
 
     def micro_step(self, batch: dict, batch_idx: int):
-        """one micro-batch: forward_old + backward (+ optimiser step on the reference's schedule)"""
-        loss, acc = self.model.forward_old(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
-                                           batch["semantic_ids_len"], batch["bert_feature"])
+        """one micro-batch: forward_old (or the DPO `forward` when config train.if_dpo, t2s_lightning_module.py:44) +
+        backward (+ optimiser step on the reference's schedule)"""
+        fwd = self.model.forward if self.config.get("train", {}).get("if_dpo", False) is True else self.model.forward_old
+        loss, acc = fwd(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
+                        batch["semantic_ids_len"], batch["bert_feature"])
         # autograd keeps the produced gradient tensors (no per-parameter `grad += new` launch); they are accumulated
         # into the flat arena with one multi-tensor add
         for p, _v in self._views:

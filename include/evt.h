@@ -293,6 +293,11 @@ int evt_relattn_bwd(const evt_relattn_params* p, const void* q, const void* k, c
 int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
                        int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, float dloss,
                        void* stream);
+/* Per-row form for the DPO branch (t2s_model.py:420-427, models/utils.py:176-183): row_loss[r] = lse_r - logit[r][t_r]
+ * (= -log p(target), written, not accumulated), dlogits = softmax - onehot (unscaled; the caller applies the per-row
+ * upstream weight), hits as above.  The summed target log-probability of a sequence is -sum of its rows. */
+int evt_ce_rows_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
+                        int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, void* stream);
 
 /* ScaledAdam (src/easevoice/soundstorm/auto_reg/modules/optim.py:206-251,300-390,448-622) over a flat fp32 arena.
  * The reference stacks same-shaped tensors only to batch its torch ops; the arithmetic is per tensor, which is what

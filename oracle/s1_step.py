@@ -4,7 +4,8 @@ Follows Text2SemanticDecoder.forward_old  src/easevoice/soundstorm/auto_reg/mode
 materialised float attention mask :456-479 and pad_y_eos :557-561), TransformerEncoderLayer (post-LN, relu)
 modules/transformer.py:266-339, multi_head_attention_forward_patched modules/patched_mha_with_cache.py:242-460,
 SinePositionalEmbedding modules/embedding.py:36-81, and ScaledAdam modules/optim.py:206-622 (per-tensor form).
-PINNED against tests/golden/s1_small.pt (reference's own modules) by tests/test_oracle_cpu.py."""
+The DPO branch (t2s_model.py:393-429, models/utils.py:160-228) is forward_dpo / make_reject_y.
+PINNED against tests/golden/s1_small.pt and s1_dpo.pt (reference's own modules) by tests/test_oracle_cpu.py."""
 import math
 
 import torch
@@ -73,6 +74,44 @@ def forward_old(sd, cfg, x, x_lens, y, y_lens, bert_feature):
     keep = targets != EOS
     acc = ((top3 == targets.unsqueeze(1)).any(dim=1) & keep).sum().float() / keep.sum().clamp(min=1).float()
     return loss, acc, logits
+
+
+def make_reject_y(y, y_lens):
+    """rejected sequences of the DPO branch, models/utils.py:185-228.  Restated with its quirks: the branch selector is
+    `randint(0, 1)` (always 0 -> always the repeat rule, the drop rule is dead code), the two cut points are drawn over
+    the PADDED row length and the row is used including its padding, and the returned length is the whole new row.
+    Draw order on torch's global CPU generator: per item one randint(0,1,(1,)) then one randint(0,len,(2,))."""
+    rows, lens = [], []
+    for b in range(len(y_lens)):
+        torch.randint(0, 1, size=(1,))
+        i0, i1 = torch.randint(0, len(y[b]), size=(2,)).sort()[0].tolist()
+        rows.append(torch.cat([y[b][:i0], y[b][i0:i1], y[b][i0:i1], y[b][i1:]]))
+        lens.append(len(rows[-1]))
+    width = max(lens)
+    out = torch.stack([F.pad(r, (0, width - len(r))) for r in rows], 0)
+    return out, torch.tensor(lens)
+
+
+def forward_dpo(sd, cfg, x, x_lens, y, y_lens, bert_feature, reject=None):
+    """Text2SemanticDecoder.forward, t2s_model.py:393-429: cross-entropy(sum) of the chosen pass + the reference-free
+    DPO term (beta 0.2, models/utils.py:160-183) between the summed target log-probabilities of the chosen and the
+    rejected pass -- summed over every position, padded ones included (their target is EOS)."""
+    reject_y, reject_lens = reject if reject is not None else make_reject_y(y, y_lens)
+    loss_1, acc, logits = forward_old(sd, cfg, x, x_lens, y, y_lens, bert_feature)
+    _, _, rlogits = forward_old(sd, cfg, x, x_lens, reject_y, reject_lens, bert_feature)
+    EOS = cfg["model"]["EOS"]
+
+    def targets_of(yy, ll):
+        mask = (torch.arange(yy.size(1))[None] >= ll[:, None]).to(torch.int64)
+        full = F.pad(yy.to(torch.int64) * (1 - mask), (0, 1), value=0) + EOS * F.pad(mask, (0, 1), value=1)
+        return full[:, 1:]
+
+    def logps(lg, tg):     # lg [B, V, T]
+        return torch.gather(lg.log_softmax(1), 1, tg.unsqueeze(1)).squeeze(1).sum(-1)
+
+    chosen, rejected = logps(logits, targets_of(y, y_lens)), logps(rlogits, targets_of(reject_y, reject_lens))
+    loss_2 = (-F.logsigmoid(0.2 * (chosen - rejected))).mean()
+    return loss_1 + loss_2, acc, (chosen, rejected, loss_2)
 
 
 class ScaledAdamRef:

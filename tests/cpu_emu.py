@@ -152,6 +152,12 @@ def cpu_emulation_s1():
             hits = torch.stack([((gt < topk) & keep).sum(), keep.sum()]).to(torch.int32)
             return loss, hits
 
+    class _CERows:
+        @staticmethod
+        def apply(logits, targets, topk, ignore_index):
+            row = F.cross_entropy(logits.float(), targets, reduction="none")
+            return row, _CE.apply(logits, targets, topk, ignore_index)[1]
+
     def k_stats(self):
         a = self.arena
         for b, e, t in self._chunk_list:
@@ -179,9 +185,11 @@ def cpu_emulation_s1():
                 p.add_(d)
 
     TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn = _Attn, _LN, _CE
+    saved_rows, TM.CrossEntropyRowsFn = TM.CrossEntropyRowsFn, _CERows
     OPT.ScaledAdam._k_stats, OPT.ScaledAdam._k_apply = k_stats, k_apply
     try:
         yield
     finally:
         (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,
          OPT.ScaledAdam._k_apply) = saved
+        TM.CrossEntropyRowsFn = saved_rows

@@ -78,5 +78,66 @@ def make_s1():
     print("wrote", path, "loss", out["loss"], "acc", out["acc"], "per-token nll", out["loss"] / (B * y_len))
 
 
+def make_s1_dpo():
+    """the DPO branch (Text2SemanticDecoder.forward, t2s_model.py:393-429): the rejected sequences come from
+    make_reject_y's draws on torch's global CPU generator, seeded here; they are stored so the product / oracle can be
+    checked both on the draw and on the arithmetic."""
+    import yaml
+    from src.easevoice.soundstorm.auto_reg.models import t2s_model as TM
+    from src.easevoice.soundstorm.auto_reg.models.utils import make_reject_y
+
+    torch.set_num_threads(8)
+    cfg = yaml.safe_load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "gpt.yaml")))
+    model = TM.Text2SemanticDecoder(config=cfg, top_k=3)
+    fill_module(model, 3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(m.dropout, float):
+            m.dropout = 0.0
+    model.train()
+    B, x_len, y_len = 3, 24, 40
+    b = s1_batch(B, x_len, y_len)
+    x_lens, y_lens = torch.tensor([24, 17, 9]), torch.tensor([40, 29, 33])
+    cases = []
+    for seed in (2024, 558):          # 558: the rejected sequences are only 1/0/1 tokens longer -> the DPO term matters
+        torch.manual_seed(seed)
+        reject_y, reject_y_lens = make_reject_y(b["semantic_ids"], y_lens)
+        torch.manual_seed(seed)
+        loss, acc = model.forward(b["phoneme_ids"], x_lens, b["semantic_ids"], y_lens, b["bert_feature"])
+        model.zero_grad()
+        loss.backward()
+        names = ["bert_proj.weight", "ar_text_embedding.word_embeddings.weight", "ar_audio_embedding.word_embeddings.weight",
+                 "ar_audio_position.alpha", "h.layers.0.self_attn.in_proj_weight", "h.layers.11.linear1.weight",
+                 "h.layers.23.linear2.bias", "h.layers.23.norm2.weight", "ar_predict_layer.weight"]
+        params = dict(model.named_parameters())
+        gss = {}
+        for n, p in params.items():
+            top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
+            gss[top] = gss.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+        # the two parts of the loss, recomputed with the reference's helpers on the same rejected batch
+        from src.easevoice.soundstorm.auto_reg.models.utils import dpo_loss, get_batch_logps
+        with torch.no_grad():
+            xy, mask, targets = model.make_input_data(b["phoneme_ids"], x_lens, b["semantic_ids"], y_lens, b["bert_feature"])
+            logits = model.ar_predict_layer(model.h((xy, None), mask=mask)[0][:, x_len:])
+            rxy, rmask, rtargets = model.make_input_data(b["phoneme_ids"], x_lens, reject_y, reject_y_lens, b["bert_feature"])
+            rlogits = model.ar_predict_layer(model.h((rxy, None), mask=rmask)[0][:, x_len:])
+            a_lp, r_lp = get_batch_logps(logits, rlogits, targets, rtargets)
+            loss_2 = dpo_loss(a_lp, r_lp, 0, 0, 0.2, reference_free=True)[0]
+        out = dict(config=dict(B=B, x_len=x_len, y_len=y_len, x_lens=[24, 17, 9], y_lens=[40, 29, 33], seed=seed),
+                   reject_y=reject_y, reject_y_lens=reject_y_lens, loss=float(loss), acc=float(acc),
+                   chosen_logps=a_lp, rejected_logps=r_lp, loss_dpo=float(loss_2),
+                   grad_slices={n: params[n].grad.flatten()[:96].clone() for n in names}, grad_sumsq=gss)
+        cases.append(out)
+        print("seed", seed, "loss", out["loss"], "dpo part", out["loss_dpo"], "acc", out["acc"], "reject lens",
+              reject_y_lens.tolist())
+    path = os.path.join(HERE, "s1_dpo.pt")
+    torch.save(dict(cases=cases), path)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
-    make_s1()
+    if "dpo" in sys.argv[1:]:
+        make_s1_dpo()
+    else:
+        make_s1()

@@ -81,6 +81,33 @@ def test_oracle_s1_matches_reference_fixture():
         assert rel(g.flatten()[:96], gold["grad_slices"][n]) < 2e-3, n
 
 
+def test_oracle_s1_dpo_matches_reference_fixture():
+    import yaml
+    from oracle import s1_step as OS
+    from util_fill import s1_batch
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    keys = json.load(open(os.path.join(HERE, "golden", "state_dict_keys.json")))
+    for gold in torch.load(os.path.join(HERE, "golden", "s1_dpo.pt"), weights_only=False)["cases"]:
+        c = gold["config"]
+        b = s1_batch(c["B"], c["x_len"], c["y_len"])
+        y_lens = torch.tensor(c["y_lens"])
+        torch.manual_seed(c["seed"])                 # same draws as the reference's make_reject_y
+        ry, rl = OS.make_reject_y(b["semantic_ids"], y_lens)
+        assert torch.equal(ry, gold["reject_y"]) and torch.equal(rl, gold["reject_y_lens"])
+        sd = {k: v.requires_grad_(True) for k, v in _filled(keys["s1"], 3).items()}
+        torch.manual_seed(c["seed"])
+        loss, acc, (chosen, rejected, loss_2) = OS.forward_dpo(sd, cfg, b["phoneme_ids"], torch.tensor(c["x_lens"]),
+                                                               b["semantic_ids"], y_lens, b["bert_feature"])
+        assert abs(float(loss) - gold["loss"]) <= 1e-4 * gold["loss"] and abs(float(acc) - gold["acc"]) < 1e-6
+        assert torch.allclose(chosen, gold["chosen_logps"], rtol=1e-4) and torch.allclose(rejected, gold["rejected_logps"], rtol=1e-4)
+        assert abs(float(loss_2) - gold["loss_dpo"]) <= 2e-3 * gold["loss_dpo"] + 1e-9
+        names = list(gold["grad_slices"])
+        grads = torch.autograd.grad(loss, [sd[n] for n in names])
+        for n, g in zip(names, grads):
+            assert rel(g.flatten()[:96], gold["grad_slices"][n]) < 2e-3, (c["seed"], n)
+
+
 def test_oracle_scaled_adam_matches_reference_trajectory():
     from oracle import s1_step as OS
 

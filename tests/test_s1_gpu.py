@@ -183,3 +183,83 @@ def test_s1_model_matches_reference_fixture(gpu):
         tot[top] = tot.get(top, 0.0) + float(p.grad.double().pow(2).sum())
     for k, v in gold["grad_sumsq"].items():
         assert abs(tot[k] - v) <= 5e-3 * v, (k, tot[k], v)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_ce_rows_parity(gpu, dtype):
+    """per-row cross-entropy with row-weighted gradient (the DPO branch's launch) vs torch fp32"""
+    from easevoice_trainer_amd.auto_reg.ops import CrossEntropyRowsFn
+
+    torch.manual_seed(4)
+    V, n = 1025, 515
+    logits = torch.randn(n, V) * 2
+    if dtype == torch.bfloat16:
+        logits = logits.bfloat16().float()
+    tg = torch.randint(0, V, (n,))
+    tg[::5] = 1024
+    w = torch.randn(n)
+    lo = logits.clone().requires_grad_(True)
+    row_o = F.cross_entropy(lo, tg, reduction="none")
+    (row_o * w).sum().backward()
+    lg = logits.to(gpu, dtype).requires_grad_(True)
+    row_g, hits = CrossEntropyRowsFn.apply(lg, tg.to(gpu), 3, 1024)
+    (row_g * w.to(gpu)).sum().backward()
+    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    assert row_g.dtype == torch.float32 and rel(row_g, row_o) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel(lg.grad, lo.grad) < tol
+    keep = tg != 1024
+    lt = logits.gather(1, tg[:, None])
+    assert int(hits[0]) == int((((logits > lt).sum(1) < 3) & keep).sum()) and int(hits[1]) == int(keep.sum())
+
+
+def test_s1_dpo_matches_reference_fixture(gpu):
+    """Text2SemanticDecoder.forward (DPO) on the GPU vs the reference's own module: same rejected sequences for the same
+    torch seed, loss / accuracy / gradients within fp32 kernel tolerance (dropout off, as in the fixture)"""
+    from easevoice_trainer_amd.train.s1_engine import S1Engine
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    eng = S1Engine(cfg, gpu, torch.float32)
+    fill_module(eng.model, 3)
+    eng.model.eval()
+    for gold in torch.load(os.path.join(HERE, "golden", "s1_dpo.pt"), weights_only=False)["cases"]:
+        c = gold["config"]
+        b = s1_batch(c["B"], c["x_len"], c["y_len"])
+        eng.model.zero_grad(set_to_none=True)
+        torch.manual_seed(c["seed"])
+        loss, acc = eng.model.forward(b["phoneme_ids"].to(gpu), torch.tensor(c["x_lens"]).to(gpu),
+                                      b["semantic_ids"].to(gpu), torch.tensor(c["y_lens"]).to(gpu),
+                                      b["bert_feature"].to(gpu))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - gold["loss"]) <= 1e-3 * gold["loss"], c["seed"]
+        assert abs(float(acc) - gold["acc"]) < 1e-6
+        params = dict(eng.model.named_parameters())
+        for n, s in gold["grad_slices"].items():
+            assert rel(params[n].grad.flatten()[:96], s) < 3e-3, (c["seed"], n)
+        tot = {}
+        for n, p in params.items():
+            top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
+            tot[top] = tot.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+        for k, v in gold["grad_sumsq"].items():
+            assert abs(tot[k] - v) <= 5e-3 * v, (c["seed"], k, tot[k], v)
+
+
+def test_s1_engine_dpo_micro_steps(gpu):
+    """bf16 engine with train.if_dpo: five micro-steps (one optimiser step), finite loss above the plain one"""
+    from easevoice_trainer_amd.train.s1_engine import S1Engine
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    cfg["train"]["if_dpo"] = True
+    torch.manual_seed(0)
+    eng = S1Engine(cfg, gpu, torch.bfloat16)
+    b = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in s1_batch(4, 32, 96).items()}
+    b["phoneme_ids_len"] = torch.tensor([32, 20, 32, 11], device=gpu)
+    b["semantic_ids_len"] = torch.tensor([96, 70, 50, 96], device=gpu)
+    before = eng.arena.param.clone()
+    stepped = []
+    for i in range(5):
+        loss, acc, st = eng.micro_step(b, i)
+        stepped.append(st)
+        assert torch.isfinite(loss) and float(loss) > 0
+    assert stepped == [False, False, False, False, True]
+    assert not torch.equal(before, eng.arena.param)

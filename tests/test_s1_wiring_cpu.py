@@ -39,6 +39,33 @@ def test_s1_forward_backward_wiring():
             assert rel(params[n].grad.flatten()[:96], s) < 2e-3, n
 
 
+def test_s1_dpo_forward_backward_wiring():
+    """the DPO branch: same rejected sequences as the reference for the same torch seed, same loss / gradients"""
+    from easevoice_trainer_amd.auto_reg.t2s_model import Text2SemanticDecoder
+    from easevoice_trainer_amd.auto_reg.utils import make_reject_y
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    for gold in torch.load(os.path.join(HERE, "golden", "s1_dpo.pt"), weights_only=False)["cases"]:
+        c = gold["config"]
+        b = s1_batch(c["B"], c["x_len"], c["y_len"])
+        y_lens = torch.tensor(c["y_lens"])
+        torch.manual_seed(c["seed"])
+        ry, rl = make_reject_y(b["semantic_ids"], y_lens)
+        assert torch.equal(ry, gold["reject_y"]) and torch.equal(rl, gold["reject_y_lens"])
+        with cpu_emulation_s1():
+            m = Text2SemanticDecoder(cfg)
+            fill_module(m, 3)
+            m.eval()
+            torch.manual_seed(c["seed"])
+            loss, acc = m.forward(b["phoneme_ids"], torch.tensor(c["x_lens"]), b["semantic_ids"], y_lens, b["bert_feature"])
+            assert abs(float(loss) - gold["loss"]) <= 1e-4 * gold["loss"]
+            assert abs(float(acc) - gold["acc"]) < 1e-6
+            loss.backward()
+            params = dict(m.named_parameters())
+            for n, s in gold["grad_slices"].items():
+                assert rel(params[n].grad.flatten()[:96], s) < 2e-3, (c["seed"], n)
+
+
 def test_scaled_adam_host_logic_matches_reference():
     from easevoice_trainer_amd.auto_reg.optim import ScaledAdam
     from easevoice_trainer_amd.runtime import ParamArena
