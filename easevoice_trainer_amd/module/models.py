@@ -219,17 +219,23 @@ class TextEncoder(nn.Module, _ComputeDtype):
         self.encoder2 = Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
         self.proj = pointwise(hidden_channels, out_channels * 2)
 
-    def forward(self, y, y_mask, text, text_mask, ge, y_lengths=None, text_lengths=None):
-        """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]; the encoders mask their own input / output"""
+    def forward(self, y, y_mask, text, text_mask, ge, y_lengths=None, text_lengths=None, speed=1):
+        """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]; the encoders mask their own input / output.
+        speed != 1 (inference only, models.py:246-248) resamples the encoded sequence to int(T/speed)+1 frames before
+        the projection and returns the resampled mask as a fourth value."""
         y = self.ssl_proj(y * y_mask)
         y = self.encoder_ssl(y, y_mask, self.cd, lengths=y_lengths)
         t = self.text_embedding(text)
         t = self.encoder_text(t, text_mask, self.cd, lengths=text_lengths)
         y = self.mrte(y, y_mask, t, text_mask, ge)
         y = self.encoder2(y, y_mask, self.cd, lengths=y_lengths)
+        if speed != 1:
+            n = int(y.size(1) / speed) + 1
+            y = F.interpolate(y.transpose(1, 2).float(), size=n, mode="linear").transpose(1, 2).to(y.dtype).contiguous()
+            y_mask = F.interpolate(y_mask.transpose(1, 2), size=n, mode="nearest").transpose(1, 2).contiguous()
         stats = (self.proj(y) * y_mask).float()
         m, logs = torch.split(stats, self.out_channels, dim=-1)
-        return y, m, logs
+        return (y, m, logs) if speed == 1 else (y, m, logs, y_mask)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -383,6 +389,16 @@ class ResidualVectorQuantizer(nn.Module):
         ind = cb.nearest(x.reshape(b * t, d).float())
         q = F.embedding(ind, cb.embed).view(b, t, d)
         return q, ind.view(1, b, t)
+
+    @torch.no_grad()
+    def decode(self, codes):
+        """codes [n_q, B, T] -> quantized [B, T, D] channels-last: sum of the layers' code vectors (quantize.py:112-119,
+        core_vq.py:367-373)"""
+        q = None
+        for layer, ind in zip(self.vq.layers, codes):
+            e = F.embedding(ind, layer._codebook.embed)
+            q = e if q is None else q + e
+        return q
 
 
 # --------------------------------------------------------------------------------------------------
@@ -586,6 +602,51 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             if self.semantic_frame_rate == "25hz":
                 q = q.repeat_interleave(2, dim=1)
         return q, codes
+
+    @torch.no_grad()
+    def extract_latent(self, x):
+        """ssl features [B, 768, T] -> semantic codes [B, n_q=1, T'] (models.py:1015-1018), the tokens the s1 stage
+        learns to predict (6-name2semantic.tsv)"""
+        _q, codes = self._quantize(x.transpose(1, 2))
+        return codes.transpose(0, 1)
+
+    @torch.no_grad()
+    def decode(self, codes, text, refer, noise_scale=0.5, speed=1, noise=None):
+        """Inference: semantic codes [1, B, Tc] + phoneme ids [B, Tt] + reference spectrogram(s) [B, spec, Tr] (a list
+        averages the style vectors) -> waveform [B, 1, T*hop] (models.py:974-1013): prior from the text/ssl encoder,
+        z_p = m_p + noise*exp(logs_p)*noise_scale, the flow run in reverse, the HiFi-GAN generator over the whole
+        sequence.  `noise` ([B, inter, >=T]) injects the prior draw for deterministic parity runs."""
+        amp = self.cd == torch.bfloat16
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            ges = []
+            for r in (refer if isinstance(refer, (list, tuple)) else [refer]):
+                r_cl = r.transpose(1, 2)
+                r_cl = r_cl if self.version == "v1" else r_cl[..., :704]
+                ges.append(self.ref_enc(r_cl, torch.ones(r_cl.size(0), r_cl.size(1), 1, device=r.device)))
+            ge = torch.stack(ges, 0).mean(0)
+            B, Tc = codes.size(1), codes.size(2)
+            T = Tc * 2 if self.semantic_frame_rate == "25hz" else Tc
+            y_lengths = torch.full((B,), T, dtype=torch.long, device=codes.device)
+            text_lengths = torch.full((B,), text.size(-1), dtype=torch.long, device=text.device)
+            quantized = self.quantizer.decode(codes)
+            if self.semantic_frame_rate == "25hz":
+                quantized = quantized.repeat_interleave(2, dim=1)
+            y_mask = torch.ones(B, T, 1, device=codes.device)
+            text_mask = torch.ones(B, text.size(1), 1, device=text.device)
+            enc = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths, speed=speed)
+            if speed != 1:
+                _x, m_p, logs_p, y_mask = enc
+                y_lengths = torch.full((B,), y_mask.size(1), dtype=torch.long, device=codes.device)
+            else:
+                _x, m_p, logs_p = enc
+            if noise is None:
+                noise = torch.randn(B, m_p.size(2), m_p.size(1), device=m_p.device)
+            eps = noise[:, :, :m_p.size(1)].transpose(1, 2).to(m_p.dtype)
+            z_p = m_p + eps * torch.exp(logs_p) * noise_scale
+            ym = y_mask.to(self.cd)
+            z = self.flow(z_p, ym, g=ge, reverse=True, lens=y_lengths.to(torch.int32))
+            o = self.dec(z * ym, g=ge)
+        return o.transpose(1, 2)
 
     def forward(self, ssl, y, y_lengths, text, text_lengths, eps=None, ids_slice=None):
         """ssl [B, 768, T], y [B, spec, T] linear spectrogram, text [B, Tt] -> same tuple as the reference:

@@ -162,12 +162,43 @@ def make_keys():
     print("wrote keys", {k: len(v) for k, v in keys.items()})
 
 
+def make_decode():
+    """inference-side entry points of the s2 model: SynthesizerTrn.decode (models.py:974-1013) at
+    speed 1 and 1.25 with one and with two reference spectrograms, and extract_latent (models.py:1015-1018).  The prior
+    noise draw (randn_like) is replaced by an injected tensor."""
+    from src.easevoice.module import models
+    from util_fill import decode_inputs
+
+    cfg = json.load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "s2.json")))
+    net_g = models.SynthesizerTrn(1025, 32, n_speakers=300, **cfg["model"])
+    fill_module(net_g, 1)
+    net_g.eval()
+    d = decode_inputs()
+    out = dict(cases=[])
+    orig = torch.randn_like
+    try:
+        for speed, refer in ((1, d["refers"][0]), (1, d["refers"]), (1.25, d["refers"][0])):
+            torch.randn_like = lambda t, **kw: d["noise"][:, :, :t.size(2)].to(t.dtype)
+            o = net_g.decode(d["codes"], d["text"], refer, noise_scale=0.5, speed=speed)
+            out["cases"].append(dict(speed=speed, n_refer=len(refer) if isinstance(refer, list) else 1,
+                                     shape=list(o.shape), o_head=o[0, 0, :4096].clone(), o_dec=o[0, 0, ::37].clone(),
+                                     abs_sum=float(o.double().abs().sum()), sq_sum=float(o.double().pow(2).sum())))
+            print("decode speed", speed, "->", tuple(o.shape), "rms", float(o.pow(2).mean().sqrt()))
+    finally:
+        torch.randn_like = orig
+    out["codes"] = net_g.extract_latent(d["ssl"])
+    print("extract_latent ->", tuple(out["codes"].shape))
+    torch.save(out, os.path.join(HERE, "s2_decode.pt"))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["keys", "s2"]
     if "keys" in what:
         make_keys()
     if "s2" in what:
         make_s2()
+    if "decode" in what:
+        make_decode()
     if "s1" in what:
         sys.path.insert(0, HERE)
         from make_golden_s1 import make_s1

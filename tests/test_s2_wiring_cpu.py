@@ -82,3 +82,27 @@ def test_s2_step_wiring_matches_reference():
         for n, s in gold["g_grad_slices"].items():
             p = dict(net_g.named_parameters())[n]
             assert rel(p.grad.flatten()[:64], s) < max(2e-3, 3 * gold["g_grad_slice_noise"][n]), n
+
+
+def test_decode_and_extract_latent_wiring():
+    """inference entry points of the s2 model vs the reference's SynthesizerTrn.decode /
+    extract_latent: one and two reference spectrograms, speed 1 and 1.25, injected prior noise"""
+    from easevoice_trainer_amd.module import models
+    from util_fill import decode_inputs
+
+    torch.set_num_threads(8)
+    gold = torch.load(os.path.join(HERE, "golden", "s2_decode.pt"), weights_only=False)
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    d = decode_inputs()
+    with cpu_emulation():
+        net_g = models.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+        fill_module(net_g, 1)
+        net_g.eval()
+        for c in gold["cases"]:
+            refer = d["refers"] if c["n_refer"] == 2 else d["refers"][0]
+            o = net_g.decode(d["codes"], d["text"], refer, noise_scale=0.5, speed=c["speed"], noise=d["noise"])
+            assert list(o.shape) == c["shape"]
+            assert rel(o[0, 0, :4096], c["o_head"]) < 1e-4 and rel(o[0, 0, ::37], c["o_dec"]) < 1e-4
+            assert abs(float(o.double().pow(2).sum()) - c["sq_sum"]) < 1e-4 * c["sq_sum"]
+        codes = net_g.extract_latent(d["ssl"])
+        assert codes.dtype == torch.long and torch.equal(codes, gold["codes"])

@@ -55,6 +55,18 @@ def s2_batch(B, T, t_text, seed=1234):
                 lengths=torch.full((B,), T, dtype=torch.long), text_lengths=torch.full((B,), t_text, dtype=torch.long))
 
 
+def decode_inputs(t_codes=30, t_text=20, t_ref=(50, 37), seed=4321):
+    """inputs of SynthesizerTrn.decode / extract_latent for the inference fixtures: codes [1,1,Tc] (25 Hz), text ids,
+    two reference spectrograms (the list form averages their style vectors), the prior noise [1,192,2*Tc+pad] and an
+    ssl feature map for extract_latent"""
+    g = torch.Generator().manual_seed(seed)
+    return dict(codes=torch.randint(0, 1024, (1, 1, t_codes), generator=g),
+                text=torch.randint(0, 732, (1, t_text), generator=g),
+                refers=[torch.rand(1, 1025, t, generator=g) * 2.0 for t in t_ref],
+                noise=torch.randn(1, 192, 2 * t_codes + 8, generator=g),
+                ssl=torch.randn(2, 768, 46, generator=g))
+
+
 def s1_batch(B, x_len, y_len, seed=1234):
     g = torch.Generator().manual_seed(seed)
     return dict(phoneme_ids=torch.randint(0, 732, (B, x_len), generator=g),
