@@ -4,7 +4,8 @@ Follows Text2SemanticDecoder.forward_old  src/easevoice/soundstorm/auto_reg/mode
 materialised float attention mask :456-479 and pad_y_eos :557-561), TransformerEncoderLayer (post-LN, relu)
 modules/transformer.py:266-339, multi_head_attention_forward_patched modules/patched_mha_with_cache.py:242-460,
 SinePositionalEmbedding modules/embedding.py:36-81, and ScaledAdam modules/optim.py:206-622 (per-tensor form).
-The DPO branch (t2s_model.py:393-429, models/utils.py:160-228) is forward_dpo / make_reject_y.
+The DPO branch (t2s_model.py:393-429, models/utils.py:160-228) is forward_dpo / make_reject_y; KV-cache decoding
+(t2s_model.py:762-863, models/utils.py:118-160) is infer_panel_naive / logits_to_probs, pinned by s1_infer.pt.
 PINNED against tests/golden/s1_small.pt and s1_dpo.pt (reference's own modules) by tests/test_oracle_cpu.py."""
 import math
 
@@ -112,6 +113,90 @@ def forward_dpo(sd, cfg, x, x_lens, y, y_lens, bert_feature, reject=None):
     chosen, rejected = logps(logits, targets_of(y, y_lens)), logps(rlogits, targets_of(reject_y, reject_lens))
     loss_2 = (-F.logsigmoid(0.2 * (chosen - rejected))).mean()
     return loss_1 + loss_2, acc, (chosen, rejected, loss_2)
+
+
+def logits_to_probs(logits, previous_tokens, temperature=1.0, top_k=None, top_p=None, repetition_penalty=1.0):
+    """models/utils.py:125-160, on a copy: repetition penalty on the already generated ids, nucleus cut on the
+    un-tempered logits (first sorted entry always kept), temperature, top-k pivot (ties kept), softmax"""
+    logits = logits.clone()
+    if previous_tokens is not None and repetition_penalty != 1.0 and previous_tokens.numel() > 0:
+        prev = previous_tokens.long()
+        score = torch.gather(logits, 1, prev)
+        score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+        logits.scatter_(1, prev, score)
+    if top_p is not None and top_p < 1.0:
+        srt, order = torch.sort(logits, descending=True)
+        remove = torch.cumsum(F.softmax(srt, dim=-1), dim=-1) > top_p
+        remove[:, 0] = False
+        logits = logits.masked_fill(remove.scatter(1, order, remove), -float("inf"))
+    logits = logits / max(temperature, 1e-5)
+    if top_k is not None:
+        pivot = torch.topk(logits, min(top_k, logits.size(-1)))[0][:, -1:]
+        logits = torch.where(logits < pivot, -float("inf"), logits)
+    return F.softmax(logits, dim=-1)
+
+
+def infer_panel_naive(sd, cfg, x, prompts, bert_feature, q, top_k=15, top_p=1, early_stop_num=-1, temperature=1.0,
+                      repetition_penalty=1.35, max_steps=1500):
+    """KV-cache decoding, t2s_model.py:762-863, for batch 1 on plain tensors.  `q` [steps, V] is the exponential noise
+    of multinomial_sample_one_no_sync (models/utils.py:118-122): token = argmax(probs / q[step]).  Returns (y without
+    its last token, idx-1 or 0 when there was no prompt, list of the raw logits per step)."""
+    m = cfg["model"]
+    E, H, nl, EOS = m["hidden_dim"], m["head"], m["n_layer"], m["EOS"]
+    d = E // H
+    pe = sine_pe(4000, E)
+    xe = F.embedding(x, sd["ar_text_embedding.word_embeddings.weight"])
+    xe = xe + F.linear(bert_feature.transpose(1, 2), sd["bert_proj.weight"], sd["bert_proj.bias"])
+    xe = xe + sd["ar_text_position.alpha"] * pe[None, :x.size(1)]
+    x_len = x.size(1)
+    if prompts is not None:
+        y = prompts
+        ye = F.embedding(y, sd["ar_audio_embedding.word_embeddings.weight"])
+        h = torch.cat([xe, ye + sd["ar_audio_position.alpha"] * pe[None, :y.size(1)]], 1)
+    else:
+        y = torch.zeros(1, 0, dtype=torch.long)
+        h = xe
+    y_len = prefix_len = y.size(1)
+    mask = prefix_lm_mask(torch.tensor([x_len]), torch.tensor([y_len]), x_len, y_len)
+    k_cache, v_cache = [None] * nl, [None] * nl
+    all_logits = []
+    idx = 0
+    for idx in range(max_steps):
+        for i in range(nl):
+            p = f"h.layers.{i}."
+            qkv = F.linear(h, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"])
+            if idx == 0:
+                k_cache[i], v_cache[i] = qkv[..., E:2 * E], qkv[..., 2 * E:]
+                a = attention(qkv, mask, H)
+            else:
+                k_cache[i] = torch.cat([k_cache[i], qkv[..., E:2 * E]], 1)
+                v_cache[i] = torch.cat([v_cache[i], qkv[..., 2 * E:]], 1)
+                L_ = k_cache[i].size(1)
+                qh = qkv[..., :E].view(1, 1, H, d).transpose(1, 2)
+                kh = k_cache[i].view(1, L_, H, d).transpose(1, 2)
+                vh = v_cache[i].view(1, L_, H, d).transpose(1, 2)
+                w = F.softmax(torch.matmul(qh, kh.transpose(-2, -1)) / math.sqrt(d), dim=-1)
+                a = torch.matmul(w, vh).transpose(1, 2).reshape(1, 1, E)
+            sa = F.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+            h = F.layer_norm(h + sa, (E,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+            ff = F.linear(F.relu(F.linear(h, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
+                          sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+            h = F.layer_norm(h + ff, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+        logits = F.linear(h[:, -1], sd["ar_predict_layer.weight"])
+        if idx < 11:
+            logits = logits[:, :-1]
+        all_logits.append(logits.clone())
+        probs = logits_to_probs(logits, y, temperature, top_k, top_p, repetition_penalty)
+        tok = torch.argmax(probs / q[idx, :probs.size(-1)], dim=-1, keepdim=True)
+        y = torch.cat([y, tok], 1)
+        stop = early_stop_num != -1 and (y.size(1) - prefix_len) > early_stop_num
+        if int(torch.argmax(logits, dim=-1)[0]) == EOS or int(tok[0, 0]) == EOS:
+            stop = True
+        if stop:
+            break
+        ye = F.embedding(y[:, -1:], sd["ar_audio_embedding.word_embeddings.weight"])
+        h = ye + sd["ar_audio_position.alpha"] * pe[None, y_len + idx:y_len + idx + 1]
+    return y[:, :-1], (0 if prompts is None else idx - 1), all_logits
 
 
 class ScaledAdamRef:

@@ -11,6 +11,7 @@ from oracle import refshim  # noqa: E402
 
 refshim.install()
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 from util_fill import fill_module, s1_batch  # noqa: E402
 
 
@@ -136,8 +137,63 @@ def make_s1_dpo():
     print("wrote", path)
 
 
+from make_golden_s1_inputs import infer_inputs  # noqa: E402
+
+
+INFER_CASES = [dict(top_k=15, top_p=1, temperature=1.0, repetition_penalty=1.35, early_stop_num=40, prompt=True),
+               dict(top_k=5, top_p=0.8, temperature=0.7, repetition_penalty=1.2, early_stop_num=25, prompt=True),
+               dict(top_k=15, top_p=1, temperature=1.0, repetition_penalty=1.35, early_stop_num=20, prompt=False)]
+
+
+def make_s1_infer():
+    """KV-cache decoding (Text2SemanticDecoder.infer_panel_naive, t2s_model.py:762-863) of the reference's own module.
+    The only stand-in: the exponential noise of multinomial_sample_one_no_sync (models/utils.py:118-122) comes from a
+    seeded table q[step] instead of the global generator, so the token sequence is reproducible on any device."""
+    import yaml
+    from src.easevoice.soundstorm.auto_reg.models import t2s_model as TM
+    from src.easevoice.soundstorm.auto_reg.models import utils as U
+
+    torch.set_num_threads(8)
+    cfg = yaml.safe_load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "gpt.yaml")))
+    model = TM.Text2SemanticDecoder(config=cfg, top_k=3)
+    fill_module(model, 3)
+    model.eval()
+    d = infer_inputs()
+    state = dict(step=0, logits=[])
+
+    def sample_one(probs):
+        qrow = d["q"][state["step"], :probs.size(-1)]
+        state["step"] += 1
+        return torch.argmax(probs / qrow, dim=-1, keepdim=True).to(dtype=torch.int)
+
+    orig_one, orig_l2p = U.multinomial_sample_one_no_sync, U.logits_to_probs
+
+    def l2p(logits, previous_tokens=None, **kw):
+        state["logits"].append(logits.detach().clone())        # before the in-place repetition penalty
+        return orig_l2p(logits=logits, previous_tokens=previous_tokens, **kw)
+
+    U.multinomial_sample_one_no_sync, U.logits_to_probs = sample_one, l2p
+    cases = []
+    try:
+        with torch.no_grad():
+            for c in INFER_CASES:
+                state["step"], state["logits"] = 0, []
+                kw = {k: v for k, v in c.items() if k != "prompt"}
+                y, idx = model.infer_panel_naive(d["x"], torch.tensor([24]), d["prompts"] if c["prompt"] else None,
+                                                 d["bert"], **kw)
+                cases.append(dict(args=c, y=y.clone(), idx=int(idx), steps=state["step"],
+                                  logits0=state["logits"][0][0].clone(), logits7=state["logits"][7][0].clone(),
+                                  logits_last=state["logits"][-1][0].clone()))
+                print(c, "->", tuple(y.shape), "idx", idx, "steps", state["step"], "tail", y[0, -6:].tolist())
+    finally:
+        U.multinomial_sample_one_no_sync, U.logits_to_probs = orig_one, orig_l2p
+    torch.save(dict(cases=cases), os.path.join(HERE, "s1_infer.pt"))
+
+
 if __name__ == "__main__":
-    if "dpo" in sys.argv[1:]:
+    if "infer" in sys.argv[1:]:
+        make_s1_infer()
+    elif "dpo" in sys.argv[1:]:
         make_s1_dpo()
     else:
         make_s1()

@@ -1,6 +1,7 @@
 """CPU: the oracle restatement (oracle/s2_step.py) is pinned against fixtures generated from the REFERENCE's own
 modules (tests/golden/s2_c1.pt).  This is what makes the oracle trustworthy as the checker for arbitrary sizes."""
 import json
+import sys
 import os
 
 import torch
@@ -106,6 +107,27 @@ def test_oracle_s1_dpo_matches_reference_fixture():
         grads = torch.autograd.grad(loss, [sd[n] for n in names])
         for n, g in zip(names, grads):
             assert rel(g.flatten()[:96], gold["grad_slices"][n]) < 2e-3, (c["seed"], n)
+
+
+def test_oracle_s1_decoding_matches_reference_fixture():
+    """KV-cache decoding: same token sequences as the reference's infer_panel_naive for the same noise table"""
+    import yaml
+    from oracle import s1_step as OS
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden_s1_inputs import infer_inputs
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    keys = json.load(open(os.path.join(HERE, "golden", "state_dict_keys.json")))
+    sd = _filled(keys["s1"], 3)
+    d = infer_inputs()
+    with torch.no_grad():
+        for gold in torch.load(os.path.join(HERE, "golden", "s1_infer.pt"), weights_only=False)["cases"]:
+            a = dict(gold["args"])
+            prompt = d["prompts"] if a.pop("prompt") else None
+            y, idx, logits = OS.infer_panel_naive(sd, cfg, d["x"], prompt, d["bert"], d["q"], **a)
+            assert rel(logits[0][0], gold["logits0"]) < 1e-4 and rel(logits[7][0], gold["logits7"]) < 1e-4
+            assert torch.equal(y, gold["y"].long()) and idx == gold["idx"] and len(logits) == gold["steps"]
+            assert rel(logits[-1][0], gold["logits_last"]) < 1e-4
 
 
 def test_oracle_scaled_adam_matches_reference_trajectory():
