@@ -1,0 +1,226 @@
+"""KV-cache decoding of the s1 model: Text2SemanticDecoder.infer_panel_naive,
+src/easevoice/soundstorm/auto_reg/models/t2s_model.py:762-863, with T2SBlock.process_prompt / decode_next_token
+(:124-222) and sample() (models/utils.py:118-171).
+
+Same token sequence as the reference for the same sampling noise; a different execution plan:
+  * prompt pass: the training kernels without gradients (packed qkv GEMM, analytic prefix-LM flash attention, fused
+    residual+LayerNorm); its keys/values are copied once into a preallocated cache [layers][B][Lmax][E];
+  * token steps: five launches per block (csrc/s1_decode.hip) + logits + sampling + embedding + counter update, all reading
+    their per-step state (cache length, step index, token count) from device memory, captured once into a HIP graph and
+    replayed per token.  The host reads the stop flag every `poll` steps; tokens decoded past the stop are discarded.
+The reference reads two device scalars per token (the EOS tests of :846) and reallocates every cache tensor per token."""
+import ctypes as C
+import os
+
+import torch
+from torch.nn import functional as F
+
+from ..hip import lib as L
+from .ops import AddLayerNormFn, PrefixLMAttentionFn
+
+MAX_STEPS = 1500          # t2s_model.py:822
+NO_EOS_STEPS = 11         # t2s_model.py:833
+
+
+class _Weights:
+    """per-block matrices in the streaming dtype (fp32 parameters as they are, or one-time bf16 copies), vectors fp32"""
+
+    def __init__(self, model, dtype):
+        self.stamp = self.stamp_of(model)
+        cv = (lambda t: t.detach().contiguous()) if dtype == torch.float32 else (lambda t: t.detach().to(dtype).contiguous())
+        f32 = lambda t: t.detach().float().contiguous()
+        self.layers = []
+        for lyr in model.h.layers:
+            a = lyr.self_attn
+            self.layers.append(dict(
+                wqkv=cv(a.in_proj_weight), bqkv=f32(a.in_proj_bias), wo=cv(a.out_proj.weight), bo=f32(a.out_proj.bias),
+                w1=cv(lyr.linear1.weight), b1=f32(lyr.linear1.bias), w2=cv(lyr.linear2.weight), b2=f32(lyr.linear2.bias),
+                g1=f32(lyr.norm1.weight), be1=f32(lyr.norm1.bias), g2=f32(lyr.norm2.weight), be2=f32(lyr.norm2.bias),
+                eps1=float(lyr.norm1.eps), eps2=float(lyr.norm2.eps)))
+        self.wpred = cv(model.ar_predict_layer.weight)
+        self.emb = f32(model.ar_audio_embedding.word_embeddings.weight)
+        self.alpha = f32(model.ar_audio_position.alpha)
+
+    @staticmethod
+    def stamp_of(model):
+        return tuple(p._version for p in model.parameters()) + tuple(p.data_ptr() for p in model.parameters())
+
+
+class DecodeSession:
+    """static buffers + the captured step graph for one (batch, cache capacity, dtype)"""
+
+    def __init__(self, model, B, Lmax, ymax, dtype, device):
+        self.model, self.B, self.Lmax, self.ymax, self.dtype, self.device = model, B, Lmax, ymax, dtype, device
+        E, nl, V = model.model_dim, model.num_layers, model.vocab_size
+        self.E, self.H, self.nl, self.V = E, model.num_head, nl, V
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
+        self.kc = z(nl, B, Lmax, E, dt=dtype)
+        self.vc = z(nl, B, Lmax, E, dt=dtype)
+        self.xa, self.xb = z(B, E), z(B, E)
+        self.qkv, self.att, self.t, self.u = z(B, 3 * E), z(B, E), z(B, E), z(B, E)
+        self.hid = z(B, 4 * E)
+        self.logits = z(B, V)
+        self.y = z(B, ymax, dt=torch.int64)
+        self.ctr = z(8, dt=torch.int32)
+        self.stop = torch.full((B,), -1, dtype=torch.int32, device=device)
+        self.graph, self.graph_key = None, None
+
+    # ---- launches ----
+    def _gemv(self, w, bias, a, r, g, b, eps, x_out, y, relu=0):
+        N, K = w.shape
+        L.check(L.lib().evt_dec_gemv(L.dt_of(w), L.ptr(w), L.ptr(bias), L.ptr(a), L.ptr(r), L.ptr(g), L.ptr(b),
+                                     C.c_float(eps), L.ptr(x_out), L.ptr(y), self.B, N, K, int(relu), L.stream_ptr()),
+                "evt_dec_gemv")
+
+    def _sample(self, sp, noise):
+        L.check(L.lib().evt_dec_sample(C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise),
+                                       L.ptr(self.stop), None, self.B, L.stream_ptr()), "evt_dec_sample")
+
+    def _embed_advance(self, W, pe, dpos):
+        lib = L.lib()
+        L.check(lib.evt_dec_embed(L.ptr(W.emb), L.ptr(pe), L.ptr(W.alpha), C.c_float(self.model.ar_audio_position.x_scale),
+                                  L.ptr(self.y), L.ptr(self.ctr), L.ptr(self.xa), self.B, self.E, self.ymax, pe.size(0),
+                                  L.stream_ptr()), "evt_dec_embed")
+        L.check(lib.evt_dec_advance(L.ptr(self.ctr), dpos, L.stream_ptr()), "evt_dec_advance")
+
+    def step_launches(self, W, sp, noise, pe):
+        """one token: 24 x (qkv, attention, out-proj, ffn1, ffn2) + logits + sample + embed + counters"""
+        lib = L.lib()
+        prev = None
+        for i, w in enumerate(W.layers):
+            if prev is None:
+                self._gemv(w["wqkv"], w["bqkv"], self.xa, None, None, None, 0.0, None, self.qkv)
+            else:       # input = LayerNorm2 of the previous block, stored to xa for this block's first residual
+                self._gemv(w["wqkv"], w["bqkv"], self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], self.xa, self.qkv)
+            L.check(lib.evt_dec_attn(L.dt_of(self.kc), L.ptr(self.qkv), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
+                                     L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
+                                     L.stream_ptr()), "evt_dec_attn")
+            self._gemv(w["wo"], w["bo"], self.att, None, None, None, 0.0, None, self.t)
+            self._gemv(w["w1"], w["b1"], self.xa, self.t, w["g1"], w["be1"], w["eps1"], self.xb, self.hid, relu=1)
+            self._gemv(w["w2"], w["b2"], self.hid, None, None, None, 0.0, None, self.u)
+            prev = w
+        self._gemv(W.wpred, None, self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], None, self.logits)
+        self._sample(sp, noise)
+        self._embed_advance(W, pe, 1)
+
+
+class T2SInfer:
+    """decoder front end bound to one Text2SemanticDecoder; `infer_panel_naive` has the reference's signature"""
+
+    def __init__(self, model):
+        self.model = model
+        self._w, self._sessions = None, {}
+
+    def weights(self, dtype):
+        if self._w is None or self._w[0] != dtype or self._w[1].stamp != _Weights.stamp_of(self.model):
+            self._w = (dtype, _Weights(self.model, dtype))
+            self._sessions.clear()          # captured graphs hold pointers into the old copies
+        return self._w[1]
+
+    def session(self, B, Lneed, yneed, dtype, device):
+        Lmax, ymax = -(-Lneed // 512) * 512, -(-yneed // 512) * 512
+        key = (B, Lmax, ymax, dtype, str(device))
+        if key not in self._sessions:
+            self._sessions[key] = DecodeSession(self.model, B, Lmax, ymax, dtype, device)
+        return self._sessions[key]
+
+    @torch.no_grad()
+    def infer_panel_naive(self, x, x_lens, prompts, bert_feature, top_k=-100, top_p=100, early_stop_num=-1,
+                          temperature=1.0, repetition_penalty=1.35, noise=None, seed=None, poll=8, **kwargs):
+        m = self.model
+        if m.training:
+            raise L.EvtError("infer_panel_naive needs model.eval() (the reference decodes with dropout off)")
+        dev, cd = x.device, m.cd
+        B, x_len = x.shape
+        if B != 1:
+            raise L.EvtError("one sequence per call (infer_panel_naive_batched loops over the items, t2s_model.py:732-760)")
+        W = self.weights(cd)
+        # ---- prompt pass (t2s_model.py:775-825, T2SBlock.process_prompt) ----
+        xe = m.ar_text_embedding(x)
+        xe = xe + F.linear(bert_feature.transpose(1, 2).to(cd), m.bert_proj.weight.to(cd), m.bert_proj.bias.to(cd)).to(xe.dtype)
+        xe = m.ar_text_position(xe)
+        ref_free = prompts is None
+        if ref_free:
+            y_len, xy = 0, xe
+        else:
+            y_len = prompts.size(1)
+            xy = torch.cat([xe, m.ar_audio_position(m.ar_audio_embedding(prompts))], dim=1)
+        xy = xy.to(cd).contiguous()
+        src_len = x_len + y_len
+        n_max = MAX_STEPS if early_stop_num == -1 else max(1, min(MAX_STEPS, int(early_stop_num) + 1))
+        S = self.session(B, src_len + n_max + 1, y_len + n_max + 1, cd, dev)
+        xl = torch.full((B,), x_len, dtype=torch.int32, device=dev)
+        yl = torch.full((B,), y_len, dtype=torch.int32, device=dev)
+        for i, lyr in enumerate(m.h.layers):
+            w = W.layers[i]
+            qkv = F.linear(xy, lyr.self_attn.in_proj_weight.to(cd), lyr.self_attn.in_proj_bias.to(cd)).contiguous()
+            S.kc[i, :, :src_len].copy_(qkv[..., S.E:2 * S.E])
+            S.vc[i, :, :src_len].copy_(qkv[..., 2 * S.E:])
+            o = PrefixLMAttentionFn.apply(qkv, xl, yl, x_len, S.H, 0.0, 0)
+            sa = F.linear(o, lyr.self_attn.out_proj.weight.to(cd), lyr.self_attn.out_proj.bias.to(cd))
+            xy = AddLayerNormFn.apply(xy, sa, w["g1"], w["be1"], w["eps1"])
+            ff = F.linear(F.relu(F.linear(xy, lyr.linear1.weight.to(cd), lyr.linear1.bias.to(cd))),
+                          lyr.linear2.weight.to(cd), lyr.linear2.bias.to(cd))
+            xy = AddLayerNormFn.apply(xy, ff, w["g2"], w["be2"], w["eps2"])
+        # ---- state ----
+        S.y.zero_()
+        if not ref_free:
+            S.y[:, :y_len].copy_(prompts)
+        # the sampling seed is device state like the counters (a new one per call must not force a re-capture); without
+        # an explicit seed it is drawn from torch's CPU generator, so torch.manual_seed makes a run repeatable
+        seed = int(seed if seed is not None else torch.randint(0, 2 ** 31 - 1, (1,)).item()) & 0x7FFFFFFF
+        S.ctr.copy_(torch.tensor([src_len, 0, y_len, y_len, seed, 0, 0, 0], dtype=torch.int32))
+        S.stop.fill_(-1)
+        sp = L.SampleParams(S.V, m.EOS, int(top_k) if top_k is not None else 0, NO_EOS_STEPS, S.ymax, float(top_p),
+                            float(temperature), float(repetition_penalty), 0x5EED5EED)
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+            assert noise.dim() == 2 and noise.size(1) == S.V and noise.size(0) >= n_max
+        pe = m.ar_audio_position.pe(max(4000, y_len + n_max + 1), dev, torch.float32).contiguous()
+        # ---- step 0: logits of the last prompt position, sample, embed ----
+        S.xb.copy_(xy[:, -1].float())
+        S._gemv(W.wpred, None, S.xb, None, None, None, 0.0, None, S.logits)
+        S._sample(sp, noise)
+        S._embed_advance(W, pe, 0)
+        # ---- token steps: one graph replay each ----
+        use_graph = os.environ.get("EVT_DECODE_GRAPH", "1") != "0"
+        gkey = (bytes(sp), None if noise is None else noise.data_ptr(), pe.data_ptr(), id(W))
+        if use_graph and S.graph_key != gkey:
+            # warm-up launches outside the capture, on throw-away counters: restore the state afterwards
+            keep = (S.ctr.clone(), S.y.clone(), S.stop.clone(), S.xa.clone())
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                S.step_launches(W, sp, noise, pe)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                S.step_launches(W, sp, noise, pe)
+            S.ctr.copy_(keep[0]); S.y.copy_(keep[1]); S.stop.copy_(keep[2]); S.xa.copy_(keep[3])
+            S.graph, S.graph_key, S._keep = g, gkey, (sp, noise, pe, W)
+        done = 1
+        stop_at = int(S.stop[0]) if n_max == 1 else -1
+        while done < n_max and stop_at < 0:
+            if use_graph:
+                S.graph.replay()
+            else:
+                S.step_launches(W, sp, noise, pe)
+            done += 1
+            if done % poll == 0 or done == n_max:
+                stop_at = int(S.stop[0])            # the only device->host read of the loop
+        if stop_at < 0:
+            stop_at = n_max - 1                     # early_stop_num reached, or 1500 steps without EOS
+        total = y_len + stop_at + 1
+        y = S.y[:, :total].clone()
+        if ref_free:
+            return y[:, :-1].to(torch.int32), 0
+        return y[:, :-1], stop_at - 1
+
+    def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, **kw):
+        ys, idxs = [], []
+        for i in range(len(x)):
+            y, idx = self.infer_panel_naive(x[i].unsqueeze(0), x_lens[i], prompts[i].unsqueeze(0) if prompts is not None
+                                            else None, bert_feature[i].unsqueeze(0), **kw)
+            ys.append(y[0])
+            idxs.append(idx)
+        return ys, idxs

@@ -9,8 +9,8 @@ TransformerEncoder / TransformerEncoderLayer (modules/transformer.py:106-339), M
     (x_len, x_lens, y_lens);
   * post-LN residuals, cross-entropy(sum) + top-3 accuracy are single fused HIP launches;
   * Linear layers are plain GEMMs (hipBLASLt via F.linear) in the compute dtype.
-`forward` is the DPO branch (t2s_model.py:393-429), `forward_old` the plain one the default config trains with.
-There is no inference path here.
+`forward` is the DPO branch (t2s_model.py:393-429), `forward_old` the plain one the default config trains with;
+`infer_panel*` (KV-cache decoding, t2s_model.py:732-878) lives in t2s_infer.py.
 """
 import math
 
@@ -213,3 +213,21 @@ class Text2SemanticDecoder(nn.Module):
         loss = row.sum() + dpo_loss(chosen_logps, rejected_logps, 0.2)
         acc = hits[0].float() / hits[1].clamp(min=1).float()
         return loss, acc
+
+    # ---- inference (t2s_model.py:732-878): KV-cache decoding, see t2s_infer.py ----
+    def _infer(self):
+        if getattr(self, "_infer_front", None) is None:
+            from .t2s_infer import T2SInfer
+            object.__setattr__(self, "_infer_front", T2SInfer(self))
+        return self._infer_front
+
+    def infer_panel_naive(self, x, x_lens, prompts, bert_feature, top_k=-100, top_p=100, early_stop_num=-1,
+                          temperature=1.0, repetition_penalty=1.35, **kwargs):
+        return self._infer().infer_panel_naive(x, x_lens, prompts, bert_feature, top_k=top_k, top_p=top_p,
+                                               early_stop_num=early_stop_num, temperature=temperature,
+                                               repetition_penalty=repetition_penalty, **kwargs)
+
+    infer_panel = infer_panel_naive
+
+    def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, **kwargs):
+        return self._infer().infer_panel_naive_batched(x, x_lens, prompts, bert_feature, **kwargs)

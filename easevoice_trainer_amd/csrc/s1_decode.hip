@@ -1,0 +1,430 @@
+// s1 KV-cache decoding step (Text2SemanticDecoder.infer_panel_naive, t2s_model.py:762-863; T2SBlock.decode_next_token
+// :186-222; sample / logits_to_probs, models/utils.py:118-160) for gfx950.
+//
+// One decoded token is a chain of batch-1 matrix-vector products over ~150 MB of weights plus attention over a growing
+// key/value cache: HBM- and launch-bound, nothing for MFMA.  Laid out so that NOTHING about a step is a host argument:
+//   * the key/value cache is preallocated [B][Lmax][E] and the current length lives in device memory (ctr[POS]) -- the
+//     reference grows it with torch.cat every step;
+//   * the step index, the number of generated tokens, the prompt length and the sampling seed are device state too
+//     (ctr[IDX|YCOUNT|YLEN|SEED]);
+//   * sampling (repetition penalty, nucleus cut, temperature, top-k, softmax, exponential-noise argmax), the EOS test,
+//     the append to the token buffer and the embedding of the new token all run on the device.
+// So the ~125 launches of a step are captured once into a HIP graph and replayed per token; the host only polls the stop
+// flag every few steps.
+//   dec_gemv   y = act(W . LN(a + r) + b): the post-LN residual of the previous sub-block is recomputed by every block in
+//              its prologue (512 values) instead of being a launch of its own; block 0 stores it for the next residual.
+//   dec_attn   one block per (batch, head): appends the new key/value to the cache, softmax(q.K/sqrt(d)).V over it.
+//   dec_sample one block per batch row, 1024 threads, whole vocabulary (1025) in LDS, bitonic sort for the nucleus /
+//              top-k pivots.
+#include "evt_common.h"
+#include "../../include/evt.h"
+
+namespace {
+
+constexpr int kMaxB = 4;
+
+__device__ __forceinline__ float block_sum(float v, float* red, int nwaves) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nwaves; ++i) s += red[i];
+  return s;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red, int nwaves) {
+  v = wave_reduce_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = -INFINITY;
+  for (int i = 0; i < nwaves; ++i) s = fmaxf(s, red[i]);
+  return s;
+}
+
+// (value, index) argmax with the FIRST index among equal values (torch.argmax on CPU); all threads get the result
+__device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* redi, int nwaves) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { redv[w] = v; redi[w] = i; }
+  __syncthreads();
+  float bv = redv[0];
+  int bi = redi[0];
+  for (int k = 1; k < nwaves; ++k)
+    if (redv[k] > bv || (redv[k] == bv && redi[k] < bi)) { bv = redv[k]; bi = redi[k]; }
+  return bi;
+}
+
+template <typename T> struct WVec { static constexpr int V = 16 / sizeof(T); };
+
+// ---- y[b][n] = act(bias[n] + sum_k W[n][k] * x[b][k]),  x = a  or  LayerNorm(a + r) --------------------------------
+template <typename T, int RPW>
+__global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const float* __restrict__ bias,
+                                                const float* __restrict__ a, const float* __restrict__ r,
+                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                float eps, float* x_out, float* __restrict__ y, int B, int N, int K,
+                                                int relu) {
+  extern __shared__ float xs[];   // [B][K]
+  __shared__ float red[4];
+  constexpr int V = WVec<T>::V;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = 0; b < B; ++b)
+    for (int k = tid; k < K; k += 256) xs[b * K + k] = a[b * K + k] + (r ? r[b * K + k] : 0.f);
+  __syncthreads();
+  if (r) {
+    for (int b = 0; b < B; ++b) {
+      float s = 0.f;
+      for (int k = tid; k < K; k += 256) s += xs[b * K + k];
+      const float mu = block_sum(s, red, 4) / K;
+      float q = 0.f;
+      for (int k = tid; k < K; k += 256) { const float d = xs[b * K + k] - mu; q += d * d; }
+      const float rs = rsqrtf(block_sum(q, red, 4) / K + eps);
+      for (int k = tid; k < K; k += 256) {
+        const float v = (xs[b * K + k] - mu) * rs * ln_g[k] + ln_b[k];
+        xs[b * K + k] = v;
+        if (x_out && blockIdx.x == 0) x_out[b * K + k] = v;
+      }
+    }
+    __syncthreads();
+  }
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  float acc[RPW][kMaxB];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int b = 0; b < kMaxB; ++b) acc[i][b] = 0.f;
+  for (int k0 = lane * V; k0 < K; k0 += 64 * V) {
+    uint4 w[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int n = n0 + i;
+      w[i] = n < N ? *reinterpret_cast<const uint4*>(W + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < kMaxB; ++b) {
+      if (b >= B) break;
+      float xv[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) xv[e] = xs[b * K + k0 + e];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const T* pw = reinterpret_cast<const T*>(&w[i]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[i][b] += to_f<T>(pw[e]) * xv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int b = 0; b < kMaxB; ++b) {
+      if (b >= B) break;
+      const float s = wave_reduce_sum(acc[i][b]);
+      const int n = n0 + i;
+      if (lane == 0 && n < N) {
+        float v = s + (bias ? bias[n] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        y[(long)b * N + n] = v;
+      }
+    }
+}
+
+// ---- append (k, v) of the new token to the cache, attend over all cached positions -------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T* kc, T* vc, const int* __restrict__ ctr,
+                                                float* __restrict__ out, int H, int Lmax) {
+  extern __shared__ float sc[];   // [Lmax] scores -> probabilities
+  __shared__ float qs[D], kn[D], vn[D], red[4], part[256 / D][D];
+  constexpr int V = WVec<T>::V;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * D;
+  const int pos = ctr[EVT_DEC_POS];
+  if (pos >= Lmax) return;            // cache full: the host bounds the number of steps, this only guards memory
+  const int L = pos + 1;
+  if (tid < D) {
+    const float* base = qkv + (long)b * 3 * E + h * D + tid;
+    qs[tid] = base[0] * rsqrtf((float)D);
+    const T kq = from_f<T>(base[E]), vq = from_f<T>(base[2 * E]);
+    kn[tid] = to_f<T>(kq);
+    vn[tid] = to_f<T>(vq);
+    kc[((long)b * Lmax + pos) * E + h * D + tid] = kq;
+    vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < L; j += 256) {
+    float s = 0.f;
+    if (j == pos) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
+    } else {
+      const T* row = kc + ((long)b * Lmax + j) * E + h * D;
+#pragma unroll
+      for (int d0 = 0; d0 < D; d0 += V) {
+        const uint4 u = *reinterpret_cast<const uint4*>(row + d0);
+        const T* pu = reinterpret_cast<const T*>(&u);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += qs[d0 + e] * to_f<T>(pu[e]);
+      }
+    }
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_max(mx, red, 4);
+  float sum = 0.f;
+  for (int j = tid; j < L; j += 256) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, red, 4);      // its barriers also publish sc[]
+  constexpr int G = 256 / D;
+  const int g = tid / D, d = tid % D;
+  float acc = 0.f;
+  for (int j = g; j < L; j += G) {
+    const float v = j == pos ? vn[d] : to_f<T>(vc[((long)b * Lmax + j) * E + h * D + d]);
+    acc += sc[j] * v;
+  }
+  part[g][d] = acc;
+  __syncthreads();
+  if (tid < D) {
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) o += part[i][tid];
+    out[(long)b * E + h * D + tid] = o / sum;
+  }
+}
+
+// ---- sampling ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32s(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ bool before(float av, int ai, float bv, int bi) {   // descending value, ascending index
+  return av > bv || (av == bv && ai < bi);
+}
+
+constexpr int kSortN = 2048;
+
+__global__ __launch_bounds__(1024) void dec_sample(evt_sample_params p, const float* __restrict__ logits, long* y,
+                                                   const int* __restrict__ ctr, const float* __restrict__ noise,
+                                                   int* stop_idx, float* probs_out) {
+  __shared__ float sv[kSortN];
+  __shared__ int si[kSortN];
+  __shared__ float cur[kSortN];
+  __shared__ unsigned char flag[kSortN];
+  __shared__ float redv[16];
+  __shared__ int redi[16];
+  __shared__ float wsum[16];
+  const int tid = threadIdx.x, b = blockIdx.x, V = p.V;
+  const int idx = ctr[EVT_DEC_IDX], ycount = ctr[EVT_DEC_YCOUNT];
+  const int Ve = idx < p.no_eos_steps ? V - 1 : V;     // "at least 10 tokens otherwise not stop", t2s_model.py:833
+  const float* lg = logits + (long)b * V;
+  long* yb = y + (long)b * p.ymax;
+  for (int v = tid; v < kSortN; v += 1024) flag[v] = 0;
+  __syncthreads();
+  if (p.repetition_penalty != 1.0f)
+    for (int j = tid; j < ycount; j += 1024) {
+      const long t = yb[j];
+      if (t >= 0 && t < Ve) flag[t] = 1;
+    }
+  __syncthreads();
+  float bvv = -INFINITY;
+  int bii = 0x7fffffff;
+  for (int v = tid; v < kSortN; v += 1024) {
+    float x = -INFINITY;
+    if (v < Ve) {
+      x = lg[v];
+      if (flag[v]) x = x < 0.f ? x * p.repetition_penalty : x / p.repetition_penalty;
+      if (x > bvv || (x == bvv && v < bii)) { bvv = x; bii = v; }
+    }
+    cur[v] = x;
+    sv[v] = x;
+    si[v] = v;
+  }
+  // argmax of the (penalised, in place in the reference) logits: the EOS test of t2s_model.py:846
+  const int amax = block_argmax(bvv, bii, redv, redi, 16);
+  // bitonic sort, descending
+  for (int k = 2; k <= kSortN; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      const int i = 2 * j * (tid / j) + (tid % j), l = i + j;
+      const bool up = (i & k) == 0;
+      const float av = sv[i], bv = sv[l];
+      const int ai = si[i], bi = si[l];
+      const bool in_order = before(av, ai, bv, bi);
+      if (in_order != up) { sv[i] = bv; sv[l] = av; si[i] = bi; si[l] = ai; }
+    }
+  __syncthreads();
+  if (p.top_p < 1.0f) {
+    // cumulative softmax over the sorted logits; entries past the nucleus are removed, the first is always kept
+    const float m = sv[0];
+    const float e0 = expf(sv[2 * tid] - m), e1 = expf(sv[2 * tid + 1] - m);
+    float run = e0 + e1;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(run, o, 64);
+      if (lane >= o) run += t;
+    }
+    if (lane == 63) wsum[w] = run;
+    __syncthreads();
+    float offs = 0.f, total = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      if (i < w) offs += wsum[i];
+      total += wsum[i];
+    }
+    const float c1 = (offs + run) / total, c0 = (offs + run - e1) / total;
+    if (2 * tid > 0 && c0 > p.top_p && si[2 * tid] < Ve) cur[si[2 * tid]] = -INFINITY;
+    if (c1 > p.top_p && si[2 * tid + 1] < Ve) cur[si[2 * tid + 1]] = -INFINITY;
+    __syncthreads();
+  }
+  const float tdiv = fmaxf(p.temperature, 1e-5f);
+  float pivot = -INFINITY;
+  if (p.top_k > 0) {
+    const int kk = p.top_k < Ve ? p.top_k : Ve;
+    pivot = cur[si[kk - 1]] / tdiv;
+  }
+  float x0[2], mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = tid + u * 1024;
+    float x = -INFINITY;
+    if (v < Ve) {
+      x = cur[v] / tdiv;
+      if (x < pivot) x = -INFINITY;
+    }
+    x0[u] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = block_max(mx, redv, 16);
+  float e[2], sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    e[u] = x0[u] == -INFINITY ? 0.f : expf(x0[u] - mx);
+    sum += e[u];
+  }
+  sum = block_sum(sum, redv, 16);
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = tid + u * 1024;
+    if (v < Ve) {
+      const float pr = e[u] / sum;
+      if (probs_out) probs_out[(long)b * V + v] = pr;
+      float q;
+      if (noise) {
+        q = noise[(long)idx * V + v];
+      } else {
+        const unsigned hsh =
+            mix32s(mix32s((p.seed ^ (unsigned)ctr[EVT_DEC_SEED]) + (unsigned)idx * 0x9E3779B9u) ^ ((unsigned)b << 16) ^ (unsigned)v);
+        q = -logf(((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f));
+      }
+      const float s = pr / q;
+      if (s > best || (s == best && v < besti)) { best = s; besti = v; }
+    } else if (probs_out && v < V) {
+      probs_out[(long)b * V + v] = 0.f;
+    }
+  }
+  const int tok = block_argmax(best, besti, redv, redi, 16);
+  if (tid == 0) {
+    if (ycount < p.ymax) yb[ycount] = tok;
+    if ((amax == p.eos || tok == p.eos) && stop_idx[b] < 0) stop_idx[b] = idx;
+  }
+}
+
+// ---- x_next = emb[token] * x_scale + alpha * pe[y_len + idx]  (t2s_model.py:860-861) ----------------------------
+__global__ __launch_bounds__(256) void dec_embed(const float* __restrict__ emb, const float* __restrict__ pe,
+                                                 const float* __restrict__ alpha, float x_scale,
+                                                 const long* __restrict__ y, const int* __restrict__ ctr,
+                                                 float* __restrict__ x, int E, int ymax, int npos) {
+  const int b = blockIdx.x;
+  const int idx = ctr[EVT_DEC_IDX], ycount = ctr[EVT_DEC_YCOUNT], ylen = ctr[EVT_DEC_YLEN];
+  const long tok = y[(long)b * ymax + (ycount < ymax ? ycount : ymax - 1)];
+  int ppos = ylen + idx;
+  if (ppos >= npos) ppos = npos - 1;
+  const float al = alpha[0];
+  for (int c = threadIdx.x; c < E; c += 256) x[(long)b * E + c] = emb[tok * E + c] * x_scale + al * pe[(long)ppos * E + c];
+}
+
+__global__ void dec_advance(int* ctr, int dpos) {
+  ctr[EVT_DEC_POS] += dpos;
+  ctr[EVT_DEC_IDX] += 1;
+  ctr[EVT_DEC_YCOUNT] += 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* a, const float* r, const float* ln_g,
+                 const float* ln_b, float ln_eps, float* x_out, float* y, int32_t B, int32_t N, int32_t K, int32_t relu,
+                 void* stream) {
+  if (!W || !a || !y || B <= 0 || N <= 0 || K <= 0) return EVT_EINVAL;
+  if (r && (!ln_g || !ln_b)) return EVT_EINVAL;
+  if (B > kMaxB || K % 512 || (size_t)B * K * 4 > 64 * 1024) return EVT_ENOTSUP;
+  constexpr int RPW = 2;
+  const int blocks = (N + 4 * RPW - 1) / (4 * RPW);
+  const size_t shm = (size_t)B * K * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (wdtype == EVT_DT_BF16)
+    hipLaunchKernelGGL((dec_gemv<bf16_t, RPW>), dim3(blocks), dim3(256), shm, st, (const bf16_t*)W, bias, a, r, ln_g,
+                       ln_b, ln_eps, x_out, y, B, N, K, relu);
+  else if (wdtype == EVT_DT_F32)
+    hipLaunchKernelGGL((dec_gemv<float, RPW>), dim3(blocks), dim3(256), shm, st, (const float*)W, bias, a, r, ln_g, ln_b,
+                       ln_eps, x_out, y, B, N, K, relu);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
+                 int32_t H, int32_t D, int32_t Lmax, void* stream) {
+  if (!qkv || !kcache || !vcache || !ctr || !out || B <= 0 || H <= 0 || Lmax <= 0) return EVT_EINVAL;
+  if (D != 32 || (size_t)Lmax * 4 > 60 * 1024) return EVT_ENOTSUP;
+  const size_t shm = (size_t)Lmax * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (cdtype == EVT_DT_BF16)
+    hipLaunchKernelGGL((dec_attn<bf16_t, 32>), dim3(B * H), dim3(256), shm, st, qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                       (const int*)ctr, out, H, Lmax);
+  else if (cdtype == EVT_DT_F32)
+    hipLaunchKernelGGL((dec_attn<float, 32>), dim3(B * H), dim3(256), shm, st, qkv, (float*)kcache, (float*)vcache,
+                       (const int*)ctr, out, H, Lmax);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, const int32_t* ctr, const float* noise,
+                   int32_t* stop_idx, float* probs_out, int32_t B, void* stream) {
+  if (!p || !logits || !y || !ctr || !stop_idx || B <= 0) return EVT_EINVAL;
+  if (p->V <= 1 || p->V > kSortN || p->ymax <= 0 || p->repetition_penalty <= 0.f) return EVT_EINVAL;
+  hipLaunchKernelGGL(dec_sample, dim3(B), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (const int*)ctr, noise,
+                     (int*)stop_idx, probs_out);
+  return evt_check_launch();
+}
+
+int evt_dec_embed(const float* emb, const float* pe, const float* alpha, float x_scale, const int64_t* y,
+                  const int32_t* ctr, float* x, int32_t B, int32_t E, int32_t ymax, int32_t npos, void* stream) {
+  if (!emb || !pe || !alpha || !y || !ctr || !x || B <= 0 || E <= 0 || ymax <= 0 || npos <= 0) return EVT_EINVAL;
+  hipLaunchKernelGGL(dec_embed, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, pe, alpha, x_scale, (const long*)y,
+                     (const int*)ctr, x, E, ymax, npos);
+  return evt_check_launch();
+}
+
+int evt_dec_advance(int32_t* ctr, int32_t dpos, void* stream) {
+  if (!ctr) return EVT_EINVAL;
+  hipLaunchKernelGGL(dec_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)ctr, dpos);
+  return evt_check_launch();
+}
+
+}  // extern "C"

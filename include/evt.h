@@ -299,6 +299,49 @@ int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets
 int evt_ce_rows_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
                         int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * s1 KV-cache decoding step (Text2SemanticDecoder.infer_panel_naive, t2s_model.py:762-863).
+ * Every per-step quantity is device state, so the launches of a step take the same arguments for every token and can be
+ * captured into a HIP graph.  ctr is a device int32[8]:
+ * ------------------------------------------------------------------------------------- */
+#define EVT_DEC_POS 0    /* key/value positions already in the cache */
+#define EVT_DEC_IDX 1    /* decode step index (`idx` of t2s_model.py:822) */
+#define EVT_DEC_YCOUNT 2 /* tokens in the y buffer (prompt + generated) */
+#define EVT_DEC_YLEN 3   /* prompt length: the new token's position is YLEN + IDX (t2s_model.py:861) */
+#define EVT_DEC_SEED 4   /* per-call sampling seed, xor-ed with evt_sample_params.seed */
+/* y[b][n] = act(bias[n] + sum_k W[n][k] * x[b][k]); W [N][K] row-major in `wdtype`, vectors fp32, B <= 4, K % 512 == 0.
+ * r == NULL: x = a.  r != NULL: x = LayerNorm(a + r) * ln_g + ln_b (the post-LN residual of T2SBlock.decode_next_token,
+ * t2s_model.py:208-221, recomputed per workgroup); x_out (may be NULL) receives it for the next residual and must not
+ * alias a or r.  relu != 0 applies max(0, .) (T2SMLP.forward, t2s_model.py:74-77). */
+int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* a, const float* r, const float* ln_g,
+                 const float* ln_b, float ln_eps, float* x_out, float* y, int32_t B, int32_t N, int32_t K, int32_t relu,
+                 void* stream);
+/* qkv fp32 [B][3*H*D] of the new token: its key/value are stored at cache position ctr[POS] (kcache/vcache
+ * [B][Lmax][H*D] in `cdtype`) and out[b][h*D+d] = softmax(q.K^T/sqrt(D)).V over positions 0..ctr[POS]
+ * (t2s_model.py:187-204 without the torch.cat growth).  D == 32. */
+int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
+                 int32_t H, int32_t D, int32_t Lmax, void* stream);
+/* sample() of models/utils.py:125-171 for one step: the EOS column is dropped while ctr[IDX] < no_eos_steps
+ * (t2s_model.py:833-834); repetition penalty over y[b][0..ctr[YCOUNT]); nucleus cut (top_p < 1) on the un-tempered
+ * logits; division by max(temperature, 1e-5); top-k pivot (top_k <= 0: off; ties kept); softmax;
+ * token = argmax(probs / q) with q = noise[ctr[IDX]][v] (noise fp32 [steps][V]) or, when noise == NULL, exponential
+ * noise from a counter hash of (seed ^ ctr[SEED], step, b, v).  The token is written to y[b][ctr[YCOUNT]] (y int64 [B][ymax]);
+ * stop_idx[b] (int32, initialised to -1 by the caller) receives the first step at which argmax of the penalised logits
+ * or the token equals eos (t2s_model.py:846).  probs_out (may be NULL) fp32 [B][V]. */
+typedef struct evt_sample_params {
+  int32_t V, eos, top_k, no_eos_steps, ymax;
+  float top_p, temperature, repetition_penalty;
+  uint32_t seed;
+} evt_sample_params;
+int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, const int32_t* ctr, const float* noise,
+                   int32_t* stop_idx, float* probs_out, int32_t B, void* stream);
+/* x[b] = emb[y[b][ctr[YCOUNT]]] * x_scale + alpha[0] * pe[ctr[YLEN] + ctr[IDX]]  (t2s_model.py:860-861); emb fp32
+ * [V][E], pe fp32 [npos][E]. */
+int evt_dec_embed(const float* emb, const float* pe, const float* alpha, float x_scale, const int64_t* y,
+                  const int32_t* ctr, float* x, int32_t B, int32_t E, int32_t ymax, int32_t npos, void* stream);
+/* end of a step: ctr[IDX] += 1, ctr[YCOUNT] += 1, ctr[POS] += dpos (1 after a decode step, 0 after the prompt pass) */
+int evt_dec_advance(int32_t* ctr, int32_t dpos, void* stream);
+
 /* ScaledAdam (src/easevoice/soundstorm/auto_reg/modules/optim.py:206-251,300-390,448-622) over a flat fp32 arena.
  * The reference stacks same-shaped tensors only to batch its torch ops; the arithmetic is per tensor, which is what
  * these two launches implement for ALL tensors at once:

@@ -1,0 +1,203 @@
+"""GPU: the s1 KV-cache decoding step (csrc/s1_decode.hip, auto_reg/t2s_infer.py).
+Kernels against torch fp32 / the oracle's sampling restatement; the whole decode loop against token sequences produced by
+the REFERENCE's infer_panel_naive (tests/golden/s1_infer.pt) with the same sampling-noise table."""
+import ctypes as C
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+from util_fill import fill_module
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 1536, 512), (3, 512, 512), (1, 2048, 512), (2, 512, 2048), (1, 1025, 512)])
+def test_dec_gemv(gpu, dtype, shape):
+    from easevoice_trainer_amd.hip import lib as L
+
+    B, N, K = shape
+    g = torch.Generator().manual_seed(N + K + B)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    bias, a, r = torch.randn(N, generator=g), torch.randn(B, K, generator=g), torch.randn(B, K, generator=g)
+    lg, lb = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    Wg, dev = W.to(gpu), lambda t: t.to(gpu)
+    for use_ln in (False, True) if K == 512 else (False,):
+        for relu in (0, 1):
+            x = F.layer_norm(a + r, (K,), lg, lb, 1e-5) if use_ln else a
+            want = x @ W.float().t() + bias
+            want = want.clamp(min=0) if relu else want
+            y = torch.empty(B, N, device=gpu)
+            xo = torch.full((B, K), -7.0, device=gpu)
+            args = [dev(a), dev(r), dev(lg), dev(lb)] if use_ln else [dev(a), None, None, None]
+            L.check(L.lib().evt_dec_gemv(L.dt_of(Wg), L.ptr(Wg), L.ptr(dev(bias)), L.ptr(args[0]), L.ptr(args[1]),
+                                         L.ptr(args[2]), L.ptr(args[3]), C.c_float(1e-5), L.ptr(xo) if use_ln else None,
+                                         L.ptr(y), B, N, K, relu, L.stream_ptr()), "evt_dec_gemv")
+            torch.cuda.synchronize()
+            assert rel(y, want) < 2e-5, (use_ln, relu)
+            if use_ln:
+                assert rel(xo, x) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("pos", [0, 37, 700])
+def test_dec_attn(gpu, dtype, pos):
+    from easevoice_trainer_amd.hip import lib as L
+
+    B, H, D, Lmax = 2, 16, 32, 1024
+    E = H * D
+    g = torch.Generator().manual_seed(pos + 5)
+    kc, vc = torch.randn(B, Lmax, E, generator=g).to(dtype), torch.randn(B, Lmax, E, generator=g).to(dtype)
+    qkv = torch.randn(B, 3 * E, generator=g)
+    kcg, vcg = kc.to(gpu), vc.to(gpu)
+    ctr = torch.tensor([pos, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=gpu)
+    out = torch.empty(B, E, device=gpu)
+    L.check(L.lib().evt_dec_attn(L.dt_of(kcg), L.ptr(qkv.to(gpu)), L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
+                                 Lmax, L.stream_ptr()), "evt_dec_attn")
+    torch.cuda.synchronize()
+    knew, vnew = qkv[:, E:2 * E].to(dtype), qkv[:, 2 * E:].to(dtype)
+    assert torch.equal(kcg[:, pos].cpu(), knew) and torch.equal(vcg[:, pos].cpu(), vnew)
+    assert torch.equal(kcg[:, :pos].cpu(), kc[:, :pos]) and torch.equal(kcg[:, pos + 1:].cpu(), kc[:, pos + 1:])
+    K = torch.cat([kc[:, :pos].float(), knew.float()[:, None]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    V = torch.cat([vc[:, :pos].float(), vnew.float()[:, None]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    q = qkv[:, :E].view(B, 1, H, D).transpose(1, 2)
+    want = (F.softmax(q @ K.transpose(-1, -2) / D ** 0.5, -1) @ V).transpose(1, 2).reshape(B, E)
+    assert rel(out, want) < 2e-5
+
+
+def _sample(gpu, logits, y, ycount, idx, noise, top_k=15, top_p=1.0, temperature=1.0, rp=1.35, eos=1024, seed=0):
+    from easevoice_trainer_amd.hip import lib as L
+
+    B, V = logits.shape
+    ymax = y.size(1)
+    yg = y.to(gpu).clone()
+    ctr = torch.tensor([0, idx, ycount, 0, seed, 0, 0, 0], dtype=torch.int32, device=gpu)
+    stop = torch.full((B,), -1, dtype=torch.int32, device=gpu)
+    probs = torch.empty(B, V, device=gpu)
+    sp = L.SampleParams(V, eos, top_k, 11, ymax, top_p, temperature, rp, 123)
+    L.check(L.lib().evt_dec_sample(C.byref(sp), L.ptr(logits.to(gpu)), L.ptr(yg), L.ptr(ctr),
+                                   L.ptr(noise.to(gpu)) if noise is not None else None, L.ptr(stop), L.ptr(probs), B,
+                                   L.stream_ptr()), "evt_dec_sample")
+    torch.cuda.synchronize()
+    return yg.cpu(), stop.cpu(), probs.cpu()
+
+
+@pytest.mark.parametrize("cfg", [dict(top_k=15, top_p=1.0, temperature=1.0, rp=1.35),
+                                 dict(top_k=5, top_p=0.8, temperature=0.7, rp=1.2),
+                                 dict(top_k=0, top_p=0.5, temperature=1.3, rp=1.0),
+                                 dict(top_k=1, top_p=1.0, temperature=1.0, rp=1.35)], ids=["k15", "k5p08", "p05", "greedy"])
+@pytest.mark.parametrize("idx", [3, 20])
+def test_dec_sample_matches_oracle(gpu, cfg, idx):
+    from oracle.s1_step import logits_to_probs
+
+    B, V, ycount = 3, 1025, 50
+    g = torch.Generator().manual_seed(idx * 7 + cfg["top_k"])
+    logits = torch.randn(B, V, generator=g) * 3
+    y = torch.zeros(B, 512, dtype=torch.int64)
+    y[:, :ycount] = torch.randint(0, 1024, (B, ycount), generator=g)
+    noise = torch.empty(32, V).exponential_(1, generator=g)
+    yg, stop, probs = _sample(gpu, logits, y, ycount, idx, noise, **cfg)
+    Ve = V - 1 if idx < 11 else V
+    want = logits_to_probs(logits[:, :Ve], y[:, :ycount], cfg["temperature"], cfg["top_k"] or None, cfg["top_p"], cfg["rp"])
+    assert torch.equal(probs[:, :Ve] > 0, want > 0)                 # the same survivors of the nucleus / top-k cuts
+    assert rel(probs[:, :Ve], want) < 1e-5 and (Ve == V or not probs[:, Ve:].any())
+    tok = torch.argmax(want / noise[idx, :Ve], dim=-1)
+    assert torch.equal(yg[:, ycount], tok) and torch.equal(yg[:, :ycount], y[:, :ycount])
+    assert torch.equal(stop, torch.full((B,), -1, dtype=torch.int32))
+
+
+def test_dec_sample_eos_and_seeded_noise(gpu):
+    B, V, ycount = 2, 1025, 4
+    logits = torch.randn(B, V, generator=torch.Generator().manual_seed(1))
+    y = torch.zeros(B, 512, dtype=torch.int64)
+    # row 0: EOS is the arg-max of the logits -> stop even if another token is drawn; row 1: EOS is the only survivor
+    logits[0, 1024] = 9.0
+    logits[1, 1024] = 50.0
+    logits[:, 7] = 5.0                                              # inside the top-k set of both rows
+    noise = torch.ones(40, V)
+    noise[12, 1024] = 1e9                                           # row 0 draws something else
+    noise[12, 7] = 1e-9
+    yg, stop, probs = _sample(gpu, logits, y, ycount, 12, noise, top_k=15)
+    assert stop[0] == 12 and yg[0, ycount] == 7 and stop[1] == 12 and yg[1, ycount] == 1024
+    # before step 11 the EOS column does not exist: no stop, EOS never drawn
+    yg, stop, probs = _sample(gpu, logits, y, ycount, 5, noise, top_k=15)
+    assert (stop == -1).all() and (yg[:, ycount] != 1024).all() and not probs[:, 1024].any()
+    # built-in noise: repeatable per (seed, step), different across seeds, tokens inside the top-k set
+    flat = torch.zeros(1, V)
+    draws = {}
+    for seed in (1, 2):
+        for idx in (20, 21):
+            yg, _, probs = _sample(gpu, flat, y[:1], 0, idx, None, top_k=0, rp=1.0, seed=seed)
+            yg2, _, _ = _sample(gpu, flat, y[:1], 0, idx, None, top_k=0, rp=1.0, seed=seed)
+            assert yg[0, 0] == yg2[0, 0]
+            draws[(seed, idx)] = int(yg[0, 0])
+    assert len(set(draws.values())) >= 3
+    counts = torch.zeros(4)
+    lg = torch.full((1, V), -20.0)
+    lg[0, :4] = torch.tensor([2.0, 1.0, 0.0, -1.0])
+    for seed in range(400):
+        yg, _, _ = _sample(gpu, lg, y[:1], 0, 30, None, top_k=4, rp=1.0, seed=seed)
+        counts[int(yg[0, 0])] += 1
+    p = F.softmax(lg[0, :4], -1)
+    assert ((counts / 400 - p).abs() < 0.08).all(), counts
+
+
+@pytest.fixture(scope="module")
+def model(gpu):
+    from easevoice_trainer_amd.train.s1_engine import S1Engine
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    eng = S1Engine(cfg, gpu, torch.float32)
+    fill_module(eng.model, 3)
+    eng.model.eval()
+    return eng.model
+
+
+@pytest.mark.parametrize("graph", ["1", "0"], ids=["graph", "eager"])
+def test_decoding_matches_reference_tokens(gpu, model, graph, monkeypatch):
+    from make_golden_s1_inputs import infer_inputs
+
+    monkeypatch.setenv("EVT_DECODE_GRAPH", graph)
+    d = infer_inputs()
+    for gold in torch.load(os.path.join(HERE, "golden", "s1_infer.pt"), weights_only=False)["cases"]:
+        a = dict(gold["args"])
+        prompts = d["prompts"].to(gpu) if a.pop("prompt") else None
+        y, idx = model.infer_panel_naive(d["x"].to(gpu), torch.tensor([24]).to(gpu), prompts, d["bert"].to(gpu),
+                                         noise=d["q"], **a)
+        assert y.shape == gold["y"].shape and y.dtype == gold["y"].dtype
+        assert torch.equal(y.cpu().long(), gold["y"].long()), (a, y.cpu()[0, -8:], gold["y"][0, -8:])
+        assert idx == gold["idx"]
+
+
+def test_decoding_bf16_and_batched_front(gpu, model):
+    from make_golden_s1_inputs import infer_inputs
+
+    d = infer_inputs()
+    model.cd = torch.bfloat16
+    try:
+        torch.manual_seed(5)
+        y1, i1 = model.infer_panel(d["x"].to(gpu), None, d["prompts"].to(gpu), d["bert"].to(gpu), top_k=15, top_p=1,
+                                   early_stop_num=30)
+        torch.manual_seed(5)
+        y2, i2 = model.infer_panel(d["x"].to(gpu), None, d["prompts"].to(gpu), d["bert"].to(gpu), top_k=15, top_p=1,
+                                   early_stop_num=30)
+        assert torch.equal(y1, y2) and i1 == i2 == 29 and y1.shape == (1, 12 + 30)
+        assert int(y1.min()) >= 0 and int(y1[:, 12:].max()) <= 1024
+        ys, idxs = model.infer_panel_naive_batched([d["x"][0].to(gpu)] * 2, [24, 24], d["prompts"].expand(2, -1).to(gpu),
+                                                   [d["bert"][0].to(gpu)] * 2, top_k=5, top_p=1, early_stop_num=10)
+        assert len(ys) == 2 and ys[0].shape == (12 + 10,) and idxs == [9, 9]
+    finally:
+        model.cd = torch.float32
