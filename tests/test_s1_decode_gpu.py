@@ -43,7 +43,8 @@ def test_dec_gemv(gpu, dtype, shape):
             y = torch.empty(B, N, device=gpu)
             xo = torch.full((B, K), -7.0, device=gpu)
             args = [dev(a), dev(r), dev(lg), dev(lb)] if use_ln else [dev(a), None, None, None]
-            L.check(L.lib().evt_dec_gemv(L.dt_of(Wg), L.ptr(Wg), L.ptr(dev(bias)), L.ptr(args[0]), L.ptr(args[1]),
+            bg = dev(bias)
+            L.check(L.lib().evt_dec_gemv(L.dt_of(Wg), L.ptr(Wg), L.ptr(bg), L.ptr(args[0]), L.ptr(args[1]),
                                          L.ptr(args[2]), L.ptr(args[3]), C.c_float(1e-5), L.ptr(xo) if use_ln else None,
                                          L.ptr(y), B, N, K, relu, L.stream_ptr()), "evt_dec_gemv")
             torch.cuda.synchronize()
@@ -65,7 +66,8 @@ def test_dec_attn(gpu, dtype, pos):
     kcg, vcg = kc.to(gpu), vc.to(gpu)
     ctr = torch.tensor([pos, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=gpu)
     out = torch.empty(B, E, device=gpu)
-    L.check(L.lib().evt_dec_attn(L.dt_of(kcg), L.ptr(qkv.to(gpu)), L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
+    qg = qkv.to(gpu)
+    L.check(L.lib().evt_dec_attn(L.dt_of(kcg), L.ptr(qg), L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
                                  Lmax, L.stream_ptr()), "evt_dec_attn")
     torch.cuda.synchronize()
     knew, vnew = qkv[:, E:2 * E].to(dtype), qkv[:, 2 * E:].to(dtype)
@@ -88,8 +90,9 @@ def _sample(gpu, logits, y, ycount, idx, noise, top_k=15, top_p=1.0, temperature
     stop = torch.full((B,), -1, dtype=torch.int32, device=gpu)
     probs = torch.empty(B, V, device=gpu)
     sp = L.SampleParams(V, eos, top_k, 11, ymax, top_p, temperature, rp, 123)
-    L.check(L.lib().evt_dec_sample(C.byref(sp), L.ptr(logits.to(gpu)), L.ptr(yg), L.ptr(ctr),
-                                   L.ptr(noise.to(gpu)) if noise is not None else None, L.ptr(stop), L.ptr(probs), B,
+    lg = logits.to(gpu).contiguous()                    # named: the buffers must outlive the launch
+    ng = noise.to(gpu).contiguous() if noise is not None else None
+    L.check(L.lib().evt_dec_sample(C.byref(sp), L.ptr(lg), L.ptr(yg), L.ptr(ctr), L.ptr(ng), L.ptr(stop), L.ptr(probs), B,
                                    L.stream_ptr()), "evt_dec_sample")
     torch.cuda.synchronize()
     return yg.cpu(), stop.cpu(), probs.cpu()
