@@ -33,7 +33,7 @@ def main():
     m = S1Engine(cfg, dev, dtype).model
     m.eval()
     with torch.no_grad():
-        m.ar_predict_layer.weight[-1].fill_(-1e4 if False else 0.0)      # random init: EOS is as unlikely as any token
+        m.ar_predict_layer.weight[-1].zero_()      # EOS logit 0: never the arg-max of 1025 random logits
     g = torch.Generator().manual_seed(1)
     x = torch.randint(0, 732, (1, args.x_len), generator=g).to(dev)
     bert = torch.randn(1, 1024, args.x_len, generator=g).to(dev)
