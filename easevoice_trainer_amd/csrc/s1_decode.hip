@@ -67,48 +67,68 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* re
 template <typename T> struct WVec { static constexpr int V = 16 / sizeof(T); };
 
 // ---- y[b][n] = act(bias[n] + sum_k W[n][k] * x[b][k]),  x = a  or  LayerNorm(a + r) --------------------------------
-template <typename T, int RPW>
+// A launch is a dependent chain of memory latencies, not a bandwidth problem (a workgroup touches 8-16 KB of weights), so
+// the chain is kept as short as it gets: every weight load of the wave's rows is issued first (RPW x NPASS 16-byte loads
+// in flight per lane), the input vector is staged -- and normalised with ONE block reduction of (sum, sum of squares) --
+// while they are outstanding, then the dot products run out of registers and LDS.
+template <typename T, int RPW, int NPASS>
 __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const float* __restrict__ bias,
                                                 const float* __restrict__ a, const float* __restrict__ r,
                                                 const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                float eps, float* x_out, float* __restrict__ y, int B, int N, int K,
-                                                int relu) {
+                                                float eps, float* x_out, float* __restrict__ y, int B, int N, int relu) {
   extern __shared__ float xs[];   // [B][K]
-  __shared__ float red[4];
+  __shared__ float red[8];
   constexpr int V = WVec<T>::V;
+  constexpr int K = NPASS * 64 * V;
+  constexpr int KPT = K / 256;     // input values per thread while staging
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int b = 0; b < B; ++b)
-    for (int k = tid; k < K; k += 256) xs[b * K + k] = a[b * K + k] + (r ? r[b * K + k] : 0.f);
-  __syncthreads();
-  if (r) {
-    for (int b = 0; b < B; ++b) {
-      float s = 0.f;
-      for (int k = tid; k < K; k += 256) s += xs[b * K + k];
-      const float mu = block_sum(s, red, 4) / K;
-      float q = 0.f;
-      for (int k = tid; k < K; k += 256) { const float d = xs[b * K + k] - mu; q += d * d; }
-      const float rs = rsqrtf(block_sum(q, red, 4) / K + eps);
-      for (int k = tid; k < K; k += 256) {
-        const float v = (xs[b * K + k] - mu) * rs * ln_g[k] + ln_b[k];
-        xs[b * K + k] = v;
-        if (x_out && blockIdx.x == 0) x_out[b * K + k] = v;
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  uint4 w[RPW][NPASS];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int n = n0 + i;
+      w[i][ps] = n < N ? *reinterpret_cast<const uint4*>(W + (long)n * K + (ps * 64 + lane) * V) : make_uint4(0, 0, 0, 0);
+    }
+  for (int b = 0; b < B; ++b) {
+    float v[KPT];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+      const int k = tid + e * 256;
+      v[e] = a[b * K + k] + (r ? r[b * K + k] : 0.f);
+      s += v[e];
+      q += v[e] * v[e];
+    }
+    if (r) {
+      s = wave_reduce_sum(s);
+      q = wave_reduce_sum(q);
+      __syncthreads();
+      if (lane == 0) { red[wave] = s; red[4 + wave] = q; }
+      __syncthreads();
+      const float mu = (red[0] + red[1] + red[2] + red[3]) / K;
+      const float var = fmaxf((red[4] + red[5] + red[6] + red[7]) / K - mu * mu, 0.f);
+      const float rs = rsqrtf(var + eps);
+#pragma unroll
+      for (int e = 0; e < KPT; ++e) {
+        const int k = tid + e * 256;
+        v[e] = (v[e] - mu) * rs * ln_g[k] + ln_b[k];
+        if (x_out && blockIdx.x == 0) x_out[b * K + k] = v[e];
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) xs[b * K + tid + e * 256] = v[e];
   }
-  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  __syncthreads();
   float acc[RPW][kMaxB];
 #pragma unroll
   for (int i = 0; i < RPW; ++i)
 #pragma unroll
     for (int b = 0; b < kMaxB; ++b) acc[i][b] = 0.f;
-  for (int k0 = lane * V; k0 < K; k0 += 64 * V) {
-    uint4 w[RPW];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int n = n0 + i;
-      w[i] = n < N ? *reinterpret_cast<const uint4*>(W + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
-    }
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int k0 = (ps * 64 + lane) * V;
 #pragma unroll
     for (int b = 0; b < kMaxB; ++b) {
       if (b >= B) break;
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
       for (int e = 0; e < V; ++e) xv[e] = xs[b * K + k0 + e];
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
-        const T* pw = reinterpret_cast<const T*>(&w[i]);
+        const T* pw = reinterpret_cast<const T*>(&w[i][ps]);
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[i][b] += to_f<T>(pw[e]) * xv[e];
       }
@@ -128,23 +148,28 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
 #pragma unroll
     for (int b = 0; b < kMaxB; ++b) {
       if (b >= B) break;
-      const float s = wave_reduce_sum(acc[i][b]);
+      const float sum = wave_reduce_sum(acc[i][b]);
       const int n = n0 + i;
       if (lane == 0 && n < N) {
-        float v = s + (bias ? bias[n] : 0.f);
-        if (relu) v = fmaxf(v, 0.f);
-        y[(long)b * N + n] = v;
+        float o = sum + (bias ? bias[n] : 0.f);
+        if (relu) o = fmaxf(o, 0.f);
+        y[(long)b * N + n] = o;
       }
     }
 }
 
 // ---- append (k, v) of the new token to the cache, attend over all cached positions -------------------------------
+// Scores: one key per thread (D elements = D/V 16-byte loads, all in flight).  P.V: a thread owns one 16-byte chunk of
+// the value rows of every G-th key (G = 256 / chunks-per-row), so the cache is read with 16-byte loads only; the G
+// partial rows are summed through LDS.
 template <typename T, int D>
 __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T* kc, T* vc, const int* __restrict__ ctr,
                                                 float* __restrict__ out, int H, int Lmax) {
   extern __shared__ float sc[];   // [Lmax] scores -> probabilities
-  __shared__ float qs[D], kn[D], vn[D], red[4], part[256 / D][D];
   constexpr int V = WVec<T>::V;
+  constexpr int C = D / V;        // 16-byte chunks per row
+  constexpr int G = 256 / C;      // key groups in the P.V phase
+  __shared__ float qs[D], kn[D], vn[D], red[4], part[G][D + 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * D;
   const int pos = ctr[EVT_DEC_POS];
@@ -168,12 +193,14 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
       for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
     } else {
       const T* row = kc + ((long)b * Lmax + j) * E + h * D;
+      uint4 u[C];
 #pragma unroll
-      for (int d0 = 0; d0 < D; d0 += V) {
-        const uint4 u = *reinterpret_cast<const uint4*>(row + d0);
-        const T* pu = reinterpret_cast<const T*>(&u);
+      for (int c = 0; c < C; ++c) u[c] = *reinterpret_cast<const uint4*>(row + c * V);
 #pragma unroll
-        for (int e = 0; e < V; ++e) s += qs[d0 + e] * to_f<T>(pu[e]);
+      for (int c = 0; c < C; ++c) {
+        const T* pu = reinterpret_cast<const T*>(&u[c]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += qs[c * V + e] * to_f<T>(pu[e]);
       }
     }
     sc[j] = s;
@@ -187,18 +214,28 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
     sum += e;
   }
   sum = block_sum(sum, red, 4);      // its barriers also publish sc[]
-  constexpr int G = 256 / D;
-  const int g = tid / D, d = tid % D;
-  float acc = 0.f;
+  const int g = tid / C, c = tid % C;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
   for (int j = g; j < L; j += G) {
-    const float v = j == pos ? vn[d] : to_f<T>(vc[((long)b * Lmax + j) * E + h * D + d]);
-    acc += sc[j] * v;
+    const float pj = sc[j];
+    if (j == pos) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += pj * vn[c * V + e];
+    } else {
+      const uint4 u = *reinterpret_cast<const uint4*>(vc + ((long)b * Lmax + j) * E + h * D + c * V);
+      const T* pu = reinterpret_cast<const T*>(&u);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += pj * to_f<T>(pu[e]);
+    }
   }
-  part[g][d] = acc;
+#pragma unroll
+  for (int e = 0; e < V; ++e) part[g][c * V + e] = acc[e];
   __syncthreads();
   if (tid < D) {
     float o = 0.f;
-#pragma unroll
+#pragma unroll 8
     for (int i = 0; i < G; ++i) o += part[i][tid];
     out[(long)b * E + h * D + tid] = o / sum;
   }
@@ -366,6 +403,30 @@ __global__ void dec_advance(int* ctr, int dpos) {
 
 }  // namespace
 
+template <typename T>
+static int launch_gemv(const void* W, const float* bias, const float* a, const float* r, const float* g, const float* bt,
+                       float eps, float* x_out, float* y, int B, int N, int K, int relu, hipStream_t st) {
+  constexpr int V = WVec<T>::V;
+  const size_t shm = (size_t)B * K * sizeof(float);
+  const int npass = K / (64 * V);
+  // rows per wave: keep >= ~128 workgroups in flight for the short matrices, two rows per wave for the tall ones
+  const int rpw = N >= 1024 ? 2 : 1;
+  const int blocks = (N + 4 * rpw - 1) / (4 * rpw);
+#define EVT_GEMV(RPW, NP)                                                                                            \
+  hipLaunchKernelGGL((dec_gemv<T, RPW, NP>), dim3(blocks), dim3(256), shm, st, (const T*)W, bias, a, r, g, bt, eps, \
+                     x_out, y, B, N, relu)
+  if (npass * 64 * V != K) return EVT_ENOTSUP;
+  if (rpw == 2) {
+    if (npass == 1) EVT_GEMV(2, 1); else if (npass == 2) EVT_GEMV(2, 2); else if (npass == 4) EVT_GEMV(2, 4);
+    else if (npass == 8) EVT_GEMV(2, 8); else return EVT_ENOTSUP;
+  } else {
+    if (npass == 1) EVT_GEMV(1, 1); else if (npass == 2) EVT_GEMV(1, 2); else if (npass == 4) EVT_GEMV(1, 4);
+    else if (npass == 8) EVT_GEMV(1, 8); else return EVT_ENOTSUP;
+  }
+#undef EVT_GEMV
+  return evt_check_launch();
+}
+
 extern "C" {
 
 int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* a, const float* r, const float* ln_g,
@@ -374,18 +435,10 @@ int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* 
   if (!W || !a || !y || B <= 0 || N <= 0 || K <= 0) return EVT_EINVAL;
   if (r && (!ln_g || !ln_b)) return EVT_EINVAL;
   if (B > kMaxB || K % 512 || (size_t)B * K * 4 > 64 * 1024) return EVT_ENOTSUP;
-  constexpr int RPW = 2;
-  const int blocks = (N + 4 * RPW - 1) / (4 * RPW);
-  const size_t shm = (size_t)B * K * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (wdtype == EVT_DT_BF16)
-    hipLaunchKernelGGL((dec_gemv<bf16_t, RPW>), dim3(blocks), dim3(256), shm, st, (const bf16_t*)W, bias, a, r, ln_g,
-                       ln_b, ln_eps, x_out, y, B, N, K, relu);
-  else if (wdtype == EVT_DT_F32)
-    hipLaunchKernelGGL((dec_gemv<float, RPW>), dim3(blocks), dim3(256), shm, st, (const float*)W, bias, a, r, ln_g, ln_b,
-                       ln_eps, x_out, y, B, N, K, relu);
-  else return EVT_EINVAL;
-  return evt_check_launch();
+  if (wdtype == EVT_DT_BF16) return launch_gemv<bf16_t>(W, bias, a, r, ln_g, ln_b, ln_eps, x_out, y, B, N, K, relu, st);
+  if (wdtype == EVT_DT_F32) return launch_gemv<float>(W, bias, a, r, ln_g, ln_b, ln_eps, x_out, y, B, N, K, relu, st);
+  return EVT_EINVAL;
 }
 
 int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
