@@ -91,6 +91,15 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
       const int n = n0 + i;
       w[i][ps] = n < N ? *reinterpret_cast<const uint4*>(W + (long)n * K + (ps * 64 + lane) * V) : make_uint4(0, 0, 0, 0);
     }
+  // everything the epilogues need is requested now as well: a load placed after a barrier starts a new latency
+  float lg[KPT], lb[KPT], bz[RPW];
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) {
+    lg[e] = r ? ln_g[tid + e * 256] : 1.f;
+    lb[e] = r ? ln_b[tid + e * 256] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) bz[i] = (bias && n0 + i < N) ? bias[n0 + i] : 0.f;
   for (int b = 0; b < B; ++b) {
     float v[KPT];
     float s = 0.f, q = 0.f;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
 #pragma unroll
       for (int e = 0; e < KPT; ++e) {
         const int k = tid + e * 256;
-        v[e] = (v[e] - mu) * rs * ln_g[k] + ln_b[k];
+        v[e] = (v[e] - mu) * rs * lg[e] + lb[e];
         if (x_out && blockIdx.x == 0) x_out[b * K + k] = v[e];
       }
     }
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
       const float sum = wave_reduce_sum(acc[i][b]);
       const int n = n0 + i;
       if (lane == 0 && n < N) {
-        float o = sum + (bias ? bias[n] : 0.f);
+        float o = sum + bz[i];
         if (relu) o = fmaxf(o, 0.f);
         y[(long)b * N + n] = o;
       }
@@ -175,6 +184,21 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
   const int pos = ctr[EVT_DEC_POS];
   if (pos >= Lmax) return;            // cache full: the host bounds the number of steps, this only guards memory
   const int L = pos + 1;
+  // requests first: this thread's first key row and its first PF value chunks do not depend on anything computed here
+  constexpr int PF = 8;
+  const int g = tid / C, c = tid % C;
+  uint4 u0[C], vpre[PF];
+  const bool own0 = tid < L && tid != pos;
+  if (own0) {
+    const T* row = kc + ((long)b * Lmax + tid) * E + h * D;
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) u0[cc] = *reinterpret_cast<const uint4*>(row + cc * V);
+  }
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int j = g + i * G;
+    if (j < L && j != pos) vpre[i] = *reinterpret_cast<const uint4*>(vc + ((long)b * Lmax + j) * E + h * D + c * V);
+  }
   if (tid < D) {
     const float* base = qkv + (long)b * 3 * E + h * D + tid;
     qs[tid] = base[0] * rsqrtf((float)D);
@@ -192,15 +216,20 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
 #pragma unroll
       for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
     } else {
-      const T* row = kc + ((long)b * Lmax + j) * E + h * D;
       uint4 u[C];
+      if (j == tid) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) u[c] = *reinterpret_cast<const uint4*>(row + c * V);
+        for (int cc = 0; cc < C; ++cc) u[cc] = u0[cc];
+      } else {
+        const T* row = kc + ((long)b * Lmax + j) * E + h * D;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const T* pu = reinterpret_cast<const T*>(&u[c]);
+        for (int cc = 0; cc < C; ++cc) u[cc] = *reinterpret_cast<const uint4*>(row + cc * V);
+      }
 #pragma unroll
-        for (int e = 0; e < V; ++e) s += qs[c * V + e] * to_f<T>(pu[e]);
+      for (int cc = 0; cc < C; ++cc) {
+        const T* pu = reinterpret_cast<const T*>(&u[cc]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += qs[cc * V + e] * to_f<T>(pu[e]);
       }
     }
     sc[j] = s;
@@ -214,11 +243,25 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
     sum += e;
   }
   sum = block_sum(sum, red, 4);      // its barriers also publish sc[]
-  const int g = tid / C, c = tid % C;
   float acc[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) acc[e] = 0.f;
-  for (int j = g; j < L; j += G) {
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int j = g + i * G;
+    if (j < L) {
+      const float pj = sc[j];
+      if (j == pos) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += pj * vn[c * V + e];
+      } else {
+        const T* pu = reinterpret_cast<const T*>(&vpre[i]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += pj * to_f<T>(pu[e]);
+      }
+    }
+  }
+  for (int j = g + PF * G; j < L; j += G) {
     const float pj = sc[j];
     if (j == pos) {
 #pragma unroll
