@@ -5,9 +5,9 @@ src/easevoice/soundstorm/auto_reg/models/t2s_model.py:762-863, with T2SBlock.pro
 Same token sequence as the reference for the same sampling noise; a different execution plan:
   * prompt pass: the training kernels without gradients (packed qkv GEMM, analytic prefix-LM flash attention, fused
     residual+LayerNorm); its keys/values are copied once into a preallocated cache [layers][B][Lmax][E];
-  * token steps: five launches per block (csrc/s1_decode.hip) + logits + sampling + embedding + counter update, all reading
-    their per-step state (cache length, step index, token count) from device memory, captured once into a HIP graph and
-    replayed per token.  The host reads the stop flag every `poll` steps; tokens decoded past the stop are discarded.
+  * token steps: four launches per block (csrc/s1_decode.hip: in-projection + cache attention, out-projection, two for
+    the MLP) + logits + one for sampling / embedding / counters, all reading their per-step state (cache length, step
+    index, token count) from device memory, captured once into a HIP graph and replayed per token.  The host reads the stop flag every `poll` steps; tokens decoded past the stop are discarded.
 The reference reads two device scalars per token (the EOS tests of :846) and reallocates every cache tensor per token."""
 import ctypes as C
 import os
@@ -57,7 +57,7 @@ class DecodeSession:
         self.kc = z(nl, B, Lmax, E, dt=dtype)
         self.vc = z(nl, B, Lmax, E, dt=dtype)
         self.xa, self.xb = z(B, E), z(B, E)
-        self.qkv, self.att, self.t, self.u = z(B, 3 * E), z(B, E), z(B, E), z(B, E)
+        self.att, self.t, self.u = z(B, E), z(B, E), z(B, E)
         self.hid = z(B, 4 * E)
         self.logits = z(B, V)
         self.y = z(B, ymax, dt=torch.int64)
@@ -72,36 +72,33 @@ class DecodeSession:
                                      C.c_float(eps), L.ptr(x_out), L.ptr(y), self.B, N, K, int(relu), L.stream_ptr()),
                 "evt_dec_gemv")
 
-    def _sample(self, sp, noise):
-        L.check(L.lib().evt_dec_sample(C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise),
-                                       L.ptr(self.stop), None, self.B, L.stream_ptr()), "evt_dec_sample")
+    def _sample_embed_advance(self, W, sp, noise, pe, dpos):
+        """sampling, append, embedding of the new token and the counter update: one launch for one sequence"""
+        L.check(L.lib().evt_dec_sample_embed(
+            C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise), L.ptr(self.stop), L.ptr(W.emb),
+            L.ptr(pe), L.ptr(W.alpha), C.c_float(self.model.ar_audio_position.x_scale), L.ptr(self.xa), self.E, pe.size(0),
+            dpos, L.stream_ptr()), "evt_dec_sample_embed")
 
-    def _embed_advance(self, W, pe, dpos):
-        lib = L.lib()
-        L.check(lib.evt_dec_embed(L.ptr(W.emb), L.ptr(pe), L.ptr(W.alpha), C.c_float(self.model.ar_audio_position.x_scale),
-                                  L.ptr(self.y), L.ptr(self.ctr), L.ptr(self.xa), self.B, self.E, self.ymax, pe.size(0),
-                                  L.stream_ptr()), "evt_dec_embed")
-        L.check(lib.evt_dec_advance(L.ptr(self.ctr), dpos, L.stream_ptr()), "evt_dec_advance")
+    def _qkv_attn(self, i, w, a, r, g, b, eps, x_out):
+        L.check(L.lib().evt_dec_qkv_attn(L.dt_of(self.kc), L.ptr(w["wqkv"]), L.ptr(w["bqkv"]), L.ptr(a), L.ptr(r), L.ptr(g),
+                                         L.ptr(b), C.c_float(eps), L.ptr(x_out), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
+                                         L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
+                                         L.stream_ptr()), "evt_dec_qkv_attn")
 
     def step_launches(self, W, sp, noise, pe):
-        """one token: 24 x (qkv, attention, out-proj, ffn1, ffn2) + logits + sample + embed + counters"""
-        lib = L.lib()
+        """one token: 24 x (qkv + cache attention, out-proj, ffn1, ffn2) + logits + sample/embed/counters = 98 launches"""
         prev = None
         for i, w in enumerate(W.layers):
             if prev is None:
-                self._gemv(w["wqkv"], w["bqkv"], self.xa, None, None, None, 0.0, None, self.qkv)
+                self._qkv_attn(i, w, self.xa, None, None, None, 0.0, None)
             else:       # input = LayerNorm2 of the previous block, stored to xa for this block's first residual
-                self._gemv(w["wqkv"], w["bqkv"], self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], self.xa, self.qkv)
-            L.check(lib.evt_dec_attn(L.dt_of(self.kc), L.ptr(self.qkv), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
-                                     L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
-                                     L.stream_ptr()), "evt_dec_attn")
+                self._qkv_attn(i, w, self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], self.xa)
             self._gemv(w["wo"], w["bo"], self.att, None, None, None, 0.0, None, self.t)
             self._gemv(w["w1"], w["b1"], self.xa, self.t, w["g1"], w["be1"], w["eps1"], self.xb, self.hid, relu=1)
             self._gemv(w["w2"], w["b2"], self.hid, None, None, None, 0.0, None, self.u)
             prev = w
         self._gemv(W.wpred, None, self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], None, self.logits)
-        self._sample(sp, noise)
-        self._embed_advance(W, pe, 1)
+        self._sample_embed_advance(W, sp, noise, pe, 1)
 
 
 class T2SInfer:
@@ -180,8 +177,7 @@ class T2SInfer:
         # ---- step 0: logits of the last prompt position, sample, embed ----
         S.xb.copy_(xy[:, -1].float())
         S._gemv(W.wpred, None, S.xb, None, None, None, 0.0, None, S.logits)
-        S._sample(sp, noise)
-        S._embed_advance(W, pe, 0)
+        S._sample_embed_advance(W, sp, noise, pe, 0)
         # ---- token steps: one graph replay each ----
         use_graph = os.environ.get("EVT_DECODE_GRAPH", "1") != "0"
         gkey = (bytes(sp), None if noise is None else noise.data_ptr(), pe.data_ptr(), id(W))

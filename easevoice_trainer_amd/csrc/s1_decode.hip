@@ -170,45 +170,41 @@ __global__ __launch_bounds__(256) void dec_gemv(const T* __restrict__ W, const f
 // ---- append (k, v) of the new token to the cache, attend over all cached positions -------------------------------
 // Scores: one key per thread (D elements = D/V 16-byte loads, all in flight).  P.V: a thread owns one 16-byte chunk of
 // the value rows of every G-th key (G = 256 / chunks-per-row), so the cache is read with 16-byte loads only; the G
-// partial rows are summed through LDS.
+// partial rows are summed through LDS.  The first key row and the first PF value chunks of a thread depend on nothing
+// computed in the launch and are requested before anything else (Prefetch), the rest follows the softmax.
+template <typename T, int D> struct AttnShape {
+  static constexpr int V = WVec<T>::V;
+  static constexpr int C = D / V;        // 16-byte chunks per row
+  static constexpr int G = 256 / C;      // key groups in the P.V phase
+  static constexpr int PF = 8;
+};
+
+template <typename T, int D> struct Prefetch {
+  uint4 u0[AttnShape<T, D>::C], vpre[AttnShape<T, D>::PF];
+  __device__ __forceinline__ void issue(const T* kc, const T* vc, int b, int h, int E, int Lmax, int L, int pos) {
+    using S = AttnShape<T, D>;
+    const int tid = threadIdx.x, g = tid / S::C, c = tid % S::C;
+    if (tid < L && tid != pos) {
+      const T* row = kc + ((long)b * Lmax + tid) * E + h * D;
+#pragma unroll
+      for (int cc = 0; cc < S::C; ++cc) u0[cc] = *reinterpret_cast<const uint4*>(row + cc * S::V);
+    }
+#pragma unroll
+    for (int i = 0; i < S::PF; ++i) {
+      const int j = g + i * S::G;
+      if (j < L && j != pos) vpre[i] = *reinterpret_cast<const uint4*>(vc + ((long)b * Lmax + j) * E + h * D + c * S::V);
+    }
+  }
+};
+
+// qs (scaled query), kn / vn (new key / value, already rounded to the cache dtype) are in LDS and published
 template <typename T, int D>
-__global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T* kc, T* vc, const int* __restrict__ ctr,
-                                                float* __restrict__ out, int H, int Lmax) {
-  extern __shared__ float sc[];   // [Lmax] scores -> probabilities
-  constexpr int V = WVec<T>::V;
-  constexpr int C = D / V;        // 16-byte chunks per row
-  constexpr int G = 256 / C;      // key groups in the P.V phase
-  __shared__ float qs[D], kn[D], vn[D], red[4], part[G][D + 1];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * D;
-  const int pos = ctr[EVT_DEC_POS];
-  if (pos >= Lmax) return;            // cache full: the host bounds the number of steps, this only guards memory
-  const int L = pos + 1;
-  // requests first: this thread's first key row and its first PF value chunks do not depend on anything computed here
-  constexpr int PF = 8;
-  const int g = tid / C, c = tid % C;
-  uint4 u0[C], vpre[PF];
-  const bool own0 = tid < L && tid != pos;
-  if (own0) {
-    const T* row = kc + ((long)b * Lmax + tid) * E + h * D;
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) u0[cc] = *reinterpret_cast<const uint4*>(row + cc * V);
-  }
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const int j = g + i * G;
-    if (j < L && j != pos) vpre[i] = *reinterpret_cast<const uint4*>(vc + ((long)b * Lmax + j) * E + h * D + c * V);
-  }
-  if (tid < D) {
-    const float* base = qkv + (long)b * 3 * E + h * D + tid;
-    qs[tid] = base[0] * rsqrtf((float)D);
-    const T kq = from_f<T>(base[E]), vq = from_f<T>(base[2 * E]);
-    kn[tid] = to_f<T>(kq);
-    vn[tid] = to_f<T>(vq);
-    kc[((long)b * Lmax + pos) * E + h * D + tid] = kq;
-    vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
-  }
-  __syncthreads();
+__device__ __forceinline__ void attn_tail(const Prefetch<T, D>& pf, const float* qs, const float* kn, const float* vn,
+                                          float* sc, float* red, float (*part)[D + 1], const T* kc, const T* vc,
+                                          float* __restrict__ out, int b, int h, int E, int Lmax, int L, int pos) {
+  using S = AttnShape<T, D>;
+  constexpr int V = S::V, C = S::C, G = S::G, PF = S::PF;
+  const int tid = threadIdx.x, g = tid / C, c = tid % C;
   float mx = -INFINITY;
   for (int j = tid; j < L; j += 256) {
     float s = 0.f;
@@ -219,7 +215,7 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
       uint4 u[C];
       if (j == tid) {
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) u[cc] = u0[cc];
+        for (int cc = 0; cc < C; ++cc) u[cc] = pf.u0[cc];
       } else {
         const T* row = kc + ((long)b * Lmax + j) * E + h * D;
 #pragma unroll
@@ -255,7 +251,7 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] += pj * vn[c * V + e];
       } else {
-        const T* pu = reinterpret_cast<const T*>(&vpre[i]);
+        const T* pu = reinterpret_cast<const T*>(&pf.vpre[i]);
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] += pj * to_f<T>(pu[e]);
       }
@@ -284,6 +280,130 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
   }
 }
 
+template <typename T, int D>
+__global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T* kc, T* vc, const int* __restrict__ ctr,
+                                                float* __restrict__ out, int H, int Lmax) {
+  extern __shared__ float sc[];   // [Lmax] scores -> probabilities
+  __shared__ float qs[D], kn[D], vn[D], red[4], part[AttnShape<T, D>::G][D + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * D;
+  const int pos = ctr[EVT_DEC_POS];
+  if (pos >= Lmax) return;            // cache full: the host bounds the number of steps, this only guards memory
+  const int L = pos + 1;
+  Prefetch<T, D> pf;
+  pf.issue(kc, vc, b, h, E, Lmax, L, pos);
+  if (tid < D) {
+    const float* base = qkv + (long)b * 3 * E + h * D + tid;
+    qs[tid] = base[0] * rsqrtf((float)D);
+    const T kq = from_f<T>(base[E]), vq = from_f<T>(base[2 * E]);
+    kn[tid] = to_f<T>(kq);
+    vn[tid] = to_f<T>(vq);
+    kc[((long)b * Lmax + pos) * E + h * D + tid] = kq;
+    vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
+  }
+  __syncthreads();
+  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos);
+}
+
+// ---- the same with the head's own rows of the packed in-projection computed in the launch -------------------------
+// A workgroup (batch b, head h) needs only rows {q, k, v} x [h*D, (h+1)*D) of W_qkv: 3*D rows of E values (96 KB in
+// bf16).  Computing them here removes the qkv launch of every block from the token step.  Input x = a or
+// LayerNorm(a + r) as in dec_gemv (workgroups h == 0 store it to x_out).
+template <typename T, int D, int NPASS>
+__global__ __launch_bounds__(256) void dec_qkv_attn(const T* __restrict__ W, const float* __restrict__ bias,
+                                                    const float* __restrict__ a, const float* __restrict__ r,
+                                                    const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                    float eps, float* x_out, T* kc, T* vc, const int* __restrict__ ctr,
+                                                    float* __restrict__ out, int H, int Lmax) {
+  extern __shared__ float sc[];   // [Lmax]
+  constexpr int V = WVec<T>::V;
+  constexpr int E = NPASS * 64 * V;       // model width == K of the projection
+  constexpr int KPT = E / 256;
+  constexpr int ROWS = 3 * D, RPWV = ROWS / 4;   // rows per wave
+  constexpr int RC = NPASS == 1 ? RPWV : RPWV / 2;   // rows whose weights are in flight at once
+  __shared__ float xs[E], proj[ROWS], qs[D], kn[D], vn[D], red[8], part[AttnShape<T, D>::G][D + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int pos = ctr[EVT_DEC_POS];
+  if (pos >= Lmax) return;
+  const int L = pos + 1;
+  // projection row rho in [0, 3D): part = rho / D selects q / k / v, global row = part*E + h*D + rho % D
+  auto grow = [&](int rho) { return (rho / D) * E + h * D + rho % D; };
+  uint4 w[RC][NPASS];
+#pragma unroll
+  for (int i = 0; i < RC; ++i)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+      w[i][ps] = *reinterpret_cast<const uint4*>(W + (long)grow(wave * RPWV + i) * E + (ps * 64 + lane) * V);
+  Prefetch<T, D> pf;
+  pf.issue(kc, vc, b, h, E, Lmax, L, pos);
+  float lg[KPT], lb[KPT], v[KPT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) {
+    const int k = tid + e * 256;
+    lg[e] = r ? ln_g[k] : 1.f;
+    lb[e] = r ? ln_b[k] : 0.f;
+    v[e] = a[b * E + k] + (r ? r[b * E + k] : 0.f);
+    s += v[e];
+    q += v[e] * v[e];
+  }
+  const float bz = tid < ROWS ? bias[grow(tid)] : 0.f;
+  if (r) {
+    s = wave_reduce_sum(s);
+    q = wave_reduce_sum(q);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = q; }
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / E;
+    const float var = fmaxf((red[4] + red[5] + red[6] + red[7]) / E - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) {
+      v[e] = (v[e] - mu) * rs * lg[e] + lb[e];
+      if (x_out && h == 0) x_out[b * E + tid + e * 256] = v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) xs[tid + e * 256] = v[e];
+  __syncthreads();
+#pragma unroll
+  for (int chunk = 0; chunk < RPWV / RC; ++chunk) {
+    if (chunk > 0) {
+#pragma unroll
+      for (int i = 0; i < RC; ++i)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+          w[i][ps] = *reinterpret_cast<const uint4*>(W + (long)grow(wave * RPWV + chunk * RC + i) * E + (ps * 64 + lane) * V);
+    }
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const T* pw = reinterpret_cast<const T*>(&w[i][ps]);
+        const int k0 = (ps * 64 + lane) * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc += to_f<T>(pw[e]) * xs[k0 + e];
+      }
+      acc = wave_reduce_sum(acc);
+      if (lane == 0) proj[wave * RPWV + chunk * RC + i] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < ROWS) proj[tid] += bz;
+  __syncthreads();
+  if (tid < D) {
+    qs[tid] = proj[tid] * rsqrtf((float)D);
+    const T kq = from_f<T>(proj[D + tid]), vq = from_f<T>(proj[2 * D + tid]);
+    kn[tid] = to_f<T>(kq);
+    vn[tid] = to_f<T>(vq);
+    kc[((long)b * Lmax + pos) * E + h * D + tid] = kq;
+    vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
+  }
+  __syncthreads();
+  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos);
+}
+
 // ---- sampling ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned mix32s(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -296,9 +416,13 @@ __device__ __forceinline__ bool before(float av, int ai, float bv, int bi) {   /
 
 constexpr int kSortN = 2048;
 
+struct EmbedArgs {          // optional tail of dec_sample: x_next and the counter update of the step (B == 1 only)
+  const float* emb; const float* pe; const float* alpha; float* x; float x_scale; int E, npos, dpos;
+};
+
 __global__ __launch_bounds__(1024) void dec_sample(evt_sample_params p, const float* __restrict__ logits, long* y,
-                                                   const int* __restrict__ ctr, const float* __restrict__ noise,
-                                                   int* stop_idx, float* probs_out) {
+                                                   int* ctr, const float* __restrict__ noise, int* stop_idx,
+                                                   float* probs_out, EmbedArgs ea) {
   __shared__ float sv[kSortN];
   __shared__ int si[kSortN];
   __shared__ float cur[kSortN];
@@ -422,6 +546,19 @@ __global__ __launch_bounds__(1024) void dec_sample(evt_sample_params p, const fl
     if (ycount < p.ymax) yb[ycount] = tok;
     if ((amax == p.eos || tok == p.eos) && stop_idx[b] < 0) stop_idx[b] = idx;
   }
+  if (ea.x) {       // x_next = emb[token] * x_scale + alpha * pe[y_len + idx], then the step's counter update
+    int ppos = ctr[EVT_DEC_YLEN] + idx;
+    if (ppos >= ea.npos) ppos = ea.npos - 1;
+    const float al = ea.alpha[0];
+    for (int c = tid; c < ea.E; c += 1024)
+      ea.x[(long)b * ea.E + c] = ea.emb[(long)tok * ea.E + c] * ea.x_scale + al * ea.pe[(long)ppos * ea.E + c];
+    __syncthreads();     // every read of ctr[] above is done (single workgroup: the launcher checks B == 1)
+    if (tid == 0) {
+      ctr[EVT_DEC_POS] += ea.dpos;
+      ctr[EVT_DEC_IDX] = idx + 1;
+      ctr[EVT_DEC_YCOUNT] = ycount + 1;
+    }
+  }
 }
 
 // ---- x_next = emb[token] * x_scale + alpha * pe[y_len + idx]  (t2s_model.py:860-861) ----------------------------
@@ -504,8 +641,38 @@ int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, 
                    int32_t* stop_idx, float* probs_out, int32_t B, void* stream) {
   if (!p || !logits || !y || !ctr || !stop_idx || B <= 0) return EVT_EINVAL;
   if (p->V <= 1 || p->V > kSortN || p->ymax <= 0 || p->repetition_penalty <= 0.f) return EVT_EINVAL;
-  hipLaunchKernelGGL(dec_sample, dim3(B), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (const int*)ctr, noise,
-                     (int*)stop_idx, probs_out);
+  EmbedArgs none{};
+  hipLaunchKernelGGL(dec_sample, dim3(B), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (int*)ctr, noise,
+                     (int*)stop_idx, probs_out, none);
+  return evt_check_launch();
+}
+
+int evt_dec_sample_embed(const evt_sample_params* p, const float* logits, int64_t* y, int32_t* ctr, const float* noise,
+                         int32_t* stop_idx, const float* emb, const float* pe, const float* alpha, float x_scale, float* x,
+                         int32_t E, int32_t npos, int32_t dpos, void* stream) {
+  if (!p || !logits || !y || !ctr || !stop_idx || !emb || !pe || !alpha || !x || E <= 0 || npos <= 0) return EVT_EINVAL;
+  if (p->V <= 1 || p->V > kSortN || p->ymax <= 0 || p->repetition_penalty <= 0.f) return EVT_EINVAL;
+  EmbedArgs ea{emb, pe, alpha, x, x_scale, E, npos, dpos};
+  hipLaunchKernelGGL(dec_sample, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (int*)ctr, noise,
+                     (int*)stop_idx, (float*)nullptr, ea);
+  return evt_check_launch();
+}
+
+int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const float* a, const float* r,
+                     const float* ln_g, const float* ln_b, float ln_eps, float* x_out, void* kcache, void* vcache,
+                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, void* stream) {
+  if (!Wqkv || !bqkv || !a || !kcache || !vcache || !ctr || !out || B <= 0 || H <= 0 || Lmax <= 0) return EVT_EINVAL;
+  if (r && (!ln_g || !ln_b)) return EVT_EINVAL;
+  if (D != 32 || H * D != 512 || (size_t)Lmax * 4 > 48 * 1024) return EVT_ENOTSUP;
+  const size_t shm = (size_t)Lmax * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL((dec_qkv_attn<bf16_t, 32, 1>), dim3(B * H), dim3(256), shm, st, (const bf16_t*)Wqkv, bqkv, a, r,
+                       ln_g, ln_b, ln_eps, x_out, (bf16_t*)kcache, (bf16_t*)vcache, (const int*)ctr, out, H, Lmax);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL((dec_qkv_attn<float, 32, 2>), dim3(B * H), dim3(256), shm, st, (const float*)Wqkv, bqkv, a, r,
+                       ln_g, ln_b, ln_eps, x_out, (float*)kcache, (float*)vcache, (const int*)ctr, out, H, Lmax);
+  else return EVT_EINVAL;
   return evt_check_launch();
 }
 

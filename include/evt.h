@@ -321,6 +321,12 @@ int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* 
  * (t2s_model.py:187-204 without the torch.cat growth).  D == 32. */
 int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
                  int32_t H, int32_t D, int32_t Lmax, void* stream);
+/* evt_dec_gemv (the packed in-projection) and evt_dec_attn in one launch: workgroup (b, h) computes only its head's
+ * 3*D rows of Wqkv [3*H*D][H*D] (+ bqkv) from x = a or LayerNorm(a + r) (workgroups h == 0 store it to x_out), then
+ * appends and attends as evt_dec_attn does.  The weights and the cache share `dtype`.  H*D == 512, D == 32. */
+int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const float* a, const float* r,
+                     const float* ln_g, const float* ln_b, float ln_eps, float* x_out, void* kcache, void* vcache,
+                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, void* stream);
 /* sample() of models/utils.py:125-171 for one step: the EOS column is dropped while ctr[IDX] < no_eos_steps
  * (t2s_model.py:833-834); repetition penalty over y[b][0..ctr[YCOUNT]); nucleus cut (top_p < 1) on the un-tempered
  * logits; division by max(temperature, 1e-5); top-k pivot (top_k <= 0: off; ties kept); softmax;
@@ -335,6 +341,10 @@ typedef struct evt_sample_params {
 } evt_sample_params;
 int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, const int32_t* ctr, const float* noise,
                    int32_t* stop_idx, float* probs_out, int32_t B, void* stream);
+/* evt_dec_sample + evt_dec_embed + evt_dec_advance(dpos) for ONE sequence in a single launch */
+int evt_dec_sample_embed(const evt_sample_params* p, const float* logits, int64_t* y, int32_t* ctr, const float* noise,
+                         int32_t* stop_idx, const float* emb, const float* pe, const float* alpha, float x_scale, float* x,
+                         int32_t E, int32_t npos, int32_t dpos, void* stream);
 /* x[b] = emb[y[b][ctr[YCOUNT]]] * x_scale + alpha[0] * pe[ctr[YLEN] + ctr[IDX]]  (t2s_model.py:860-861); emb fp32
  * [V][E], pe fp32 [npos][E]. */
 int evt_dec_embed(const float* emb, const float* pe, const float* alpha, float x_scale, const int64_t* y,

@@ -80,6 +80,84 @@ def test_dec_attn(gpu, dtype, pos):
     assert rel(out, want) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("pos,use_ln", [(0, False), (300, True), (1100, True)])
+def test_dec_qkv_attn(gpu, dtype, pos, use_ln):
+    """in-projection of the head's own rows + cache attention in one launch == evt_dec_gemv + evt_dec_attn"""
+    from easevoice_trainer_amd.hip import lib as L
+
+    B, H, D, Lmax = 2, 16, 32, 1536
+    E = H * D
+    g = torch.Generator().manual_seed(pos + 11)
+    W = (torch.randn(3 * E, E, generator=g) / E ** 0.5).to(dtype)
+    bias = 0.1 * torch.randn(3 * E, generator=g)
+    a, r = torch.randn(B, E, generator=g), torch.randn(B, E, generator=g)
+    lg, lb = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    kc, vc = torch.randn(B, Lmax, E, generator=g).to(dtype), torch.randn(B, Lmax, E, generator=g).to(dtype)
+    x = F.layer_norm(a + r, (E,), lg, lb, 1e-5) if use_ln else a
+    qkv = x @ W.float().t() + bias
+    knew, vnew = qkv[:, E:2 * E].to(dtype), qkv[:, 2 * E:].to(dtype)
+    K = torch.cat([kc[:, :pos].float(), knew.float()[:, None]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    Vv = torch.cat([vc[:, :pos].float(), vnew.float()[:, None]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    q = qkv[:, :E].view(B, 1, H, D).transpose(1, 2)
+    want = (F.softmax(q @ K.transpose(-1, -2) / D ** 0.5, -1) @ Vv).transpose(1, 2).reshape(B, E)
+    Wg, bg, ag, rg, lgg, lbg = (t.to(gpu) for t in (W, bias, a, r, lg, lb))
+    kcg, vcg = kc.to(gpu), vc.to(gpu)
+    ctr = torch.tensor([pos, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=gpu)
+    out, xo = torch.empty(B, E, device=gpu), torch.full((B, E), -7.0, device=gpu)
+    L.check(L.lib().evt_dec_qkv_attn(L.dt_of(Wg), L.ptr(Wg), L.ptr(bg), L.ptr(ag), L.ptr(rg) if use_ln else None,
+                                     L.ptr(lgg) if use_ln else None, L.ptr(lbg) if use_ln else None, C.c_float(1e-5),
+                                     L.ptr(xo) if use_ln else None, L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
+                                     Lmax, L.stream_ptr()), "evt_dec_qkv_attn")
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 2e-2       # bf16: the new key/value are rounded after an fp32 projection
+    assert rel(out, want) < tol
+    assert rel(kcg[:, pos], knew) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert torch.equal(kcg[:, :pos].cpu(), kc[:, :pos]) and torch.equal(vcg[:, pos + 1:].cpu(), vc[:, pos + 1:])
+    if use_ln:
+        assert rel(xo, x) < 1e-5
+
+
+def test_dec_sample_embed_fused(gpu):
+    """sampling + embedding + counter update in one launch == the three separate entry points"""
+    from easevoice_trainer_amd.hip import lib as L
+
+    V, E, ymax, ycount, idx, ylen = 1025, 512, 512, 40, 17, 12
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(1, V, generator=g) * 3).to(gpu)
+    y = torch.zeros(1, ymax, dtype=torch.int64)
+    y[:, :ycount] = torch.randint(0, 1024, (1, ycount), generator=g)
+    noise = torch.empty(32, V).exponential_(1, generator=g).to(gpu)
+    emb, pe = torch.randn(V, E, generator=g).to(gpu), torch.randn(600, E, generator=g).to(gpu)
+    alpha = torch.tensor([0.7], device=gpu)
+    sp = L.SampleParams(V, 1024, 15, 11, ymax, 1.0, 1.0, 1.35, 9)
+    res = []
+    for fused in (False, True):
+        yg = y.to(gpu).clone()
+        ctr = torch.tensor([100, idx, ycount, ylen, 0, 0, 0, 0], dtype=torch.int32, device=gpu)
+        stop = torch.full((1,), -1, dtype=torch.int32, device=gpu)
+        x = torch.zeros(1, E, device=gpu)
+        lib = L.lib()
+        if fused:
+            L.check(lib.evt_dec_sample_embed(C.byref(sp), L.ptr(logits), L.ptr(yg), L.ptr(ctr), L.ptr(noise), L.ptr(stop),
+                                             L.ptr(emb), L.ptr(pe), L.ptr(alpha), C.c_float(1.0), L.ptr(x), E, 600, 1,
+                                             L.stream_ptr()), "fused")
+        else:
+            L.check(lib.evt_dec_sample(C.byref(sp), L.ptr(logits), L.ptr(yg), L.ptr(ctr), L.ptr(noise), L.ptr(stop), None, 1,
+                                       L.stream_ptr()), "sample")
+            L.check(lib.evt_dec_embed(L.ptr(emb), L.ptr(pe), L.ptr(alpha), C.c_float(1.0), L.ptr(yg), L.ptr(ctr), L.ptr(x), 1,
+                                      E, ymax, 600, L.stream_ptr()), "embed")
+            L.check(lib.evt_dec_advance(L.ptr(ctr), 1, L.stream_ptr()), "advance")
+        torch.cuda.synchronize()
+        res.append((yg.cpu(), ctr.cpu(), x.cpu(), stop.cpu()))
+    for k in (0, 1, 3):
+        assert torch.equal(res[0][k], res[1][k])
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-6)
+    tok = int(res[0][0][0, ycount])
+    assert res[0][1].tolist()[:4] == [101, idx + 1, ycount + 1, ylen]
+    assert torch.allclose(res[1][2][0], (emb[tok] * 1.0 + 0.7 * pe[ylen + idx]).cpu(), rtol=1e-6, atol=1e-6)
+
+
 def _sample(gpu, logits, y, ycount, idx, noise, top_k=15, top_p=1.0, temperature=1.0, rp=1.35, eos=1024, seed=0):
     from easevoice_trainer_amd.hip import lib as L
 
