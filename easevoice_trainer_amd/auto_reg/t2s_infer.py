@@ -5,7 +5,7 @@ src/easevoice/soundstorm/auto_reg/models/t2s_model.py:762-863, with T2SBlock.pro
 Same token sequence as the reference for the same sampling noise; a different execution plan:
   * prompt pass: the training kernels without gradients (packed qkv GEMM, analytic prefix-LM flash attention, fused
     residual+LayerNorm); its keys/values are copied once into a preallocated cache [layers][B][Lmax][E];
-  * token steps: four launches per block (csrc/s1_decode.hip: in-projection + cache attention, out-projection, two for
+  * token steps: five launches per block (csrc/s1_decode.hip: in-projection, cache attention, out-projection, two for
     the MLP) + logits + one for sampling / embedding / counters, all reading their per-step state (cache length, step
     index, token count) from device memory, captured once into a HIP graph and replayed per token.  The host reads the stop flag every `poll` steps; tokens decoded past the stop are discarded.
 The reference reads two device scalars per token (the EOS tests of :846) and reallocates every cache tensor per token."""
@@ -57,7 +57,7 @@ class DecodeSession:
         self.kc = z(nl, B, Lmax, E, dt=dtype)
         self.vc = z(nl, B, Lmax, E, dt=dtype)
         self.xa, self.xb = z(B, E), z(B, E)
-        self.att, self.t, self.u = z(B, E), z(B, E), z(B, E)
+        self.qkv, self.att, self.t, self.u = z(B, 3 * E), z(B, E), z(B, E), z(B, E)
         self.hid = z(B, 4 * E)
         self.logits = z(B, V)
         self.y = z(B, ymax, dt=torch.int64)
@@ -85,14 +85,22 @@ class DecodeSession:
                                          L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
                                          L.stream_ptr()), "evt_dec_qkv_attn")
 
-    def step_launches(self, W, sp, noise, pe):
-        """one token: 24 x (qkv + cache attention, out-proj, ffn1, ffn2) + logits + sample/embed/counters = 98 launches"""
+    def step_launches(self, W, sp, noise, pe, fused_qkv=False):
+        """one token: 24 x (in-projection, cache attention, out-proj, ffn1, ffn2) + logits + one launch for sampling /
+        embedding / counters = 122 launches.  fused_qkv puts the in-projection into the attention launch (98 launches):
+        16 workgroups then stream all of W_qkv, which is slower on the device (measured 696 vs 614 us per token under
+        graph replay) but faster when the HOST is the bottleneck (eager launches: 959 vs 1210 us)."""
         prev = None
         for i, w in enumerate(W.layers):
-            if prev is None:
-                self._qkv_attn(i, w, self.xa, None, None, None, 0.0, None)
-            else:       # input = LayerNorm2 of the previous block, stored to xa for this block's first residual
-                self._qkv_attn(i, w, self.xb, self.u, prev["g2"], prev["be2"], prev["eps2"], self.xa)
+            ln = (None, None, None, 0.0, None) if prev is None else (self.u, prev["g2"], prev["be2"], prev["eps2"], self.xa)
+            src = self.xa if prev is None else self.xb   # later blocks: LayerNorm2 of the previous one, stored to xa
+            if fused_qkv:
+                self._qkv_attn(i, w, src, *ln)
+            else:
+                self._gemv(w["wqkv"], w["bqkv"], src, *ln, self.qkv)
+                L.check(L.lib().evt_dec_attn(L.dt_of(self.kc), L.ptr(self.qkv), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
+                                             L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
+                                             L.stream_ptr()), "evt_dec_attn")
             self._gemv(w["wo"], w["bo"], self.att, None, None, None, 0.0, None, self.t)
             self._gemv(w["w1"], w["b1"], self.xa, self.t, w["g1"], w["be1"], w["eps1"], self.xb, self.hid, relu=1)
             self._gemv(w["w2"], w["b2"], self.hid, None, None, None, 0.0, None, self.u)
@@ -200,7 +208,7 @@ class T2SInfer:
             if use_graph:
                 S.graph.replay()
             else:
-                S.step_launches(W, sp, noise, pe)
+                S.step_launches(W, sp, noise, pe, fused_qkv=True)
             done += 1
             if done % poll == 0 or done == n_max:
                 stop_at = int(S.stop[0])            # the only device->host read of the loop
