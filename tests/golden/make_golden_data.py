@@ -105,6 +105,24 @@ def main():
                     rec[k]["values"] = t.tolist()
             out["s2_collate"].append(rec)
 
+        # the `token` step (normalize.py:181-211) over the same 4-cnhubert files, with the reference's model
+        from src.easevoice.module import models as RM
+        from util_fill import fill_module
+        cfg = json.load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "s2.json")))
+        vq = RM.SynthesizerTrn(1025, 32, n_speakers=300, **cfg["model"])
+        fill_module(vq, 1)
+        vq.eval()
+        tsv = ["item_name\tsemantic_audio"]
+        token_names = [it[0] for it in F.ITEMS] + ["missing.wav"]
+        with torch.no_grad():
+            for name in token_names:
+                hp_ = os.path.join(root, "4-cnhubert", name + ".pt")
+                if not os.path.exists(hp_):
+                    continue
+                codes = vq.extract_latent(torch.load(hp_, map_location="cpu").float())
+                tsv.append("%s\t%s" % (name, " ".join(str(i) for i in codes[0, 0, :].tolist())))
+        out["semantic_tsv"] = dict(names=token_names, text="\n".join(tsv) + "\n")
+
         # s1 table
         sem = DS.Text2SemanticDataset(phoneme_path=os.path.join(root, "2-name2text.txt"),
                                       semantic_path=os.path.join(root, "6-name2semantic.tsv"), max_sec=100, pad_val=1024)

@@ -254,3 +254,24 @@ def test_open_source_picks_the_feature_directory(feature_dir, monkeypatch):
     assert isinstance(src, D.S1Reader)
     with pytest.raises(FileNotFoundError):
         data_mod.open_source("s2", os.path.join(feature_dir, "missing"), "cpu", lambda n: None, batch_size=4, cfg=CFG)
+
+
+def test_semantic_tsv_matches_reference_token_step(feature_dir, gold, tmp_path):
+    """6-name2semantic.tsv written from the 4-cnhubert files == the reference's `token` step with the same weights"""
+    from cpu_emu import cpu_emulation
+    from util_fill import fill_module
+    from easevoice_trainer_amd.inference.semantic import write_semantic_tsv
+    from easevoice_trainer_amd.module import models
+
+    hps = json.load(open(os.path.join(os.path.dirname(HERE), "configs", "s2.json")))
+    g = gold["semantic_tsv"]
+    with cpu_emulation():
+        net = models.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+        fill_module(net, 1)
+        net.eval()
+        out = str(tmp_path / "6-name2semantic.tsv")
+        n = write_semantic_tsv(net.extract_latent, g["names"], os.path.join(feature_dir, "4-cnhubert"), out)
+    assert open(out, encoding="utf8").read() == g["text"] and n == g["text"].count("\n") - 1
+    # and the file is what the s1 reader parses
+    tab = D.S1SemanticTable(os.path.join(feature_dir, "2-name2text.txt"), out, symbol_to_id={s: i for i, s in enumerate(gold["symbols"])})
+    assert len(tab) >= 1
