@@ -63,6 +63,8 @@ class DecodeSession:
         self.y = z(B, ymax, dt=torch.int64)
         self.ctr = z(8, dt=torch.int32)
         self.stop = torch.full((B,), -1, dtype=torch.int32, device=device)
+        self.x_lens, self.x_len = None, 0      # key-padding of a batch of texts (infer_panel_batch_infer); None = no padding
+        self.x_lens_buf = z(B, dt=torch.int32)
         self.graph, self.graph_key = None, None
 
     # ---- launches ----
@@ -73,17 +75,27 @@ class DecodeSession:
                 "evt_dec_gemv")
 
     def _sample_embed_advance(self, W, sp, noise, pe, dpos):
-        """sampling, append, embedding of the new token and the counter update: one launch for one sequence"""
-        L.check(L.lib().evt_dec_sample_embed(
-            C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise), L.ptr(self.stop), L.ptr(W.emb),
-            L.ptr(pe), L.ptr(W.alpha), C.c_float(self.model.ar_audio_position.x_scale), L.ptr(self.xa), self.E, pe.size(0),
-            dpos, L.stream_ptr()), "evt_dec_sample_embed")
+        """sampling, append, embedding of the new token and the counter update: one launch for one sequence, three for a
+        batch (the counters may only move after every row's workgroup has read them)"""
+        lib = L.lib()
+        xs = C.c_float(self.model.ar_audio_position.x_scale)
+        if self.B == 1:
+            L.check(lib.evt_dec_sample_embed(
+                C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise), L.ptr(self.stop),
+                L.ptr(W.emb), L.ptr(pe), L.ptr(W.alpha), xs, L.ptr(self.xa), self.E, pe.size(0), dpos, L.stream_ptr()),
+                "evt_dec_sample_embed")
+            return
+        L.check(lib.evt_dec_sample(C.byref(sp), L.ptr(self.logits), L.ptr(self.y), L.ptr(self.ctr), L.ptr(noise),
+                                   L.ptr(self.stop), None, self.B, L.stream_ptr()), "evt_dec_sample")
+        L.check(lib.evt_dec_embed(L.ptr(W.emb), L.ptr(pe), L.ptr(W.alpha), xs, L.ptr(self.y), L.ptr(self.ctr), L.ptr(self.xa),
+                                  self.B, self.E, self.ymax, pe.size(0), L.stream_ptr()), "evt_dec_embed")
+        L.check(lib.evt_dec_advance(L.ptr(self.ctr), dpos, L.stream_ptr()), "evt_dec_advance")
 
     def _qkv_attn(self, i, w, a, r, g, b, eps, x_out):
         L.check(L.lib().evt_dec_qkv_attn(L.dt_of(self.kc), L.ptr(w["wqkv"]), L.ptr(w["bqkv"]), L.ptr(a), L.ptr(r), L.ptr(g),
                                          L.ptr(b), C.c_float(eps), L.ptr(x_out), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
                                          L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
-                                         L.stream_ptr()), "evt_dec_qkv_attn")
+                                         L.ptr(self.x_lens), self.x_len, L.stream_ptr()), "evt_dec_qkv_attn")
 
     def step_launches(self, W, sp, noise, pe, fused_qkv=False):
         """one token: 24 x (in-projection, cache attention, out-proj, ffn1, ffn2) + logits + one launch for sampling /
@@ -100,7 +112,7 @@ class DecodeSession:
                 self._gemv(w["wqkv"], w["bqkv"], src, *ln, self.qkv)
                 L.check(L.lib().evt_dec_attn(L.dt_of(self.kc), L.ptr(self.qkv), L.ptr(self.kc[i]), L.ptr(self.vc[i]),
                                              L.ptr(self.ctr), L.ptr(self.att), self.B, self.H, self.E // self.H, self.Lmax,
-                                             L.stream_ptr()), "evt_dec_attn")
+                                             L.ptr(self.x_lens), self.x_len, L.stream_ptr()), "evt_dec_attn")
             self._gemv(w["wo"], w["bo"], self.att, None, None, None, 0.0, None, self.t)
             self._gemv(w["w1"], w["b1"], self.xa, self.t, w["g1"], w["be1"], w["eps1"], self.xb, self.hid, relu=1)
             self._gemv(w["w2"], w["b2"], self.hid, None, None, None, 0.0, None, self.u)
@@ -129,23 +141,31 @@ class T2SInfer:
             self._sessions[key] = DecodeSession(self.model, B, Lmax, ymax, dtype, device)
         return self._sessions[key]
 
+    MAX_ROWS = 4      # rows per session (kMaxB of csrc/s1_decode.hip); larger batches run in groups
+
     @torch.no_grad()
-    def infer_panel_naive(self, x, x_lens, prompts, bert_feature, top_k=-100, top_p=100, early_stop_num=-1,
-                          temperature=1.0, repetition_penalty=1.35, noise=None, seed=None, poll=8, **kwargs):
+    def _decode(self, xs, berts, prompts, no_eos_steps, top_k, top_p, early_stop_num, temperature, repetition_penalty,
+                noise=None, seed=None, poll=8):
+        """xs: B id vectors (any lengths), berts: B x [1024, n_b], prompts [B, y_len] or None.  Returns (token buffer
+        [B, >= y_len + steps] on the device, per-row index of the last sampled step, per-row EOS flag, y_len)."""
         m = self.model
         if m.training:
-            raise L.EvtError("infer_panel_naive needs model.eval() (the reference decodes with dropout off)")
-        dev, cd = x.device, m.cd
-        B, x_len = x.shape
-        if B != 1:
-            raise L.EvtError("one sequence per call (infer_panel_naive_batched loops over the items, t2s_model.py:732-760)")
+            raise L.EvtError("decoding needs model.eval() (the reference decodes with dropout off)")
+        dev, cd = xs[0].device, m.cd
+        B = len(xs)
         W = self.weights(cd)
-        # ---- prompt pass (t2s_model.py:775-825, T2SBlock.process_prompt) ----
-        xe = m.ar_text_embedding(x)
-        xe = xe + F.linear(bert_feature.transpose(1, 2).to(cd), m.bert_proj.weight.to(cd), m.bert_proj.bias.to(cd)).to(xe.dtype)
-        xe = m.ar_text_position(xe)
-        ref_free = prompts is None
-        if ref_free:
+        # ---- prompt pass (t2s_model.py:575-660 / 775-825, T2SBlock.process_prompt) ----
+        x_lens = [int(x.numel()) for x in xs]
+        x_len = max(x_lens)
+        rows = []
+        for x, bert in zip(xs, berts):
+            xe = m.ar_text_embedding(x.unsqueeze(0))
+            xe = xe + F.linear(bert.transpose(0, 1).unsqueeze(0).to(cd), m.bert_proj.weight.to(cd), m.bert_proj.bias.to(cd)
+                               ).to(xe.dtype)
+            xe = m.ar_text_position(xe).squeeze(0)
+            rows.append(F.pad(xe, (0, 0, 0, x_len - xe.size(0))))      # padded text positions: masked as keys below
+        xe = torch.stack(rows, dim=0)
+        if prompts is None:
             y_len, xy = 0, xe
         else:
             y_len = prompts.size(1)
@@ -154,7 +174,7 @@ class T2SInfer:
         src_len = x_len + y_len
         n_max = MAX_STEPS if early_stop_num == -1 else max(1, min(MAX_STEPS, int(early_stop_num) + 1))
         S = self.session(B, src_len + n_max + 1, y_len + n_max + 1, cd, dev)
-        xl = torch.full((B,), x_len, dtype=torch.int32, device=dev)
+        xl = torch.tensor(x_lens, dtype=torch.int32, device=dev)
         yl = torch.full((B,), y_len, dtype=torch.int32, device=dev)
         for i, lyr in enumerate(m.h.layers):
             w = W.layers[i]
@@ -169,18 +189,24 @@ class T2SInfer:
             xy = AddLayerNormFn.apply(xy, ff, w["g2"], w["be2"], w["eps2"])
         # ---- state ----
         S.y.zero_()
-        if not ref_free:
+        if prompts is not None:
             S.y[:, :y_len].copy_(prompts)
         # the sampling seed is device state like the counters (a new one per call must not force a re-capture); without
         # an explicit seed it is drawn from torch's CPU generator, so torch.manual_seed makes a run repeatable
         seed = int(seed if seed is not None else torch.randint(0, 2 ** 31 - 1, (1,)).item()) & 0x7FFFFFFF
         S.ctr.copy_(torch.tensor([src_len, 0, y_len, y_len, seed, 0, 0, 0], dtype=torch.int32))
         S.stop.fill_(-1)
-        sp = L.SampleParams(S.V, m.EOS, int(top_k) if top_k is not None else 0, NO_EOS_STEPS, S.ymax, float(top_p),
-                            float(temperature), float(repetition_penalty), 0x5EED5EED)
+        padded = min(x_lens) < x_len
+        if padded:
+            S.x_lens_buf.copy_(xl)
+        S.x_lens, S.x_len = (S.x_lens_buf if padded else None), x_len
+        noise_rows = 1
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
-            assert noise.dim() == 2 and noise.size(1) == S.V and noise.size(0) >= n_max
+            noise_rows = 1 if noise.dim() == 2 else noise.size(1)
+            assert noise.size(-1) == S.V and noise.size(0) >= n_max and noise_rows in (1, B)
+        sp = L.SampleParams(S.V, m.EOS, int(top_k) if top_k is not None else 0, no_eos_steps, S.ymax, float(top_p),
+                            float(temperature), float(repetition_penalty), 0x5EED5EED, noise_rows)
         pe = m.ar_audio_position.pe(max(4000, y_len + n_max + 1), dev, torch.float32).contiguous()
         # ---- step 0: logits of the last prompt position, sample, embed ----
         S.xb.copy_(xy[:, -1].float())
@@ -188,7 +214,7 @@ class T2SInfer:
         S._sample_embed_advance(W, sp, noise, pe, 0)
         # ---- token steps: one graph replay each ----
         use_graph = os.environ.get("EVT_DECODE_GRAPH", "1") != "0"
-        gkey = (bytes(sp), None if noise is None else noise.data_ptr(), pe.data_ptr(), id(W))
+        gkey = (bytes(sp), None if noise is None else noise.data_ptr(), pe.data_ptr(), id(W), padded, x_len)
         if use_graph and S.graph_key != gkey:
             # warm-up launches outside the capture, on throw-away counters: restore the state afterwards
             keep = (S.ctr.clone(), S.y.clone(), S.stop.clone(), S.xa.clone())
@@ -203,22 +229,30 @@ class T2SInfer:
             S.ctr.copy_(keep[0]); S.y.copy_(keep[1]); S.stop.copy_(keep[2]); S.xa.copy_(keep[3])
             S.graph, S.graph_key, S._keep = g, gkey, (sp, noise, pe, W)
         done = 1
-        stop_at = int(S.stop[0]) if n_max == 1 else -1
-        while done < n_max and stop_at < 0:
+        stop = S.stop.tolist() if n_max == 1 else [-1] * B
+        while done < n_max and min(stop) < 0:
             if use_graph:
                 S.graph.replay()
             else:
                 S.step_launches(W, sp, noise, pe, fused_qkv=True)
             done += 1
             if done % poll == 0 or done == n_max:
-                stop_at = int(S.stop[0])            # the only device->host read of the loop
-        if stop_at < 0:
-            stop_at = n_max - 1                     # early_stop_num reached, or 1500 steps without EOS
-        total = y_len + stop_at + 1
-        y = S.y[:, :total].clone()
-        if ref_free:
-            return y[:, :-1].to(torch.int32), 0
-        return y[:, :-1], stop_at - 1
+                stop = S.stop.tolist()              # the only device->host read of the loop
+        eos = [s >= 0 for s in stop]
+        last = [s if s >= 0 else n_max - 1 for s in stop]   # else: early_stop_num reached, or 1500 steps without EOS
+        return S.y, last, eos, y_len
+
+    def infer_panel_naive(self, x, x_lens, prompts, bert_feature, top_k=-100, top_p=100, early_stop_num=-1,
+                          temperature=1.0, repetition_penalty=1.35, noise=None, seed=None, poll=8, **kwargs):
+        """t2s_model.py:762-863: one sequence; returns (y without its last token, idx - 1), or (.., 0) without a prompt"""
+        if x.size(0) != 1:
+            raise L.EvtError("one sequence per call (infer_panel_naive_batched loops over the items, t2s_model.py:732-760)")
+        ybuf, last, _eos, y_len = self._decode([x[0]], [bert_feature[0]], prompts, NO_EOS_STEPS, top_k, top_p, early_stop_num,
+                                               temperature, repetition_penalty, noise=noise, seed=seed, poll=poll)
+        y = ybuf[:, :y_len + last[0]].clone()       # the last sampled token (EOS or the stop token) is dropped
+        if prompts is None:
+            return y.to(torch.int32), 0
+        return y, last[0] - 1
 
     def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, **kw):
         ys, idxs = [], []
@@ -227,4 +261,28 @@ class T2SInfer:
                                             else None, bert_feature[i].unsqueeze(0), **kw)
             ys.append(y[0])
             idxs.append(idx)
+        return ys, idxs
+
+    def infer_panel_batch_infer(self, x, x_lens, prompts, bert_feature, top_k=-100, top_p=100, early_stop_num=-1,
+                                temperature=1.0, repetition_penalty=1.35, noise=None, seed=None, poll=8, **kwargs):
+        """t2s_model.py:563-730, the TTS default (parallel_infer=True): texts of different lengths decoded together.
+        x: list of id vectors, bert_feature: list of [1024, n].  Rows are independent (padded text positions are masked
+        as keys, a finished row only leaves the batch), so instead of compacting the batch whenever a row meets EOS, all
+        rows of a group keep stepping through the same graph and each row's tokens are cut at its own stop.  Kept
+        differences to infer_panel_naive: the EOS column is dropped at step 0 only, the returned index is idx - 1 for an
+        EOS stop and idx for the early stop."""
+        if prompts is None:
+            return self.infer_panel_naive_batched(x, x_lens, prompts, bert_feature, top_k=top_k, top_p=top_p,
+                                                  early_stop_num=early_stop_num, temperature=temperature, noise=noise,
+                                                  seed=seed, poll=poll)
+        ys, idxs = [], []
+        for g0 in range(0, len(x), self.MAX_ROWS):
+            rows = list(range(g0, min(len(x), g0 + self.MAX_ROWS)))
+            nz = noise if noise is None or noise.dim() == 2 else noise[:, rows]
+            ybuf, last, eos, y_len = self._decode([x[r] for r in rows], [bert_feature[r] for r in rows], prompts[rows], 1,
+                                                  top_k, top_p, early_stop_num, temperature, repetition_penalty, noise=nz,
+                                                  seed=None if seed is None else seed + g0, poll=poll)
+            for k in range(len(rows)):
+                ys.append(ybuf[k, :y_len + last[k]].clone())
+                idxs.append(last[k] - 1 if eos[k] else last[k])
         return ys, idxs

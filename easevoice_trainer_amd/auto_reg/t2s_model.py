@@ -229,5 +229,8 @@ class Text2SemanticDecoder(nn.Module):
 
     infer_panel = infer_panel_naive
 
+    def infer_panel_batch_infer(self, x, x_lens, prompts, bert_feature, **kwargs):
+        return self._infer().infer_panel_batch_infer(x, x_lens, prompts, bert_feature, **kwargs)
+
     def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, **kwargs):
         return self._infer().infer_panel_naive_batched(x, x_lens, prompts, bert_feature, **kwargs)

@@ -201,14 +201,18 @@ template <typename T, int D> struct Prefetch {
 template <typename T, int D>
 __device__ __forceinline__ void attn_tail(const Prefetch<T, D>& pf, const float* qs, const float* kn, const float* vn,
                                           float* sc, float* red, float (*part)[D + 1], const T* kc, const T* vc,
-                                          float* __restrict__ out, int b, int h, int E, int Lmax, int L, int pos) {
+                                          float* __restrict__ out, int b, int h, int E, int Lmax, int L, int pos,
+                                          int mlo, int mhi) {
+  // keys mlo <= j < mhi are padding of a shorter text in a batch (infer_panel_batch_infer's padding mask): skipped
   using S = AttnShape<T, D>;
   constexpr int V = S::V, C = S::C, G = S::G, PF = S::PF;
   const int tid = threadIdx.x, g = tid / C, c = tid % C;
   float mx = -INFINITY;
   for (int j = tid; j < L; j += 256) {
     float s = 0.f;
-    if (j == pos) {
+    if (j >= mlo && j < mhi) {
+      s = -INFINITY;
+    } else if (j == pos) {
 #pragma unroll
       for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
     } else {
@@ -234,7 +238,7 @@ __device__ __forceinline__ void attn_tail(const Prefetch<T, D>& pf, const float*
   mx = block_max(mx, red, 4);
   float sum = 0.f;
   for (int j = tid; j < L; j += 256) {
-    const float e = expf(sc[j] - mx);
+    const float e = sc[j] == -INFINITY ? 0.f : expf(sc[j] - mx);
     sc[j] = e;
     sum += e;
   }
@@ -282,7 +286,8 @@ __device__ __forceinline__ void attn_tail(const Prefetch<T, D>& pf, const float*
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T* kc, T* vc, const int* __restrict__ ctr,
-                                                float* __restrict__ out, int H, int Lmax) {
+                                                float* __restrict__ out, int H, int Lmax,
+                                                const int* __restrict__ x_lens, int x_len) {
   extern __shared__ float sc[];   // [Lmax] scores -> probabilities
   __shared__ float qs[D], kn[D], vn[D], red[4], part[AttnShape<T, D>::G][D + 1];
   const int tid = threadIdx.x;
@@ -302,7 +307,8 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ qkv, T
     vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
   }
   __syncthreads();
-  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos);
+  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos, x_lens ? x_lens[b] : 0,
+                  x_lens ? x_len : 0);
 }
 
 // ---- the same with the head's own rows of the packed in-projection computed in the launch -------------------------
@@ -314,7 +320,8 @@ __global__ __launch_bounds__(256) void dec_qkv_attn(const T* __restrict__ W, con
                                                     const float* __restrict__ a, const float* __restrict__ r,
                                                     const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                     float eps, float* x_out, T* kc, T* vc, const int* __restrict__ ctr,
-                                                    float* __restrict__ out, int H, int Lmax) {
+                                                    float* __restrict__ out, int H, int Lmax,
+                                                    const int* __restrict__ x_lens, int x_len) {
   extern __shared__ float sc[];   // [Lmax]
   constexpr int V = WVec<T>::V;
   constexpr int E = NPASS * 64 * V;       // model width == K of the projection
@@ -401,7 +408,8 @@ __global__ __launch_bounds__(256) void dec_qkv_attn(const T* __restrict__ W, con
     vc[((long)b * Lmax + pos) * E + h * D + tid] = vq;
   }
   __syncthreads();
-  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos);
+  attn_tail<T, D>(pf, qs, kn, vn, sc, red, part, kc, vc, out, b, h, E, Lmax, L, pos, x_lens ? x_lens[b] : 0,
+                  x_lens ? x_len : 0);
 }
 
 // ---- sampling ---------------------------------------------------------------------------------------------------
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(1024) void dec_sample(evt_sample_params p, const fl
       if (probs_out) probs_out[(long)b * V + v] = pr;
       float q;
       if (noise) {
-        q = noise[(long)idx * V + v];
+        q = noise[((long)idx * p.noise_rows + (p.noise_rows > 1 ? b : 0)) * V + v];
       } else {
         const unsigned hsh =
             mix32s(mix32s((p.seed ^ (unsigned)ctr[EVT_DEC_SEED]) + (unsigned)idx * 0x9E3779B9u) ^ ((unsigned)b << 16) ^ (unsigned)v);
@@ -622,17 +630,17 @@ int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* 
 }
 
 int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
-                 int32_t H, int32_t D, int32_t Lmax, void* stream) {
+                 int32_t H, int32_t D, int32_t Lmax, const int32_t* x_lens, int32_t x_len, void* stream) {
   if (!qkv || !kcache || !vcache || !ctr || !out || B <= 0 || H <= 0 || Lmax <= 0) return EVT_EINVAL;
   if (D != 32 || (size_t)Lmax * 4 > 60 * 1024) return EVT_ENOTSUP;
   const size_t shm = (size_t)Lmax * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (cdtype == EVT_DT_BF16)
     hipLaunchKernelGGL((dec_attn<bf16_t, 32>), dim3(B * H), dim3(256), shm, st, qkv, (bf16_t*)kcache, (bf16_t*)vcache,
-                       (const int*)ctr, out, H, Lmax);
+                       (const int*)ctr, out, H, Lmax, (const int*)x_lens, x_len);
   else if (cdtype == EVT_DT_F32)
     hipLaunchKernelGGL((dec_attn<float, 32>), dim3(B * H), dim3(256), shm, st, qkv, (float*)kcache, (float*)vcache,
-                       (const int*)ctr, out, H, Lmax);
+                       (const int*)ctr, out, H, Lmax, (const int*)x_lens, x_len);
   else return EVT_EINVAL;
   return evt_check_launch();
 }
@@ -642,7 +650,9 @@ int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, 
   if (!p || !logits || !y || !ctr || !stop_idx || B <= 0) return EVT_EINVAL;
   if (p->V <= 1 || p->V > kSortN || p->ymax <= 0 || p->repetition_penalty <= 0.f) return EVT_EINVAL;
   EmbedArgs none{};
-  hipLaunchKernelGGL(dec_sample, dim3(B), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (int*)ctr, noise,
+  evt_sample_params sp = *p;
+  if (sp.noise_rows < 1) sp.noise_rows = 1;
+  hipLaunchKernelGGL(dec_sample, dim3(B), dim3(1024), 0, (hipStream_t)stream, sp, logits, (long*)y, (int*)ctr, noise,
                      (int*)stop_idx, probs_out, none);
   return evt_check_launch();
 }
@@ -653,14 +663,17 @@ int evt_dec_sample_embed(const evt_sample_params* p, const float* logits, int64_
   if (!p || !logits || !y || !ctr || !stop_idx || !emb || !pe || !alpha || !x || E <= 0 || npos <= 0) return EVT_EINVAL;
   if (p->V <= 1 || p->V > kSortN || p->ymax <= 0 || p->repetition_penalty <= 0.f) return EVT_EINVAL;
   EmbedArgs ea{emb, pe, alpha, x, x_scale, E, npos, dpos};
-  hipLaunchKernelGGL(dec_sample, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p, logits, (long*)y, (int*)ctr, noise,
+  evt_sample_params sp = *p;
+  sp.noise_rows = 1;
+  hipLaunchKernelGGL(dec_sample, dim3(1), dim3(1024), 0, (hipStream_t)stream, sp, logits, (long*)y, (int*)ctr, noise,
                      (int*)stop_idx, (float*)nullptr, ea);
   return evt_check_launch();
 }
 
 int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const float* a, const float* r,
                      const float* ln_g, const float* ln_b, float ln_eps, float* x_out, void* kcache, void* vcache,
-                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, void* stream) {
+                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, const int32_t* x_lens,
+                     int32_t x_len, void* stream) {
   if (!Wqkv || !bqkv || !a || !kcache || !vcache || !ctr || !out || B <= 0 || H <= 0 || Lmax <= 0) return EVT_EINVAL;
   if (r && (!ln_g || !ln_b)) return EVT_EINVAL;
   if (D != 32 || H * D != 512 || (size_t)Lmax * 4 > 48 * 1024) return EVT_ENOTSUP;
@@ -668,10 +681,12 @@ int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const f
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL((dec_qkv_attn<bf16_t, 32, 1>), dim3(B * H), dim3(256), shm, st, (const bf16_t*)Wqkv, bqkv, a, r,
-                       ln_g, ln_b, ln_eps, x_out, (bf16_t*)kcache, (bf16_t*)vcache, (const int*)ctr, out, H, Lmax);
+                       ln_g, ln_b, ln_eps, x_out, (bf16_t*)kcache, (bf16_t*)vcache, (const int*)ctr, out, H, Lmax,
+                       (const int*)x_lens, x_len);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL((dec_qkv_attn<float, 32, 2>), dim3(B * H), dim3(256), shm, st, (const float*)Wqkv, bqkv, a, r,
-                       ln_g, ln_b, ln_eps, x_out, (float*)kcache, (float*)vcache, (const int*)ctr, out, H, Lmax);
+                       ln_g, ln_b, ln_eps, x_out, (float*)kcache, (float*)vcache, (const int*)ctr, out, H, Lmax,
+                       (const int*)x_lens, x_len);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

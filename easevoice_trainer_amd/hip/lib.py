@@ -69,7 +69,7 @@ class AttnParams(C.Structure):
 class SampleParams(C.Structure):
     _fields_ = [("V", C.c_int32), ("eos", C.c_int32), ("top_k", C.c_int32), ("no_eos_steps", C.c_int32),
                 ("ymax", C.c_int32), ("top_p", C.c_float), ("temperature", C.c_float),
-                ("repetition_penalty", C.c_float), ("seed", C.c_uint32)]
+                ("repetition_penalty", C.c_float), ("seed", C.c_uint32), ("noise_rows", C.c_int32)]
 
 
 DEC_POS, DEC_IDX, DEC_YCOUNT, DEC_YLEN, DEC_SEED = 0, 1, 2, 3, 4

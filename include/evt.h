@@ -318,15 +318,18 @@ int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* 
                  void* stream);
 /* qkv fp32 [B][3*H*D] of the new token: its key/value are stored at cache position ctr[POS] (kcache/vcache
  * [B][Lmax][H*D] in `cdtype`) and out[b][h*D+d] = softmax(q.K^T/sqrt(D)).V over positions 0..ctr[POS]
- * (t2s_model.py:187-204 without the torch.cat growth).  D == 32. */
+ * (t2s_model.py:187-204 without the torch.cat growth).  D == 32.
+ * x_lens (may be NULL): int32 [B]; cache positions x_lens[b] <= j < x_len are the padding of a shorter text in a batch
+ * (the padding mask of infer_panel_batch_infer, t2s_model.py:620-650) and are not attended. */
 int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, const int32_t* ctr, float* out, int32_t B,
-                 int32_t H, int32_t D, int32_t Lmax, void* stream);
+                 int32_t H, int32_t D, int32_t Lmax, const int32_t* x_lens, int32_t x_len, void* stream);
 /* evt_dec_gemv (the packed in-projection) and evt_dec_attn in one launch: workgroup (b, h) computes only its head's
  * 3*D rows of Wqkv [3*H*D][H*D] (+ bqkv) from x = a or LayerNorm(a + r) (workgroups h == 0 store it to x_out), then
  * appends and attends as evt_dec_attn does.  The weights and the cache share `dtype`.  H*D == 512, D == 32. */
 int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const float* a, const float* r,
                      const float* ln_g, const float* ln_b, float ln_eps, float* x_out, void* kcache, void* vcache,
-                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, void* stream);
+                     const int32_t* ctr, float* out, int32_t B, int32_t H, int32_t D, int32_t Lmax, const int32_t* x_lens,
+                     int32_t x_len, void* stream);
 /* sample() of models/utils.py:125-171 for one step: the EOS column is dropped while ctr[IDX] < no_eos_steps
  * (t2s_model.py:833-834); repetition penalty over y[b][0..ctr[YCOUNT]); nucleus cut (top_p < 1) on the un-tempered
  * logits; division by max(temperature, 1e-5); top-k pivot (top_k <= 0: off; ties kept); softmax;
@@ -338,6 +341,7 @@ typedef struct evt_sample_params {
   int32_t V, eos, top_k, no_eos_steps, ymax;
   float top_p, temperature, repetition_penalty;
   uint32_t seed;
+  int32_t noise_rows;   /* 1: noise [steps][V] shared by the batch rows; B: noise [steps][B][V] */
 } evt_sample_params;
 int evt_dec_sample(const evt_sample_params* p, const float* logits, int64_t* y, const int32_t* ctr, const float* noise,
                    int32_t* stop_idx, float* probs_out, int32_t B, void* stream);

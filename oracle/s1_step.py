@@ -137,7 +137,7 @@ def logits_to_probs(logits, previous_tokens, temperature=1.0, top_k=None, top_p=
 
 
 def infer_panel_naive(sd, cfg, x, prompts, bert_feature, q, top_k=15, top_p=1, early_stop_num=-1, temperature=1.0,
-                      repetition_penalty=1.35, max_steps=1500):
+                      repetition_penalty=1.35, max_steps=1500, no_eos_steps=11, info=None):
     """KV-cache decoding, t2s_model.py:762-863, for batch 1 on plain tensors.  `q` [steps, V] is the exponential noise
     of multinomial_sample_one_no_sync (models/utils.py:118-122): token = argmax(probs / q[step]).  Returns (y without
     its last token, idx-1 or 0 when there was no prompt, list of the raw logits per step)."""
@@ -183,20 +183,37 @@ def infer_panel_naive(sd, cfg, x, prompts, bert_feature, q, top_k=15, top_p=1, e
                           sd[p + "linear2.weight"], sd[p + "linear2.bias"])
             h = F.layer_norm(h + ff, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
         logits = F.linear(h[:, -1], sd["ar_predict_layer.weight"])
-        if idx < 11:
+        if idx < no_eos_steps:
             logits = logits[:, :-1]
         all_logits.append(logits.clone())
         probs = logits_to_probs(logits, y, temperature, top_k, top_p, repetition_penalty)
         tok = torch.argmax(probs / q[idx, :probs.size(-1)], dim=-1, keepdim=True)
         y = torch.cat([y, tok], 1)
         stop = early_stop_num != -1 and (y.size(1) - prefix_len) > early_stop_num
-        if int(torch.argmax(logits, dim=-1)[0]) == EOS or int(tok[0, 0]) == EOS:
-            stop = True
-        if stop:
+        eos = int(torch.argmax(logits, dim=-1)[0]) == EOS or int(tok[0, 0]) == EOS
+        if info is not None:
+            info["eos"] = eos
+        if stop or eos:
             break
         ye = F.embedding(y[:, -1:], sd["ar_audio_embedding.word_embeddings.weight"])
         h = ye + sd["ar_audio_position.alpha"] * pe[None, y_len + idx:y_len + idx + 1]
     return y[:, :-1], (0 if prompts is None else idx - 1), all_logits
+
+
+def infer_panel_batch_infer(sd, cfg, xs, prompts, berts, q, **kw):
+    """infer_panel_batch_infer, t2s_model.py:563-730 (the TTS default, parallel_infer=True), restated through the
+    independence of the batch rows: padded text positions are masked for every query and never read back, and a finished
+    row is only removed from the batch, so row b decodes exactly like a batch of one on its unpadded text with its own
+    noise q[:, b].  Differences to infer_panel_naive that are kept: the EOS column is dropped at step 0 only
+    (:661-663), the returned index is idx-1 for an EOS stop but idx for the early stop (:687, :705)."""
+    ys, idxs = [], []
+    for b, (x, bert) in enumerate(zip(xs, berts)):
+        info = {}
+        y, idx_m1, _ = infer_panel_naive(sd, cfg, x[None], prompts[b:b + 1], bert[None], q[:, b], no_eos_steps=1, info=info,
+                                         **kw)
+        ys.append(y[0])
+        idxs.append(idx_m1 if info["eos"] else idx_m1 + 1)
+    return ys, idxs
 
 
 class ScaledAdamRef:

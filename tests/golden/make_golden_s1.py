@@ -190,8 +190,55 @@ def make_s1_infer():
     torch.save(dict(cases=cases), os.path.join(HERE, "s1_infer.pt"))
 
 
+BATCH_CASES = [dict(rows=[0, 1, 2], top_k=1100, top_p=1, temperature=1.0, repetition_penalty=1.35, early_stop_num=20),
+               dict(rows=[1], top_k=15, top_p=1, temperature=1.0, repetition_penalty=1.35, early_stop_num=12)]
+
+
+def make_s1_batch_infer():
+    """the default decoding path of the reference's TTS (parallel_infer=True): infer_panel_batch_infer,
+    t2s_model.py:563-730, with padded texts, per-row EOS stops and the early stop.  Stand-in as in make_s1_infer: the
+    exponential noise comes from a seeded table, here one row per batch item."""
+    import yaml
+    from make_golden_s1_inputs import batch_infer_inputs
+    from src.easevoice.soundstorm.auto_reg.models import t2s_model as TM
+    from src.easevoice.soundstorm.auto_reg.models import utils as U
+
+    torch.set_num_threads(8)
+    cfg = yaml.safe_load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "gpt.yaml")))
+    model = TM.Text2SemanticDecoder(config=cfg, top_k=3)
+    fill_module(model, 3)
+    model.eval()
+    d = batch_infer_inputs()
+    state = dict(step=0, rows=None)
+
+    def sample_one(probs):
+        qrow = d["q"][state["step"]][state["rows"][:probs.size(0)], :probs.size(-1)]
+        state["step"] += 1
+        return torch.argmax(probs / qrow, dim=-1, keepdim=True).to(dtype=torch.int)
+
+    orig = U.multinomial_sample_one_no_sync
+    U.multinomial_sample_one_no_sync = sample_one
+    cases = []
+    try:
+        with torch.no_grad():
+            for c in BATCH_CASES:
+                rows = c["rows"]
+                state["step"], state["rows"] = 0, rows
+                kw = {k: v for k, v in c.items() if k != "rows"}
+                x_lens = d["x_lens"][rows]
+                ys, idxs = model.infer_panel_batch_infer([d["x"][r] for r in rows], x_lens, d["prompts"][rows],
+                                                         [d["bert"][r] for r in rows], max_len=int(x_lens.max()), **kw)
+                cases.append(dict(args=c, y=[y.clone() for y in ys], idx=[int(i) for i in idxs], steps=state["step"]))
+                print(c, "-> lens", [int(y.numel()) for y in ys], "idx", idxs, "steps", state["step"])
+    finally:
+        U.multinomial_sample_one_no_sync = orig
+    torch.save(dict(cases=cases), os.path.join(HERE, "s1_batch_infer.pt"))
+
+
 if __name__ == "__main__":
-    if "infer" in sys.argv[1:]:
+    if "batch" in sys.argv[1:]:
+        make_s1_batch_infer()
+    elif "infer" in sys.argv[1:]:
         make_s1_infer()
     elif "dpo" in sys.argv[1:]:
         make_s1_dpo()

@@ -7,3 +7,17 @@ def infer_inputs(seed=99):
     return dict(x=torch.randint(0, 732, (1, 24), generator=g), bert=torch.randn(1, 1024, 24, generator=g),
                 prompts=torch.randint(0, 1024, (1, 12), generator=g),
                 q=torch.empty(64, 1025).exponential_(1, generator=g))
+
+
+def batch_infer_inputs(seed=77):
+    """three texts of different lengths sharing one prompt; per-row sampling noise q[step][row][v] whose EOS column makes
+    row 2 stop at step 7 and row 1 at step 15 (rows leave the batch from the back, so the survivors stay a prefix)"""
+    g = torch.Generator().manual_seed(seed)
+    lens = [24, 17, 9]
+    x = [torch.randint(0, 732, (n,), generator=g) for n in lens]
+    bert = [torch.randn(1024, n, generator=g) for n in lens]
+    prompt = torch.randint(0, 1024, (1, 12), generator=g)
+    q = torch.empty(64, 3, 1025).exponential_(1, generator=g)
+    q[7, 2, 1024] = 1e-30
+    q[15, 1, 1024] = 1e-30
+    return dict(x=x, bert=bert, x_lens=torch.tensor(lens), prompts=prompt.expand(3, -1).contiguous(), q=q)

@@ -130,6 +130,28 @@ def test_oracle_s1_decoding_matches_reference_fixture():
             assert rel(logits[-1][0], gold["logits_last"]) < 1e-4
 
 
+def test_oracle_s1_batch_decoding_matches_reference_fixture():
+    """the TTS default path (infer_panel_batch_infer): padded batch, rows stopping at different steps, early stop"""
+    import yaml
+    from oracle import s1_step as OS
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden_s1_inputs import batch_infer_inputs
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    keys = json.load(open(os.path.join(HERE, "golden", "state_dict_keys.json")))
+    sd = _filled(keys["s1"], 3)
+    d = batch_infer_inputs()
+    with torch.no_grad():
+        for gold in torch.load(os.path.join(HERE, "golden", "s1_batch_infer.pt"), weights_only=False)["cases"]:
+            a = dict(gold["args"])
+            rows = a.pop("rows")
+            ys, idxs = OS.infer_panel_batch_infer(sd, cfg, [d["x"][r] for r in rows], d["prompts"][rows],
+                                                  [d["bert"][r] for r in rows], d["q"][:, rows], **a)
+            assert idxs == gold["idx"]
+            for y, g in zip(ys, gold["y"]):
+                assert torch.equal(y.long(), g.long())
+
+
 def test_oracle_scaled_adam_matches_reference_trajectory():
     from oracle import s1_step as OS
 

@@ -68,7 +68,7 @@ def test_dec_attn(gpu, dtype, pos):
     out = torch.empty(B, E, device=gpu)
     qg = qkv.to(gpu)
     L.check(L.lib().evt_dec_attn(L.dt_of(kcg), L.ptr(qg), L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
-                                 Lmax, L.stream_ptr()), "evt_dec_attn")
+                                 Lmax, None, 0, L.stream_ptr()), "evt_dec_attn")
     torch.cuda.synchronize()
     knew, vnew = qkv[:, E:2 * E].to(dtype), qkv[:, 2 * E:].to(dtype)
     assert torch.equal(kcg[:, pos].cpu(), knew) and torch.equal(vcg[:, pos].cpu(), vnew)
@@ -108,7 +108,7 @@ def test_dec_qkv_attn(gpu, dtype, pos, use_ln):
     L.check(L.lib().evt_dec_qkv_attn(L.dt_of(Wg), L.ptr(Wg), L.ptr(bg), L.ptr(ag), L.ptr(rg) if use_ln else None,
                                      L.ptr(lgg) if use_ln else None, L.ptr(lbg) if use_ln else None, C.c_float(1e-5),
                                      L.ptr(xo) if use_ln else None, L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D,
-                                     Lmax, L.stream_ptr()), "evt_dec_qkv_attn")
+                                     Lmax, None, 0, L.stream_ptr()), "evt_dec_qkv_attn")
     torch.cuda.synchronize()
     tol = 3e-5 if dtype == torch.float32 else 2e-2       # bf16: the new key/value are rounded after an fp32 projection
     assert rel(out, want) < tol
@@ -156,6 +156,46 @@ def test_dec_sample_embed_fused(gpu):
     tok = int(res[0][0][0, ycount])
     assert res[0][1].tolist()[:4] == [101, idx + 1, ycount + 1, ylen]
     assert torch.allclose(res[1][2][0], (emb[tok] * 1.0 + 0.7 * pe[ylen + idx]).cpu(), rtol=1e-6, atol=1e-6)
+
+
+def test_dec_attn_key_padding(gpu):
+    """cache positions x_lens[b] <= j < x_len (text padding of a batch) are not attended; qkv-fused variant included"""
+    from easevoice_trainer_amd.hip import lib as L
+
+    B, H, D, Lmax, x_len, pos = 3, 16, 32, 512, 40, 90
+    E = H * D
+    g = torch.Generator().manual_seed(21)
+    kc, vc = torch.randn(B, Lmax, E, generator=g), torch.randn(B, Lmax, E, generator=g)
+    qkv = torch.randn(B, 3 * E, generator=g)
+    x_lens = torch.tensor([40, 13, 1], dtype=torch.int32)
+    keep = torch.ones(B, pos + 1, dtype=torch.bool)
+    for b in range(B):
+        keep[b, int(x_lens[b]):x_len] = False
+    K = torch.cat([kc[:, :pos], qkv[:, None, E:2 * E]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    V = torch.cat([vc[:, :pos], qkv[:, None, 2 * E:]], 1).view(B, pos + 1, H, D).transpose(1, 2)
+    q = qkv[:, :E].view(B, 1, H, D).transpose(1, 2)
+    sc = (q @ K.transpose(-1, -2) / D ** 0.5).masked_fill(~keep[:, None, None, :], float("-inf"))
+    want = (F.softmax(sc, -1) @ V).transpose(1, 2).reshape(B, E)
+    kcg, vcg, qg, xl = kc.to(gpu), vc.to(gpu), qkv.to(gpu), x_lens.to(gpu)
+    ctr = torch.tensor([pos, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=gpu)
+    out = torch.empty(B, E, device=gpu)
+    L.check(L.lib().evt_dec_attn(L.dt_of(kcg), L.ptr(qg), L.ptr(kcg), L.ptr(vcg), L.ptr(ctr), L.ptr(out), B, H, D, Lmax,
+                                 L.ptr(xl), x_len, L.stream_ptr()), "evt_dec_attn")
+    torch.cuda.synchronize()
+    assert rel(out, want) < 2e-5
+    # fused in-projection with an identity-free check: W = I-blocks would hide bugs, use random W and compare both entry points
+    W = (torch.randn(3 * E, E, generator=g) / E ** 0.5).to(gpu)
+    bias, a = (0.1 * torch.randn(3 * E, generator=g)).to(gpu), torch.randn(B, E, generator=g).to(gpu)
+    qkv2 = a @ W.t() + bias
+    kc1, vc1, kc2, vc2 = kc.to(gpu), vc.to(gpu), kc.to(gpu), vc.to(gpu)
+    o1, o2 = torch.empty(B, E, device=gpu), torch.empty(B, E, device=gpu)
+    L.check(L.lib().evt_dec_attn(L.dt_of(kc1), L.ptr(qkv2), L.ptr(kc1), L.ptr(vc1), L.ptr(ctr), L.ptr(o1), B, H, D, Lmax,
+                                 L.ptr(xl), x_len, L.stream_ptr()), "evt_dec_attn")
+    L.check(L.lib().evt_dec_qkv_attn(L.dt_of(W), L.ptr(W), L.ptr(bias), L.ptr(a), None, None, None, C.c_float(0.0), None,
+                                     L.ptr(kc2), L.ptr(vc2), L.ptr(ctr), L.ptr(o2), B, H, D, Lmax, L.ptr(xl), x_len,
+                                     L.stream_ptr()), "evt_dec_qkv_attn")
+    torch.cuda.synchronize()
+    assert rel(o2, o1) < 3e-5 and rel(kc2[:, pos], kc1[:, pos]) < 1e-5
 
 
 def _sample(gpu, logits, y, ycount, idx, noise, top_k=15, top_p=1.0, temperature=1.0, rp=1.35, eos=1024, seed=0):
@@ -261,6 +301,40 @@ def test_decoding_matches_reference_tokens(gpu, model, graph, monkeypatch):
         assert y.shape == gold["y"].shape and y.dtype == gold["y"].dtype
         assert torch.equal(y.cpu().long(), gold["y"].long()), (a, y.cpu()[0, -8:], gold["y"][0, -8:])
         assert idx == gold["idx"]
+
+
+@pytest.mark.parametrize("graph", ["1", "0"], ids=["graph", "eager"])
+def test_batch_decoding_matches_reference_tokens(gpu, model, graph, monkeypatch):
+    """infer_panel_batch_infer (the TTS default): three texts of different lengths in one padded batch, two rows meeting
+    EOS at different steps, one running into the early stop -- token for token the reference's lists"""
+    from make_golden_s1_inputs import batch_infer_inputs
+
+    monkeypatch.setenv("EVT_DECODE_GRAPH", graph)
+    d = batch_infer_inputs()
+    for gold in torch.load(os.path.join(HERE, "golden", "s1_batch_infer.pt"), weights_only=False)["cases"]:
+        a = dict(gold["args"])
+        rows = a.pop("rows")
+        ys, idxs = model.infer_panel_batch_infer([d["x"][r].to(gpu) for r in rows], d["x_lens"][rows].to(gpu),
+                                                 d["prompts"][rows].to(gpu), [d["bert"][r].to(gpu) for r in rows],
+                                                 noise=d["q"][:, rows], **a)
+        assert idxs == gold["idx"], (idxs, gold["idx"])
+        for y, g in zip(ys, gold["y"]):
+            assert torch.equal(y.cpu().long(), g.long())
+
+
+def test_batch_decoding_groups_of_rows(gpu, model):
+    """more rows than one session holds: decoded in groups of four; the same text with the same noise gives the same
+    tokens whichever group and row it lands in (both groups pad to the longest text, so even the key order is equal)"""
+    from make_golden_s1_inputs import batch_infer_inputs
+
+    d = batch_infer_inputs()
+    order = [0, 1, 2, 1, 0, 2]
+    ys, idxs = model.infer_panel_batch_infer([d["x"][r].to(gpu) for r in order], d["x_lens"][order].to(gpu),
+                                             d["prompts"][order].to(gpu), [d["bert"][r].to(gpu) for r in order],
+                                             top_k=15, top_p=1, early_stop_num=10, noise=d["q"][:, order])
+    assert len(ys) == 6 and idxs == [10] * 6 and all(y.shape == (12 + 10,) for y in ys)
+    assert torch.equal(ys[1], ys[3]) and torch.equal(ys[0], ys[4]) and torch.equal(ys[2], ys[5])
+    assert not torch.equal(ys[0][12:], ys[1][12:])
 
 
 def test_decoding_bf16_and_batched_front(gpu, model):
