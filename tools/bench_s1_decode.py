@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=0, help="also time infer_panel_batch_infer with this many texts (<= 4)")
     args = ap.parse_args()
     from easevoice_trainer_amd.train.s1_engine import S1Engine
 
@@ -60,6 +61,23 @@ def main():
         t = sorted(times[1:])[len(times[1:]) // 2]
         out["graph" if mode == "1" else "eager"] = dict(seconds=round(t, 4), tokens_per_s=round((args.tokens + 1) / t, 1),
                                                         us_per_token=round(1e6 * t / (args.tokens + 1), 1))
+    if args.rows:
+        os.environ["EVT_DECODE_GRAPH"] = "1"
+        R = args.rows
+        xs = [x[0][: args.x_len - 7 * r].contiguous() for r in range(R)]         # different text lengths: padded batch
+        berts = [bert[0][:, : args.x_len - 7 * r].contiguous() for r in range(R)]
+        times = []
+        for rep in range(args.reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ys, idxs = m.infer_panel_batch_infer(xs, None, prompts.expand(R, -1).contiguous(), berts, top_k=15, top_p=1,
+                                                 early_stop_num=args.tokens, noise=noise, repetition_penalty=1.35)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            assert all(y.numel() == args.prompt + args.tokens for y in ys), [y.shape for y in ys]
+        t = sorted(times[1:])[len(times[1:]) // 2]
+        out[f"batch{R}_graph"] = dict(seconds=round(t, 4), tokens_per_s=round(R * (args.tokens + 1) / t, 1),
+                                      us_per_step=round(1e6 * t / (args.tokens + 1), 1))
     L_avg = args.x_len + args.prompt + args.tokens / 2
     cache_bytes = nl * 2 * L_avg * E * esz
     per_tok = w_bytes + cache_bytes
