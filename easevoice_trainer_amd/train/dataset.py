@@ -247,17 +247,27 @@ def _even_pad(n):
     return int(2 * ((n // 2) + 1))
 
 
-def collate_s2(items, spec_bins, pin=False):
+def _round_up(n, k):
+    return -(-n // k) * k
+
+
+def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640):
     """TextAudioSpeakerCollate (data_utils.py:167-226) for items (ssl, wav, text, frames, ...): rows sorted by spectrogram
     length, longest first; ssl and spec time axes padded to 2*(max//2+1); everything else to the batch maximum.
     Returns the reference's 8-tuple with `spec_padded` zero-filled plus `order` (source index of each row): the caller
-    writes row i's spectrogram into spec_padded[i, :, :spec_lengths[i]]."""
+    writes row i's spectrogram into spec_padded[i, :, :spec_lengths[i]].
+    pad_frames > 0 (not in the reference) rounds the padded time axes up to a multiple of that many frames (samples: x hop):
+    every consumer masks by the lengths, so the step's result does not change, but the batches of a run then repeat a
+    few dozen shapes instead of several hundred -- what the trainer's per-shape HIP-graph replay needs."""
     n = len(items)
     _, order = torch.sort(torch.tensor([it[3] for it in items], dtype=torch.long), dim=0, descending=True)
     order = order.tolist()
     max_ssl = _even_pad(max(it[0].size(2) for it in items))
     max_spec = _even_pad(max(it[3] for it in items))
     max_wav = max(it[1].size(1) for it in items)
+    if pad_frames > 0:
+        max_ssl = max_spec = _round_up(max(max_ssl, max_spec), pad_frames)
+        max_wav = _round_up(max_wav, pad_frames * hop)
     max_text = max(it[2].size(0) for it in items)
 
     def buf(shape, dtype):
@@ -322,10 +332,11 @@ class S2Reader:
     """Iterable of device batches with the layout of the reference's s2 DataLoader (src/train/sovits.py:229-267)."""
 
     def __init__(self, exp_dir, data_cfg, batch_size, device, rank=0, world=1, boundaries=None, prefetch=4,
-                 symbol_to_id=None, spec_fn=None):
+                 symbol_to_id=None, spec_fn=None, pad_frames=None):
         self.ds = S2FeatureDir(exp_dir, data_cfg, symbol_to_id=symbol_to_id)
         self.sampler = S2BucketSampler(self.ds.lengths, batch_size, boundaries, num_replicas=world, rank=rank)
         self.device, self.prefetch = torch.device(device), prefetch
+        self.pad_frames = int(os.environ.get("EVT_PAD_FRAMES", "0")) if pad_frames is None else int(pad_frames)
         self.spec_bins = self.ds.filter_length // 2 + 1
         if spec_fn is None:
             from ..module.mel_processing import spectrogram_torch as spec_fn
@@ -339,7 +350,8 @@ class S2Reader:
 
     def _host_batch(self, indices):
         items = [self.ds.load(i) for i in indices]
-        batch, order = collate_s2(items, self.spec_bins, pin=self.device.type == "cuda")
+        batch, order = collate_s2(items, self.spec_bins, pin=self.device.type == "cuda", pad_frames=self.pad_frames,
+                                  hop=self.ds.hop_length)
         return batch, [items[src][4] for src in order]
 
     def __iter__(self):

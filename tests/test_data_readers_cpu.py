@@ -195,6 +195,26 @@ def test_s2_reader_end_to_end_cpu(feature_dir):
     it.close()
 
 
+def test_s2_reader_shape_quantisation(feature_dir):
+    """pad_frames: same items, lengths and content as the reference layout, time axes rounded up to a multiple"""
+    a = D.S2Reader(feature_dir, CFG, batch_size=4, device="cpu", spec_fn=oracle_spec, pad_frames=0)
+    b = D.S2Reader(feature_dir, CFG, batch_size=4, device="cpu", spec_fn=oracle_spec, pad_frames=64)
+    a.set_epoch(2)
+    b.set_epoch(2)
+    shapes = set()
+    for ba, bb in zip(a, b):
+        for i in (1, 3, 5, 7):
+            assert torch.equal(ba[i], bb[i])                    # lengths
+        assert torch.equal(ba[6], bb[6])                        # text
+        T = bb[2].shape[2]
+        assert T % 64 == 0 and bb[0].shape[2] == T and bb[4].shape[2] % (64 * F.HOP) == 0 and T >= ba[2].shape[2]
+        for x, y in ((ba[0], bb[0]), (ba[2], bb[2]), (ba[4], bb[4])):
+            n = x.shape[-1]
+            assert torch.equal(x, y[..., :n]) and not y[..., n:].any()
+        shapes.add(T)
+    assert shapes <= {64, 128, 192}
+
+
 def test_s1_table_matches_reference(feature_dir, gold):
     tab = D.S1SemanticTable(os.path.join(feature_dir, "2-name2text.txt"), os.path.join(feature_dir, "6-name2semantic.tsv"))
     g = gold["s1_dataset"]
