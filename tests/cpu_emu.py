@@ -193,3 +193,92 @@ def cpu_emulation_s1():
         (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,
          OPT.ScaledAdam._k_apply) = saved
         TM.CrossEntropyRowsFn = saved_rows
+
+
+@contextlib.contextmanager
+def cpu_emulation_decode():
+    """the s1 decoding session (auto_reg/t2s_infer.py) with its HIP launches substituted by torch CPU arithmetic on the
+    session's own buffers and counters: pins the host side -- prompt pass, counters, stop polling, per-row cuts, batch
+    groups -- against the reference's token sequences without a GPU.  Graph capture is off (EVT_DECODE_GRAPH=0)."""
+    import os
+    from easevoice_trainer_amd.auto_reg import t2s_infer as TI
+    from oracle import s1_step as OS
+
+    DS = TI.DecodeSession
+    saved = (DS._gemv, DS._sample_embed_advance, DS.step_launches, TI.PrefixLMAttentionFn, TI.AddLayerNormFn,
+             os.environ.get("EVT_DECODE_GRAPH"))
+
+    class _Attn:
+        @staticmethod
+        def apply(qkv, x_lens, y_lens, x_len, n_head, dropout_p, seed):
+            mask = OS.prefix_lm_mask(x_lens.long(), y_lens.long(), x_len, qkv.size(1) - x_len)
+            return OS.attention(qkv, mask, n_head)
+
+    class _LN:
+        @staticmethod
+        def apply(x, r, gamma, beta, eps):
+            return F.layer_norm(x + r if r is not None else x, (x.size(-1),), gamma, beta, eps)
+
+    def gemv(self, w, bias, a, r, g, b, eps, x_out, y, relu=0):
+        x = a if r is None else F.layer_norm(a + r, (a.size(-1),), g, b, eps)
+        if r is not None and x_out is not None:
+            x_out.copy_(x)
+        o = x @ w.float().t() + (bias if bias is not None else 0.0)
+        y.copy_(o.clamp(min=0) if relu else o)
+
+    def sample_embed_advance(self, W, sp, noise, pe, dpos):
+        pos, idx, ycount, ylen = self.ctr[:4].tolist()
+        Ve = sp.V - 1 if idx < sp.no_eos_steps else sp.V
+        for b in range(self.B):
+            lg = self.logits[b:b + 1, :Ve].clone()
+            prev = self.y[b:b + 1, :ycount]
+            if sp.repetition_penalty != 1.0 and ycount > 0:       # in place in the reference: the EOS test sees it
+                sc = torch.gather(lg, 1, prev)
+                lg.scatter_(1, prev, torch.where(sc < 0, sc * sp.repetition_penalty, sc / sp.repetition_penalty))
+            probs = OS.logits_to_probs(lg, None, sp.temperature, sp.top_k if sp.top_k > 0 else None, sp.top_p, 1.0)
+            q = noise[idx, b if sp.noise_rows > 1 else 0, :Ve] if noise.dim() == 3 else noise[idx, :Ve]
+            tok = int(torch.argmax(probs / q, dim=-1)[0])
+            self.y[b, ycount] = tok
+            if (int(torch.argmax(lg, dim=-1)[0]) == sp.eos or tok == sp.eos) and int(self.stop[b]) < 0:
+                self.stop[b] = idx
+            self.xa[b] = W.emb[tok] * self.model.ar_audio_position.x_scale + W.alpha * pe[ylen + idx]
+        self.ctr[0] += dpos
+        self.ctr[1] += 1
+        self.ctr[2] += 1
+
+    def step_launches(self, W, sp, noise, pe, fused_qkv=False):
+        pos = int(self.ctr[0])
+        E, H = self.E, self.H
+        d = E // H
+        x = self.xa.clone()
+        keep = torch.ones(self.B, pos + 1, dtype=torch.bool)
+        if self.x_lens is not None:
+            for b in range(self.B):
+                keep[b, int(self.x_lens[b]):self.x_len] = False
+        for i, w in enumerate(W.layers):
+            qkv = x @ w["wqkv"].float().t() + w["bqkv"]
+            self.kc[i, :, pos] = qkv[:, E:2 * E]
+            self.vc[i, :, pos] = qkv[:, 2 * E:]
+            K = self.kc[i, :, :pos + 1].float().view(self.B, pos + 1, H, d).transpose(1, 2)
+            V = self.vc[i, :, :pos + 1].float().view(self.B, pos + 1, H, d).transpose(1, 2)
+            q = qkv[:, :E].view(self.B, 1, H, d).transpose(1, 2)
+            s = (q @ K.transpose(-1, -2) / d ** 0.5).masked_fill(~keep[:, None, None, :], float("-inf"))
+            att = (F.softmax(s, -1) @ V).transpose(1, 2).reshape(self.B, E)
+            t = att @ w["wo"].float().t() + w["bo"]
+            x1 = F.layer_norm(x + t, (E,), w["g1"], w["be1"], w["eps1"])
+            u = F.relu(x1 @ w["w1"].float().t() + w["b1"]) @ w["w2"].float().t() + w["b2"]
+            x = F.layer_norm(x1 + u, (E,), w["g2"], w["be2"], w["eps2"])
+        self.logits.copy_(x @ W.wpred.float().t())
+        sample_embed_advance(self, W, sp, noise, pe, 1)
+
+    DS._gemv, DS._sample_embed_advance, DS.step_launches = gemv, sample_embed_advance, step_launches
+    TI.PrefixLMAttentionFn, TI.AddLayerNormFn = _Attn, _LN
+    os.environ["EVT_DECODE_GRAPH"] = "0"
+    try:
+        yield
+    finally:
+        DS._gemv, DS._sample_embed_advance, DS.step_launches, TI.PrefixLMAttentionFn, TI.AddLayerNormFn = saved[:5]
+        if saved[5] is None:
+            os.environ.pop("EVT_DECODE_GRAPH", None)
+        else:
+            os.environ["EVT_DECODE_GRAPH"] = saved[5]

@@ -4,6 +4,7 @@ covered by the -m gpu tests."""
 import json
 import os
 
+import pytest
 import torch
 import yaml
 
@@ -91,3 +92,44 @@ def test_scaled_adam_host_logic_matches_reference():
             opt.param_groups[0]["lr"] = 0.002
             for k in params:
                 assert torch.allclose(params[k].detach(), want[k], rtol=5e-5, atol=2e-6), (step, k)
+
+
+def test_decoding_host_logic_matches_reference_tokens():
+    """auto_reg/t2s_infer.py with its launches emulated on the session's buffers: prompt pass, device-counter protocol,
+    stop polling, output cuts and index conventions of infer_panel_naive and infer_panel_batch_infer (padded batch, rows
+    stopping at different steps, groups) reproduce the reference's token sequences"""
+    import sys
+    from cpu_emu import cpu_emulation_decode
+    from easevoice_trainer_amd.auto_reg.t2s_model import Text2SemanticDecoder
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden_s1_inputs import batch_infer_inputs, infer_inputs
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    with cpu_emulation_decode():
+        m = Text2SemanticDecoder(cfg)
+        fill_module(m, 3)
+        m.eval()
+        d = infer_inputs()
+        for gold in torch.load(os.path.join(HERE, "golden", "s1_infer.pt"), weights_only=False)["cases"]:
+            a = dict(gold["args"])
+            prompts = d["prompts"] if a.pop("prompt") else None
+            y, idx = m.infer_panel_naive(d["x"], torch.tensor([24]), prompts, d["bert"], noise=d["q"], poll=5, **a)
+            assert y.dtype == gold["y"].dtype and torch.equal(y.long(), gold["y"].long()) and idx == gold["idx"]
+        d = batch_infer_inputs()
+        for gold in torch.load(os.path.join(HERE, "golden", "s1_batch_infer.pt"), weights_only=False)["cases"]:
+            a = dict(gold["args"])
+            rows = a.pop("rows")
+            ys, idxs = m.infer_panel_batch_infer([d["x"][r] for r in rows], d["x_lens"][rows], d["prompts"][rows],
+                                                 [d["bert"][r] for r in rows], noise=d["q"][:, rows], **a)
+            assert idxs == gold["idx"]
+            for y, g in zip(ys, gold["y"]):
+                assert torch.equal(y.long(), g.long())
+        # more rows than a session holds -> two groups; duplicates of a text decode to the same tokens
+        order = [0, 1, 2, 1, 0, 2]
+        ys, idxs = m.infer_panel_batch_infer([d["x"][r] for r in order], d["x_lens"][order], d["prompts"][order],
+                                             [d["bert"][r] for r in order], top_k=15, top_p=1, early_stop_num=6,
+                                             noise=d["q"][:, order])
+        assert idxs == [6] * 6 and torch.equal(ys[1], ys[3]) and torch.equal(ys[0], ys[4]) and torch.equal(ys[2], ys[5])
+        m.train()
+        with pytest.raises(Exception, match="eval"):
+            m.infer_panel_naive(d["x"][0][None], None, d["prompts"][:1], d["bert"][0][None], top_k=5, early_stop_num=2)
