@@ -173,6 +173,12 @@ class T2SInfer:
         xy = xy.to(cd).contiguous()
         src_len = x_len + y_len
         n_max = MAX_STEPS if early_stop_num == -1 else max(1, min(MAX_STEPS, int(early_stop_num) + 1))
+        noise_rows = 1
+        if noise is not None:       # an injected noise table (parity runs) also bounds the number of steps
+            noise = noise.to(dev, torch.float32).contiguous()
+            noise_rows = 1 if noise.dim() == 2 else noise.size(1)
+            assert noise.size(-1) == m.vocab_size and noise_rows in (1, B)
+            n_max = min(n_max, noise.size(0))
         S = self.session(B, src_len + n_max + 1, y_len + n_max + 1, cd, dev)
         xl = torch.tensor(x_lens, dtype=torch.int32, device=dev)
         yl = torch.full((B,), y_len, dtype=torch.int32, device=dev)
@@ -200,11 +206,6 @@ class T2SInfer:
         if padded:
             S.x_lens_buf.copy_(xl)
         S.x_lens, S.x_len = (S.x_lens_buf if padded else None), x_len
-        noise_rows = 1
-        if noise is not None:
-            noise = noise.to(dev, torch.float32).contiguous()
-            noise_rows = 1 if noise.dim() == 2 else noise.size(1)
-            assert noise.size(-1) == S.V and noise.size(0) >= n_max and noise_rows in (1, B)
         sp = L.SampleParams(S.V, m.EOS, int(top_k) if top_k is not None else 0, no_eos_steps, S.ymax, float(top_p),
                             float(temperature), float(repetition_penalty), 0x5EED5EED, noise_rows)
         pe = m.ar_audio_position.pe(max(4000, y_len + n_max + 1), dev, torch.float32).contiguous()

@@ -235,8 +235,66 @@ def make_s1_batch_infer():
     torch.save(dict(cases=cases), os.path.join(HERE, "s1_batch_infer.pt"))
 
 
+def make_pipeline():
+    """the model-side core of TTS.run (tts.py:756-817) chained from the reference's own s1 and s2 modules: batched
+    decoding of two fragments, then SynthesizerTrn.decode over the concatenation (speed 1.0) and per fragment (1.25)"""
+    import json
+    import math
+    import yaml
+    from make_golden_s1_inputs import pipeline_inputs
+    from util_fill import decode_inputs
+    from src.easevoice.module import models as RM
+    from src.easevoice.soundstorm.auto_reg.models import t2s_model as TM
+    from src.easevoice.soundstorm.auto_reg.models import utils as U
+
+    torch.set_num_threads(8)
+    cfg = yaml.safe_load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "gpt.yaml")))
+    t2s = TM.Text2SemanticDecoder(config=cfg, top_k=3)
+    fill_module(t2s, 3)
+    t2s.eval()
+    hps = json.load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "s2.json")))
+    vits = RM.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    fill_module(vits, 1)
+    vits.eval()
+    d, dd = pipeline_inputs(), decode_inputs()
+    state = dict(step=0)
+
+    def sample_one(probs):
+        qrow = d["q"][state["step"], :probs.size(0), :probs.size(-1)]
+        state["step"] += 1
+        return torch.argmax(probs / qrow, dim=-1, keepdim=True).to(dtype=torch.int)
+
+    orig_one, orig_randn = U.multinomial_sample_one_no_sync, torch.randn_like
+    U.multinomial_sample_one_no_sync = sample_one
+    out = {}
+    try:
+        with torch.no_grad():
+            lens = torch.tensor([int(i.numel()) for i in d["all_ids"]])
+            pred, idxs = t2s.infer_panel_batch_infer(d["all_ids"], lens, d["prompt"].expand(2, -1), d["bert"], top_k=1100,
+                                                     top_p=1, temperature=1.0, early_stop_num=50 * cfg["data"]["max_sec"],
+                                                     max_len=int(lens.max()), repetition_penalty=1.35)
+            out["pred"], out["idx"] = [p.clone() for p in pred], [int(i) for i in idxs]
+            torch.randn_like = lambda t, **kw: dd["noise"][:, :, :t.size(2)].to(t.dtype)
+            cut = [p[-i:] for p, i in zip(pred, idxs)]
+            up = math.prod(vits.upsample_rates)
+            ends = [0]
+            for p in cut:
+                ends.append(ends[-1] + p.shape[0] * 2 * up)
+            audio = vits.decode(torch.cat(cut)[None, None], torch.cat(d["batch_phones"])[None], dd["refers"], speed=1.0)[0, 0]
+            out["speed1"] = [audio[ends[i - 1]:ends[i]].clone() for i in range(1, len(ends))]
+            out["speed125"] = [vits.decode(p[-i:][None, None], ph[None], dd["refers"], speed=1.25)[0, 0].clone()
+                               for p, i, ph in zip(pred, idxs, d["batch_phones"])]
+    finally:
+        U.multinomial_sample_one_no_sync, torch.randn_like = orig_one, orig_randn
+    print("tokens", [int(p.numel()) for p in out["pred"]], "idx", out["idx"], "audio", [int(a.numel()) for a in out["speed1"]],
+          [int(a.numel()) for a in out["speed125"]])
+    torch.save(out, os.path.join(HERE, "pipeline.pt"))
+
+
 if __name__ == "__main__":
-    if "batch" in sys.argv[1:]:
+    if "pipeline" in sys.argv[1:]:
+        make_pipeline()
+    elif "batch" in sys.argv[1:]:
         make_s1_batch_infer()
     elif "infer" in sys.argv[1:]:
         make_s1_infer()

@@ -21,3 +21,17 @@ def batch_infer_inputs(seed=77):
     q[7, 2, 1024] = 1e-30
     q[15, 1, 1024] = 1e-30
     return dict(x=x, bert=bert, x_lens=torch.tensor(lens), prompts=prompt.expand(3, -1).contiguous(), q=q)
+
+
+def pipeline_inputs(seed=55):
+    """two text fragments (prompt phones + own phones) for the s1 -> s2 chain; EOS is forced at step 14 for row 0 and at
+    step 9 for row 1 through the noise table (top_k covers the whole vocabulary in these runs)"""
+    g = torch.Generator().manual_seed(seed)
+    lens = [24, 17]
+    ids = [torch.randint(0, 732, (n,), generator=g) for n in lens]
+    bert = [torch.randn(1024, n, generator=g) for n in lens]
+    q = torch.empty(32, 2, 1025).exponential_(1, generator=g)
+    q[14, 0, 1024] = 1e-30
+    q[9, 1, 1024] = 1e-30
+    return dict(all_ids=ids, bert=bert, batch_phones=[i[7:] for i in ids], prompt=torch.randint(0, 1024, (1, 12), generator=g),
+                q=q)

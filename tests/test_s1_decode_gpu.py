@@ -356,3 +356,36 @@ def test_decoding_bf16_and_batched_front(gpu, model):
         assert len(ys) == 2 and ys[0].shape == (12 + 10,) and idxs == [9, 9]
     finally:
         model.cd = torch.float32
+
+
+def test_semantic_to_audio_chain(gpu):
+    """both exports loaded the way the reference's TTS loads them, then the model-side core of TTS.run on the HIP kernels:
+    batched s1 decoding -> SynthesizerTrn.decode, against the reference's own two models chained the same way"""
+    from make_golden_s1_inputs import pipeline_inputs
+    from util_fill import decode_inputs
+    from easevoice_trainer_amd.auto_reg.t2s_model import Text2SemanticDecoder
+    from easevoice_trainer_amd.inference.pipeline import synthesize_fragments
+    from easevoice_trainer_amd.inference.sovits import SoVITSVoice
+    from easevoice_trainer_amd.inference.t2s import T2SVoice
+    from easevoice_trainer_amd.module import models
+
+    gold = torch.load(os.path.join(HERE, "golden", "pipeline.pt"), weights_only=False)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    d, dd = pipeline_inputs(), decode_inputs()
+    src = Text2SemanticDecoder(cfg)
+    fill_module(src, 3)
+    t2s = T2SVoice({"weight": {"model." + k: v.clone() for k, v in src.state_dict().items()}, "config": cfg, "info": "x"},
+                   device=str(gpu), dtype=torch.float32)
+    net = models.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    fill_module(net, 1)
+    voice = SoVITSVoice({"weight": {k: v.clone() for k, v in net.state_dict().items() if "enc_q" not in k}, "config": hps,
+                         "info": "x"}, device=str(gpu), dtype=torch.float32)
+    kw = dict(top_k=1100, top_p=1, temperature=1.0, repetition_penalty=1.35, sample_kwargs=dict(noise=d["q"]),
+              decode_kwargs=dict(noise=dd["noise"].to(gpu)))
+    for speed, key in ((1.0, "speed1"), (1.25, "speed125")):
+        frags = synthesize_fragments(t2s, voice, d["batch_phones"], d["all_ids"], d["bert"], d["prompt"], dd["refers"],
+                                     speed_factor=speed, **kw)
+        assert [f.numel() for f in frags] == [g.numel() for g in gold[key]]
+        for f, g in zip(frags, gold[key]):
+            assert rel(f, g) < 2e-3, (speed, rel(f, g))
