@@ -27,7 +27,7 @@ def synthesize_fragments(t2s, voice, batch_phones, all_phoneme_ids, all_bert_fea
     if speed_factor == 1.0:
         # one decode over the concatenated fragments, then cut (tts.py:795-807)
         pred = [p[-i:] for p, i in zip(pred, idx_list)]
-        up = math.prod(voice.hps["model"]["upsample_rates"])
+        up = math.prod(voice.model.upsample_rates)
         ends = [0]
         for p in pred:
             ends.append(ends[-1] + p.shape[0] * 2 * up)

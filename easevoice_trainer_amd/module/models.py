@@ -569,6 +569,7 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         super().__init__()
         self.spec_channels, self.segment_size, self.inter_channels = spec_channels, segment_size, inter_channels
         self.gin_channels, self.version = gin_channels, version
+        self.upsample_rates = upsample_rates           # read by the reference's TTS.run (tts.py:798)
         self.enc_p = TextEncoder(inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
                                  p_dropout, version=version)
         self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
