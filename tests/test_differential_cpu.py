@@ -1,0 +1,212 @@
+"""CPU, build container only: randomised differential tests of the host-side pieces against the REFERENCE's own code,
+imported read-only from /root/reference through oracle/refshim.py.  They widen what the committed golden fixtures pin
+(one seeded case each) to a few hundred random cases; on a machine without the reference checkout (the GPU box) the
+whole module is skipped -- nothing here is needed by the -m gpu tier."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+from oracle import refshim
+
+if not refshim.reference_available():
+    pytest.skip("reference checkout not present", allow_module_level=True)
+refshim.install()
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from easevoice_trainer_amd.auto_reg import utils as PU  # noqa: E402
+from easevoice_trainer_amd.train import dataset as D  # noqa: E402
+
+
+class Stub(torch.utils.data.Dataset):
+    def __init__(self, lengths):
+        self.lengths = lengths
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def get_sample_length(self, i):
+        return self.lengths[i]
+
+
+def test_s2_bucket_sampler_random_cases():
+    from src.easevoice.module import data_utils as DU
+
+    rng = random.Random(1)
+    for case in range(40):
+        n = rng.randint(5, 400)
+        lengths = [rng.randint(1, 2300) for _ in range(n)]
+        bounds = sorted(rng.sample(range(10, 2200), rng.randint(2, 12)))
+        bs, world = rng.randint(1, 9), rng.randint(1, 4)
+        inside = [v for v in lengths if bounds[0] < v <= bounds[-1]]
+        if not inside:
+            continue
+        for rank in range(world):
+            ref = DU.DistributedBucketSampler(Stub(lengths), bs, list(bounds), num_replicas=world, rank=rank, shuffle=True)
+            ours = D.S2BucketSampler(lengths, bs, list(bounds), num_replicas=world, rank=rank)
+            for epoch in (0, rng.randint(1, 50)):
+                ref.set_epoch(epoch)
+                ours.set_epoch(epoch)
+                assert list(iter(ours)) == list(iter(ref)), (case, rank, epoch)
+            assert len(ours) == len(ref) and ours.boundaries == ref.boundaries
+
+
+def test_s1_bucket_sampler_random_cases():
+    from src.easevoice.soundstorm.auto_reg.data import bucket_sampler as BS
+
+    rng = random.Random(2)
+    for case in range(40):
+        n = rng.randint(1, 300)
+        secs = [round(rng.uniform(0.2, 30.0), 2) for _ in range(n)]
+        bs, world = rng.randint(1, 16), rng.randint(1, 4)
+        drop = rng.random() < 0.3
+        for rank in range(world):
+            ref = BS.DistributedBucketSampler(Stub(secs), num_replicas=world, rank=rank, batch_size=bs, drop_last=drop,
+                                              seed=case)
+            ours = D.S1BucketSampler(Stub(secs), bs, num_replicas=world, rank=rank, drop_last=drop, seed=case)
+            for epoch in (0, rng.randint(1, 30)):
+                ref.set_epoch(epoch)
+                ours.set_epoch(epoch)
+                assert list(iter(ours)) == list(iter(ref)), (case, rank, epoch)
+            assert len(ours) == len(ref)
+
+
+def test_s2_collate_random_batches():
+    from src.easevoice.module import data_utils as DU
+
+    g = torch.Generator().manual_seed(3)
+    rng = random.Random(3)
+    for case in range(25):
+        items_ref, items = [], []
+        for _ in range(rng.randint(1, 7)):
+            frames = rng.randint(33, 300)
+            ssl_t = frames + rng.choice([0, 0, 1])
+            ssl = torch.randn(1, 8, ssl_t, generator=g)
+            spec = torch.rand(5, frames, generator=g)
+            wav = torch.randn(1, frames * 640 + rng.randint(0, 639), generator=g)
+            text = torch.randint(0, 700, (rng.randint(1, 40),), generator=g).float()
+            items_ref.append((ssl, spec, wav, text))
+            items.append((ssl, wav, text, frames, True))
+        ref = DU.TextAudioSpeakerCollate()(items_ref)
+        ours, order = D.collate_s2(items, 5)
+        for row, src in enumerate(order):
+            ours[2][row, :, :items[src][3]] = items_ref[src][1]
+        for a, b in zip(ours, ref):
+            assert a.dtype == b.dtype and torch.equal(a, b), case
+
+
+def test_s1_collate_random_batches():
+    from src.easevoice.soundstorm.auto_reg.data import dataset as DS
+
+    g = torch.Generator().manual_seed(4)
+    rng = random.Random(4)
+    ref_ds = object.__new__(DS.Text2SemanticDataset)
+    ref_ds.PAD = 1024
+    ours = object.__new__(D.S1SemanticTable)
+    ours.PAD = 1024
+    for case in range(25):
+        ex = []
+        for i in range(rng.randint(1, 6)):
+            n_ph, n_se = rng.randint(1, 50), rng.randint(1, 200)
+            ex.append(dict(idx=i, phoneme_ids=[rng.randint(0, 700) for _ in range(n_ph)], phoneme_ids_len=n_ph,
+                           semantic_ids=[rng.randint(0, 1023) for _ in range(n_se)], semantic_ids_len=n_se,
+                           bert_feature=torch.randn(1024, n_ph, generator=g) if rng.random() < 0.7 else None))
+        a, b = ours.collate(ex), ref_ds.collate(ex)
+        assert a["ids"] == b["ids"]
+        for k in ("phoneme_ids", "phoneme_ids_len", "semantic_ids", "semantic_ids_len", "bert_feature"):
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (case, k)
+
+
+def test_make_reject_y_random_seeds():
+    from src.easevoice.soundstorm.auto_reg.models import utils as RU
+
+    g = torch.Generator().manual_seed(5)
+    for seed in range(60):
+        B, T = int(torch.randint(1, 6, (1,), generator=g)), int(torch.randint(2, 90, (1,), generator=g))
+        y = torch.randint(0, 1025, (B, T), generator=g)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        torch.manual_seed(seed)
+        ry, rl = RU.make_reject_y(y, lens)
+        after_ref = torch.randint(0, 10 ** 6, (1,)).item()       # the generator ends in the same state
+        torch.manual_seed(seed)
+        oy, ol = PU.make_reject_y(y, lens)
+        after_ours = torch.randint(0, 10 ** 6, (1,)).item()
+        assert torch.equal(ry, oy) and torch.equal(rl, ol) and after_ref == after_ours, seed
+
+
+def test_sampling_restatement_random_logits():
+    """the oracle's logits_to_probs (which the GPU sampling kernel is checked against) vs the reference's"""
+    from oracle import s1_step as OS
+    from src.easevoice.soundstorm.auto_reg.models import utils as RU
+
+    g = torch.Generator().manual_seed(6)
+    rng = random.Random(6)
+    for case in range(60):
+        B, V = rng.randint(1, 4), rng.choice([1024, 1025, 300])
+        logits = torch.randn(B, V, generator=g) * rng.choice([0.5, 3.0, 10.0])
+        prev = torch.randint(0, V, (B, rng.randint(0, 80)), generator=g)
+        kw = dict(temperature=rng.choice([1.0, 0.7, 1.4, 1e-7]), top_k=rng.choice([None, 1, 5, 15, 5000]),
+                  top_p=rng.choice([None, 1, 0.95, 0.5, 0.05]), repetition_penalty=rng.choice([1.0, 1.35, 0.8]))
+        want = RU.logits_to_probs(logits.clone(), prev if prev.numel() else None, **kw)
+        got = OS.logits_to_probs(logits, prev, kw["temperature"], kw["top_k"], kw["top_p"], kw["repetition_penalty"])
+        assert torch.equal(got > 0, want > 0) and torch.allclose(got, want, rtol=1e-6, atol=1e-9), (case, kw)
+
+
+def test_frame_count_formula_random_lengths():
+    from src.easevoice.module.mel_processing import spectrogram_torch
+
+    rng = random.Random(7)
+    for _ in range(12):
+        n = rng.randint(800, 90000)
+        spec = spectrogram_torch(torch.randn(1, n), 2048, 32000, 640, 2048, center=False)
+        assert spec.shape == (1, 1025, D.spec_frames(n, 2048, 640)), n
+
+
+def test_dpo_loss_matches_reference_helper():
+    from src.easevoice.soundstorm.auto_reg.models import utils as RU
+
+    g = torch.Generator().manual_seed(8)
+    for _ in range(20):
+        a, r = torch.randn(5, generator=g) * 30, torch.randn(5, generator=g) * 30
+        want = RU.dpo_loss(a, r, 0, 0, 0.2, reference_free=True)[0]
+        assert torch.allclose(PU.dpo_loss(a, r, 0.2), want, rtol=1e-6, atol=1e-7)
+
+
+def test_commons_helpers_random():
+    from easevoice_trainer_amd.module import commons as PC
+    from src.easevoice.module import commons as RC
+
+    g = torch.Generator().manual_seed(9)
+    for case in range(20):
+        B, T, Cn, seg = int(torch.randint(1, 6, (1,), generator=g)), int(torch.randint(40, 200, (1,), generator=g)), 7, 32
+        x = torch.randn(B, Cn, T, generator=g)                        # reference layout [B, C, T]
+        lens = torch.randint(seg, T + 1, (B,), generator=g)
+        assert torch.equal(PC.sequence_mask(lens, T), RC.sequence_mask(lens, T))
+        assert torch.equal(PC.sequence_mask(lens), RC.sequence_mask(lens))
+        torch.manual_seed(case)
+        want, ids_ref = RC.rand_slice_segments(x, lens, seg)
+        torch.manual_seed(case)
+        got, ids = PC.rand_slice_segments(x.transpose(1, 2).contiguous(), lens, seg)     # ours is channels-last
+        assert torch.equal(ids, ids_ref) and torch.equal(got.transpose(1, 2), want)
+        assert torch.equal(PC.slice_segments(x.transpose(1, 2).contiguous(), ids, seg).transpose(1, 2),
+                           RC.slice_segments(x, ids, seg))
+
+
+def test_lr_schedule_trajectory():
+    from easevoice_trainer_amd.auto_reg.optim import WarmupCosineLRSchedule as Ours
+    from src.easevoice.soundstorm.auto_reg.modules.lr_schedulers import WarmupCosineLRSchedule as Ref
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [dict(lr=0.01), dict(lr=0.01)]
+
+    a, b = Opt(), Opt()
+    ra = Ref(a, init_lr=1e-5, peak_lr=1e-2, end_lr=1e-4, warmup_steps=20, total_steps=100)
+    rb = Ours(b, init_lr=1e-5, peak_lr=1e-2, end_lr=1e-4, warmup_steps=20, total_steps=100)
+    for _ in range(150):
+        assert ra.step() == rb.step() and ra.get_last_lr() == rb.get_last_lr()
+        assert [g["lr"] for g in a.param_groups] == [g["lr"] for g in b.param_groups]
