@@ -59,7 +59,10 @@ def test_symbol_table_sources(feature_dir, gold, monkeypatch, tmp_path):
     monkeypatch.setenv("EVT_SYMBOLS_JSON", str(alt))
     assert D.load_symbol_table(feature_dir) == {"x": 0, "y": 1}
     monkeypatch.delenv("EVT_SYMBOLS_JSON")
-    if "src" not in sys.modules:
+    # no table anywhere and no reference checkout importable -> a loud error (other test modules may have put the
+    # checkout on sys.path: take it off for this check)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if not os.path.isdir(os.path.join(p, "src", "easevoice"))])
+    if not any(k == "src" or k.startswith("src.") for k in sys.modules):
         with pytest.raises(FileNotFoundError):
             D.load_symbol_table(str(tmp_path))
 
