@@ -340,8 +340,12 @@ class MelStyleEncoder(nn.Module):
 # frozen residual vector quantizer (n_q = 1), eval semantics only (models.py:912-926)
 # --------------------------------------------------------------------------------------------------
 class _Codebook(nn.Module):
+    KMEANS_ITERS = 50          # ResidualVectorQuantizer default, quantize.py:48
+    KMEANS_SAMPLES = 500       # core_vq.py:72
+
     def __init__(self, dim, codebook_size):
         super().__init__()
+        self.codebook_size = codebook_size
         self.register_buffer("inited", torch.Tensor([False]))   # kmeans_init=True in the reference
         self.register_buffer("cluster_size", torch.zeros(codebook_size))
         self.register_buffer("embed", torch.zeros(codebook_size, dim))
@@ -352,6 +356,34 @@ class _Codebook(nn.Module):
         e = self.embed.t()
         dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
         return dist.max(dim=-1).indices
+
+    @torch.no_grad()
+    def init_embed_(self, data):
+        """k-means initialisation from the first batch, core_vq.py:61-92,140-149 (a run without a pretrained generator):
+        the first 500 vectors, centres drawn with randperm (randint when there are fewer vectors than codes), 50 Lloyd
+        iterations with the (s - m)^2 distance of the reference, empty clusters keep their centre.  The reference
+        materialises the [500, K, D] difference tensor (1.5 GB); here the samples go through in slices of 50."""
+        samples = data[:self.KMEANS_SAMPLES].float()
+        n, K = samples.shape[0], self.codebook_size
+        if n >= K:
+            idx = torch.randperm(n, device=samples.device)[:K]
+        else:
+            idx = torch.randint(0, n, (K,), device=samples.device)
+        means = samples[idx]
+        bins = None
+        for _ in range(self.KMEANS_ITERS):
+            buckets = torch.cat([(-((samples[i:i + 50, None, :] - means[None]) ** 2).sum(dim=-1)).max(dim=-1).indices
+                                 for i in range(0, n, 50)])
+            bins = torch.bincount(buckets, minlength=K)
+            zero = bins == 0
+            new_means = torch.zeros_like(means)
+            new_means.scatter_add_(0, buckets[:, None].expand(-1, samples.shape[1]), samples)
+            new_means = new_means / bins.masked_fill(zero, 1)[:, None]
+            means = torch.where(zero[:, None], means, new_means)
+        self.embed.copy_(means)
+        self.embed_avg.copy_(means)
+        self.cluster_size.copy_(bins.to(self.cluster_size.dtype))
+        self.inited.fill_(1.0)
 
 
 class _VQLayer(nn.Module):
@@ -380,12 +412,17 @@ class ResidualVectorQuantizer(nn.Module):
     def forward(self, x):
         """x [B, T, D] fp32 -> (quantized [B, T, D], codes [1, B, T])"""
         cb = self.vq.layers[0]._codebook
+        b, t, d = x.shape
         if not getattr(self, "_inited_ok", False):     # checked once (a host sync), not every step
             if not bool(cb.inited.cpu().item()):
-                raise L.EvtError("quantizer codebook is not initialised: load pretrained weights "
-                                 "(the reference would run k-means on the first batch, core_vq.py:140-149)")
+                # no pretrained codebook: k-means on the first batch like the reference (core_vq.py:140-149); with
+                # several ranks every rank takes rank 0's result (DDP's buffer broadcast does that in the reference)
+                cb.init_embed_(x.reshape(b * t, d))
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    for buf in (cb.embed, cb.embed_avg, cb.cluster_size, cb.inited):
+                        dist.broadcast(buf, src=0)
             self._inited_ok = True
-        b, t, d = x.shape
         ind = cb.nearest(x.reshape(b * t, d).float())
         q = F.embedding(ind, cb.embed).view(b, t, d)
         return q, ind.view(1, b, t)

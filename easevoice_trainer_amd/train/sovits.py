@@ -102,13 +102,11 @@ class SovitsTrain:
             if t["pretrained_s2D"] and os.path.exists(t["pretrained_s2D"]):
                 eng.net_d.load_state_dict(torch.load(t["pretrained_s2D"], map_location="cpu", weights_only=False)["weight"])
         cb = eng.net_g.quantizer.vq.layers[0]._codebook
-        if float(cb.inited.float().cpu()) == 0.0:
-            if os.environ.get("EVT_SYNTHETIC_STEPS"):
-                cb.embed.normal_()
-                cb.inited.fill_(1.0)
-            else:
-                raise RuntimeError("quantizer codebook not initialised: pretrained_s2G is required (the reference would "
-                                   "k-means-initialise it from the first batch, core_vq.py:140-149)")
+        if float(cb.inited.float().cpu()) == 0.0 and os.environ.get("EVT_SYNTHETIC_STEPS"):
+            cb.embed.normal_()          # synthetic runs: a random codebook instead of k-means over noise features
+            cb.inited.fill_(1.0)
+        # (no pretrained generator and real data: the codebook is k-means-initialised from the first batch, as in the
+        # reference, core_vq.py:140-149 -- module/models.py:_Codebook.init_embed_)
         if reducer is not None:
             reducer.broadcast_params(eng.rt_g.arena.param)
             reducer.broadcast_params(eng.rt_d.arena.param)

@@ -210,3 +210,28 @@ def test_lr_schedule_trajectory():
     for _ in range(150):
         assert ra.step() == rb.step() and ra.get_last_lr() == rb.get_last_lr()
         assert [g["lr"] for g in a.param_groups] == [g["lr"] for g in b.param_groups]
+
+
+def test_kmeans_codebook_init_matches_reference():
+    """a run without a pretrained generator: the codebook initialised from the first batch, same draws / same centres as
+    the reference's EuclideanCodebook, for more and for fewer vectors than codes"""
+    from easevoice_trainer_amd.module import models as PM
+    from src.easevoice.module import core_vq as RV
+
+    g = torch.Generator().manual_seed(10)
+    for n, K, dim, iters in ((700, 64, 24, 50), (40, 64, 24, 50), (300, 16, 8, 7)):
+        data = torch.randn(n, dim, generator=g) + 2.0 * torch.randint(0, 4, (n, 1), generator=g)
+        ref = RV.EuclideanCodebook(dim, K, kmeans_init=True, kmeans_iters=iters)
+        ref.eval()
+        ours = PM._Codebook(dim, K)
+        ours.KMEANS_ITERS = iters
+        torch.manual_seed(n)
+        _q, ind_ref = ref(data[None])
+        after_ref = torch.randint(0, 10 ** 6, (1,)).item()
+        torch.manual_seed(n)
+        ours.init_embed_(data)
+        after_ours = torch.randint(0, 10 ** 6, (1,)).item()
+        assert after_ref == after_ours
+        assert torch.equal(ours.embed, ref.embed) and torch.equal(ours.embed_avg, ref.embed_avg)
+        assert torch.equal(ours.cluster_size, ref.cluster_size) and float(ours.inited) == float(ref.inited) == 1.0
+        assert torch.equal(ours.nearest(data), ind_ref[0])
