@@ -63,16 +63,20 @@ class EvtConv1d(nn.Module):
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         fan_in = d1 * k if not transposed else d0 * k  # torch: fan_in is computed from weight.size(1)*k
         fan_in = w.size(1) * k
+        bias_p = None
+        if bias:
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+            bias_p = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        # registration order = the reference's parameters() order, which numbers the optimiser state of a checkpoint:
+        # plain conv (weight, bias); torch.nn.utils.weight_norm removes `weight` and appends weight_g, weight_v, so a
+        # weight-normed conv enumerates as (bias, weight_g, weight_v)
         if weight_norm:
+            self.register_parameter("bias", bias_p)
             self.weight_g = nn.Parameter(w.reshape(d0, -1).norm(dim=1).reshape((d0,) + (1,) * (w.dim() - 1)))
             self.weight_v = nn.Parameter(w)
         else:
             self.weight = nn.Parameter(w)
-        if bias:
-            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
-            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
-        else:
-            self.register_parameter("bias", None)
+            self.register_parameter("bias", bias_p)
         self._slot = None
 
     @property

@@ -58,7 +58,9 @@ class FlatAdamW:
     `grad is None` parameters."""
 
     def __init__(self, arena: ParamArena, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        """groups: list of dict(names=[param names], lr=float)"""
+        """groups: list of dict(names=[param names], lr=float[, slots=[param names]]).  `slots` is the group's parameter
+        list as the reference's optimizer holds it (it may contain parameters that never receive a gradient and so are
+        not in `names`); it only fixes the numbering of state_dict(), so that checkpoints resume in either direction."""
         self.arena, self.betas, self.eps, self.weight_decay = arena, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(arena.param)
         self.exp_avg_sq = torch.zeros_like(arena.param)
@@ -75,7 +77,8 @@ class FlatAdamW:
                     merged[-1][1] = e_al
                 else:
                     merged.append([b, e_al])
-            self.groups.append(dict(lr=g["lr"], initial_lr=g["lr"], ranges=merged, names=list(g["names"])))
+            self.groups.append(dict(lr=g["lr"], initial_lr=g["lr"], ranges=merged, names=list(g["names"]),
+                                    slots=list(g.get("slots", g["names"]))))
         self._table = None
         self._table_lrs = None
 
@@ -118,15 +121,18 @@ class FlatAdamW:
 
     # ---- torch.optim-compatible checkpoint surface (src/utils/path/ckpt.py:78-93 stores optimizer.state_dict()) ----
     def state_dict(self):
+        """torch.optim.AdamW.state_dict() layout: parameters numbered group by group in `slots` order; entries only for
+        parameters that are updated (a parameter without gradients has no state in torch either)"""
         named = dict(self.arena.model.named_parameters())
         state, idx, pgroups = {}, 0, []
         for g in self.groups:
-            ids = []
-            for n in g["names"]:
-                b, e = self.arena.range_of(n, named[n].numel())
-                state[idx] = dict(step=torch.tensor(float(self.step_count)),
-                                  exp_avg=self.exp_avg[b:e].view(named[n].shape).clone(),
-                                  exp_avg_sq=self.exp_avg_sq[b:e].view(named[n].shape).clone())
+            ids, live = [], set(g["names"])
+            for n in g["slots"]:
+                if n in live:
+                    b, e = self.arena.range_of(n, named[n].numel())
+                    state[idx] = dict(step=torch.tensor(float(self.step_count)),
+                                      exp_avg=self.exp_avg[b:e].view(named[n].shape).clone(),
+                                      exp_avg_sq=self.exp_avg_sq[b:e].view(named[n].shape).clone())
                 ids.append(idx)
                 idx += 1
             pgroups.append(dict(lr=g["lr"], initial_lr=g["initial_lr"], betas=self.betas, eps=self.eps,
@@ -137,11 +143,14 @@ class FlatAdamW:
         named = dict(self.arena.model.named_parameters())
         idx = 0
         for g, pg in zip(self.groups, sd["param_groups"]):
+            if len(pg["params"]) != len(g["slots"]):
+                raise ValueError(f"optimizer state has {len(pg['params'])} parameters in a group of {len(g['slots'])}")
             g["lr"] = pg["lr"]
             g["initial_lr"] = pg.get("initial_lr", pg["lr"])
-            for n in g["names"]:
-                st = sd["state"].get(idx)
-                if st is not None:
+            live = set(g["names"])
+            for n, pid in zip(g["slots"], pg["params"]):
+                st = sd["state"].get(pid)
+                if st is not None and n in live:
                     b, e = self.arena.range_of(n, named[n].numel())
                     self.exp_avg[b:e].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[b:e].copy_(st["exp_avg_sq"].reshape(-1))

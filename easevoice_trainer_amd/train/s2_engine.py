@@ -55,19 +55,26 @@ class S2Engine:
 
     # -- optimisers: 4 groups for G exactly as sovits.py:286-319 (text_embedding / encoder_text / mrte at a
     #    lower lr), everything that receives no gradient (ssl_proj) left out
-    def build_optimizers(self):
-        t = self.hps["train"]
-        lr, low = t["learning_rate"], t["learning_rate"] * t["text_low_lr_rate"]
-        names = [n for n, _ in self.net_g.named_parameters()]
-        frozen = [n for n in names if n.startswith("ssl_proj.")]
+    @staticmethod
+    def g_param_groups(net_g, lr, low):
+        """the four AdamW groups of src/train/sovits.py:285-313, by parameter name: everything else / text_embedding /
+        encoder_text / mrte (the last three at text_low_lr_rate).  ssl_proj never receives a gradient (models.py:912-921)
+        and is not updated, but it sits in the reference's first group, so it keeps its slot in the numbering."""
+        names = [n for n, _ in net_g.named_parameters()]
+        frozen = {n for n in names if n.startswith("ssl_proj.")}
         te = [n for n in names if n.startswith("enc_p.text_embedding.")]
         et = [n for n in names if n.startswith("enc_p.encoder_text.")]
         mr = [n for n in names if n.startswith("enc_p.mrte.")]
-        special = set(te + et + mr + frozen)
-        base = [n for n in names if n not in special]
-        self.optim_g = FlatAdamW(self.rt_g.arena, [dict(names=base, lr=lr), dict(names=te, lr=low),
-                                                   dict(names=et, lr=low), dict(names=mr, lr=low)],
-                                 betas=tuple(t["betas"]), eps=t["eps"])
+        special = set(te + et + mr)
+        slots = [n for n in names if n not in special]
+        return [dict(names=[n for n in slots if n not in frozen], slots=slots, lr=lr), dict(names=te, lr=low),
+                dict(names=et, lr=low), dict(names=mr, lr=low)]
+
+    def build_optimizers(self):
+        t = self.hps["train"]
+        lr, low = t["learning_rate"], t["learning_rate"] * t["text_low_lr_rate"]
+        self.optim_g = FlatAdamW(self.rt_g.arena, self.g_param_groups(self.net_g, lr, low), betas=tuple(t["betas"]),
+                                 eps=t["eps"])
         self.optim_d = FlatAdamW(self.rt_d.arena, [dict(names=[n for n, _ in self.net_d.named_parameters()], lr=lr)],
                                  betas=tuple(t["betas"]), eps=t["eps"])
         return self.optim_g, self.optim_d

@@ -235,3 +235,84 @@ def test_kmeans_codebook_init_matches_reference():
         assert torch.equal(ours.embed, ref.embed) and torch.equal(ours.embed_avg, ref.embed_avg)
         assert torch.equal(ours.cluster_size, ref.cluster_size) and float(ours.inited) == float(ref.inited) == 1.0
         assert torch.equal(ours.nearest(data), ind_ref[0])
+
+
+def _ref_optim_g(net_g, lr, low, betas, eps):
+    """the optimiser construction of src/train/sovits.py:285-313 (the trainer module itself needs tensorboard to import)"""
+    te_p = list(map(id, net_g.enc_p.text_embedding.parameters()))
+    et_p = list(map(id, net_g.enc_p.encoder_text.parameters()))
+    mrte_p = list(map(id, net_g.enc_p.mrte.parameters()))
+    base = filter(lambda p: id(p) not in te_p + et_p + mrte_p and p.requires_grad, net_g.parameters())
+    return torch.optim.AdamW([{"params": base, "lr": lr}, {"params": net_g.enc_p.text_embedding.parameters(), "lr": low},
+                              {"params": net_g.enc_p.encoder_text.parameters(), "lr": low},
+                              {"params": net_g.enc_p.mrte.parameters(), "lr": low}], lr, betas=betas, eps=eps)
+
+
+def test_s2_checkpoints_resume_in_both_directions(tmp_path):
+    """G_*.pth written by the reference's save_checkpoint resumes here, and ours resumes there: model tensors and every
+    parameter's AdamW moments land on the same parameter (the optimiser state is numbered by position, and ssl_proj
+    sits in the reference's first group without ever getting state)"""
+    import json
+    from easevoice_trainer_amd.module import models as PM
+    from easevoice_trainer_amd.runtime import FlatAdamW, ParamArena
+    from easevoice_trainer_amd.train.s2_engine import S2Engine
+    from easevoice_trainer_amd.utils import ckpt as PCK
+    from src.easevoice.module import models as RM
+    from src.utils.path import ckpt as RCK
+    from util_fill import fill_module
+
+    hps = json.load(open(os.path.join(os.path.dirname(HERE), "configs", "s2.json")))
+    lr, low, betas, eps = 1e-4, 4e-5, (0.8, 0.99), 1e-9
+    ref = RM.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    fill_module(ref, 1)
+    ropt = _ref_optim_g(ref, lr, low, betas, eps)
+    g = torch.Generator().manual_seed(0)
+    for n, p in ref.named_parameters():
+        if not n.startswith("ssl_proj."):
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    ropt.step()
+    for grp in ropt.param_groups:
+        grp["initial_lr"] = grp["lr"]              # what ExponentialLR adds (sovits.py:368-376)
+    p_ref = str(tmp_path / "G_ref.pth")
+    RCK.save_checkpoint(ref, ropt, lr, 3, p_ref)
+    ref_state = {n: ropt.state[p] for n, p in ref.named_parameters() if p in ropt.state}
+    assert "ssl_proj.weight" not in ref_state and len(ref_state) == len(list(ref.parameters())) - 2
+
+    # ---- reference -> ours ----
+    ours = PM.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    arena = ParamArena(ours, "cpu")
+    opt = FlatAdamW(arena, S2Engine.g_param_groups(ours, lr, low), betas=betas, eps=eps)
+    _, _, got_lr, it = PCK.load_checkpoint(p_ref, ours, opt)
+    assert (got_lr, it) == (lr, 3) and opt.step_count == 1
+    named = dict(ours.named_parameters())
+    for n, p in ref.named_parameters():
+        assert torch.equal(named[n].detach(), p.detach()), n
+        b, e = arena.range_of(n, p.numel())
+        if n in ref_state:
+            assert torch.equal(opt.exp_avg[b:e].view(p.shape), ref_state[n]["exp_avg"]), n
+            assert torch.equal(opt.exp_avg_sq[b:e].view(p.shape), ref_state[n]["exp_avg_sq"]), n
+        else:
+            assert not opt.exp_avg[b:e].any()
+    assert [g_["lr"] for g_ in opt.param_groups] == [lr, low, low, low]
+
+    # ---- ours -> reference ----
+    p_ours = str(tmp_path / "G_ours.pth")
+    PCK.save_checkpoint(ours, opt, lr, 4, p_ours)
+    ref2 = RM.SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    ropt2 = _ref_optim_g(ref2, lr, low, betas, eps)
+    _, _, got_lr, it = RCK.load_checkpoint(p_ours, ref2, ropt2)
+    assert (got_lr, it) == (lr, 4)
+    for n, p in ref2.named_parameters():
+        assert torch.equal(p.detach(), dict(ref.named_parameters())[n].detach()), n
+        if n in ref_state:
+            st = ropt2.state[p]
+            assert torch.equal(st["exp_avg"], ref_state[n]["exp_avg"]) and float(st["step"]) == 1.0, n
+            assert torch.equal(st["exp_avg_sq"], ref_state[n]["exp_avg_sq"]), n
+        else:
+            assert p not in ropt2.state
+    assert [g_["lr"] for g_ in ropt2.param_groups] == [lr, low, low, low]
+    # the reference optimiser still steps after the resume (hyper-parameters of the groups are complete)
+    for n, p in ref2.named_parameters():
+        if not n.startswith("ssl_proj."):
+            p.grad = torch.zeros_like(p)
+    ropt2.step()
