@@ -14,7 +14,7 @@ import yaml
 from ..dist import GradReducer, init_process_group_from_env
 from ..utils.connector import MultiProcessOutputConnector
 from .data import SyntheticS1Batches, open_source
-from .helper import TrainOutput, get_gpt_train_dir, repo_root, train_logs_path
+from .helper import TrainOutput, default_pretrained, get_gpt_train_dir, repo_root, train_logs_path
 from .s1_engine import S1Engine
 
 logger = logging.getLogger("easevoice")
@@ -48,7 +48,8 @@ class GPTTrain:
         c["batch_size"], c["epochs"], c["save_every_n_epoch"] = params.batch_size, params.total_epochs, params.save_every_epoch
         c["if_dpo"], c["if_save_latest"], c["if_save_every_weights"] = params.if_dpo, params.if_save_latest, params.if_save_every_weights
         c["half_weights_save_dir"], c["output_name"] = self.train_output, params.output_model_name
-        self.config["pretrained_s1"] = params.model_path
+        # the reference's dataclass default is its stock pretrained checkpoint (src/train/gpt.py:35)
+        self.config["pretrained_s1"] = params.model_path or default_pretrained("s1")
         self.config["logs_output_dir"] = self.train_logs_output
         self.global_step = 0
 

@@ -15,7 +15,7 @@ from ..dist import GradReducer, init_process_group_from_env
 from ..utils import ckpt
 from ..utils.connector import MultiProcessOutputConnector
 from .data import SyntheticS2Batches, open_source
-from .helper import TrainOutput, get_sovits_train_dir, repo_root, train_logs_path
+from .helper import TrainOutput, default_pretrained, get_sovits_train_dir, repo_root, train_logs_path
 from .s2_engine import S2Engine
 
 logger = logging.getLogger("easevoice")
@@ -50,7 +50,10 @@ class SovitsTrain:
         t["output_dir"] = get_sovits_train_dir(params.project_dir, params.output_model_name)
         t["train_logs_dir"] = os.path.join(t["output_dir"], train_logs_path)
         t["save_weight_dir"] = t["output_dir"]
-        t["pretrained_s2G"], t["pretrained_s2D"] = params.pretrained_s2G, params.pretrained_s2D
+        # an empty path (or the relative default the reference's UI sends) means "the stock pretrained pair", sovits.py:149-157
+        stock = ("", "pretrained/gsv-v2final-pretrained/s2G2333k.pth", "pretrained/gsv-v2final-pretrained/s2D2333k.pth")
+        t["pretrained_s2G"] = default_pretrained("s2G") if params.pretrained_s2G in stock[:2] else params.pretrained_s2G
+        t["pretrained_s2D"] = default_pretrained("s2D") if params.pretrained_s2D in (stock[0], stock[2]) else params.pretrained_s2D
         os.makedirs(t["output_dir"], exist_ok=True)
         os.makedirs(t["train_logs_dir"], exist_ok=True)
         self.hps, self.params, self.dtype = hps, params, dtype

@@ -316,3 +316,97 @@ def test_s2_checkpoints_resume_in_both_directions(tmp_path):
         if not n.startswith("ssl_proj."):
             p.grad = torch.zeros_like(p)
     ropt2.step()
+
+
+def test_stdout_protocol_lines_equal_reference(capsys):
+    """the `<prefix> <json>` lines a trainer process prints are what the reference's own connector prints (and parses)"""
+    from easevoice_trainer_amd.utils import connector as PC
+    from src.utils.helper import connector as RC
+    from src.utils.response import EaseVoiceResponse, ResponseStatus
+
+    ref, ours = RC.MultiProcessOutputConnector(), PC.MultiProcessOutputConnector()
+    ref.write_loss(7, 1.25, other={"loss/g/total": 1.25, "learning_rate": 1e-4})
+    ref.write_loss(8, 0.5)
+    ref.write_log({"epoch": 3, "msg": "x"})
+    ref.write_response(EaseVoiceResponse(ResponseStatus.SUCCESS, "Training completed", {"model_path": "/p/m"}))
+    ref.write_response(EaseVoiceResponse(ResponseStatus.FAILED, "boom"))
+    want = capsys.readouterr().out
+    ours.write_loss(7, 1.25, other={"loss/g/total": 1.25, "learning_rate": 1e-4})
+    ours.write_loss(8, 0.5)
+    ours.write_log({"epoch": 3, "msg": "x"})
+    ours.write_response(PC.ResponseStatus.SUCCESS, "Training completed", {"model_path": "/p/m"})
+    ours.write_response(PC.ResponseStatus.FAILED, "boom")
+    got = capsys.readouterr().out
+    assert got == want and want.count("\n") == 5
+
+
+def test_directory_and_checkpoint_selection_equal_reference(tmp_path):
+    from easevoice_trainer_amd.train import helper as PH
+    from easevoice_trainer_amd.utils import ckpt as PCK
+    from src.train import helper as RH
+    from src.utils.path import ckpt as RCK
+
+    for name in ("voice1", "", None):
+        a, b = PH.get_sovits_train_dir("/proj", name), RH.get_sovits_train_dir("/proj", name)
+        assert os.path.dirname(a) == os.path.dirname(b) and (a == b or not name)
+        a, b = PH.get_gpt_train_dir("/proj", name), RH.get_gpt_train_dir("/proj", name)
+        assert os.path.dirname(a) == os.path.dirname(b) and (a == b or not name)
+    assert PH.train_logs_path == RH.train_logs_path
+    rng = random.Random(11)
+    for case in range(20):
+        d = tmp_path / f"c{case}"
+        d.mkdir()
+        names = {f"G_{rng.randint(1, 99999)}.pth" for _ in range(rng.randint(1, 6))}
+        if rng.random() < 0.4:
+            names.add("G_latest.pth")
+        names |= {f"D_{rng.randint(1, 99999)}.pth", "notes.txt"}
+        for n in names:
+            (d / n).write_bytes(b"x")
+        assert PCK.latest_checkpoint_path(str(d), "G_*.pth") == RCK.latest_checkpoint_path(str(d), "G_*.pth"), names
+
+
+def _dataclass_fields_from_source(path, cls):
+    """(name, default) pairs of a dataclass read from source text -- the reference's trainer modules cannot be imported
+    here (tensorboard / pytorch_lightning are absent)"""
+    import ast
+    tree = ast.parse(open(path, encoding="utf8").read())
+    def lit(v):
+        try:
+            return ast.literal_eval(v)
+        except ValueError:
+            return ("name", ast.unparse(v))          # a default that is another module's constant
+
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            return [(st.target.id, lit(st.value) if st.value is not None else None)
+                    for st in node.body if isinstance(st, ast.AnnAssign)]
+    raise KeyError(cls)
+
+
+def test_params_files_and_configs_equal_reference():
+    """the `-c params.json` contract: same fields and defaults as the reference's dataclasses; same training configs"""
+    import dataclasses
+    import json
+    import yaml
+    from easevoice_trainer_amd.train.gpt import GPTTrainParams
+    from easevoice_trainer_amd.train.sovits import SovitsTrainParams
+
+    root = refshim.REFERENCE_ROOT
+    for ours, path, cls in ((SovitsTrainParams, "src/train/sovits.py", "SovitsTrainParams"),
+                            (GPTTrainParams, "src/train/gpt.py", "GPTTrainParams")):
+        want = _dataclass_fields_from_source(os.path.join(root, path), cls)
+        got = [(f.name, f.default) for f in dataclasses.fields(ours)]
+        # GPTTrainParams.model_path defaults to the reference's stock checkpoint path there; here "" resolves to the
+        # same file through helper.default_pretrained (checked below)
+        want = [(n, "" if d == ("name", "gpt_pretrained_model_path") else d) for n, d in want]
+        assert got == want, (cls, got, want)
+    repo = os.path.dirname(HERE)
+    assert json.load(open(os.path.join(repo, "configs", "s2.json"))) == json.load(open(os.path.join(root, "configs", "s2.json")))
+    # stock pretrained fallbacks: same files as src/utils/config/__init__.py:34-35 and sovits.py:149-157
+    from easevoice_trainer_amd.train import helper as PH
+    from src.utils import config as RCFG
+    assert os.path.join(RCFG.normalize_root, PH.PRETRAINED_FILES["s1"]) == RCFG.gpt_pretrained_model_path
+    assert os.path.join(RCFG.normalize_root, PH.PRETRAINED_FILES["s2G"]) == RCFG.sovits_pretrained_model_path
+    assert PH.PRETRAINED_FILES["s2D"] == PH.PRETRAINED_FILES["s2G"].replace("s2G", "s2D")
+    ours_cfg = yaml.safe_load(open(os.path.join(repo, "configs", "gpt.yaml")))
+    assert ours_cfg == yaml.safe_load(open(os.path.join(root, "configs", "gpt.yaml")))

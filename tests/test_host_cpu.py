@@ -139,3 +139,38 @@ def test_dp_flat_average_equals_full_batch():
     shards = [((x[i::2] @ w) ** 2).mean() for i in range(2)]
     gs = sum(torch.autograd.grad(s, w)[0] for s in shards) * 0.5
     assert torch.allclose(gf, gs, atol=1e-6)
+
+
+def test_stock_pretrained_fallback(tmp_path, monkeypatch):
+    """an empty pretrained path in the params file means the stock checkpoints, looked up like the reference does"""
+    from easevoice_trainer_amd.train import helper
+    from easevoice_trainer_amd.train.gpt import GPTTrain, GPTTrainParams
+    from easevoice_trainer_amd.train.sovits import SovitsTrain, SovitsTrainParams
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("EVT_PRETRAINED_DIR", raising=False)
+    if not os.path.isdir(os.path.join(helper.repo_root(), "models", "pretrained")):
+        assert helper.default_pretrained("s2G") == ""
+    root = tmp_path / "pre"
+    for k, rel in helper.PRETRAINED_FILES.items():
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_bytes(b"x")
+    monkeypatch.setenv("EVT_PRETRAINED_DIR", str(root))
+    s = SovitsTrain(SovitsTrainParams(project_dir=str(tmp_path), output_model_name="a"))
+    assert s.hps["train"]["pretrained_s2G"] == str(root / helper.PRETRAINED_FILES["s2G"])
+    assert s.hps["train"]["pretrained_s2D"] == str(root / helper.PRETRAINED_FILES["s2D"])
+    s = SovitsTrain(SovitsTrainParams(project_dir=str(tmp_path), output_model_name="b", pretrained_s2G="/x/G.pth",
+                                      pretrained_s2D="pretrained/gsv-v2final-pretrained/s2D2333k.pth"))
+    assert s.hps["train"]["pretrained_s2G"] == "/x/G.pth"
+    assert s.hps["train"]["pretrained_s2D"] == str(root / helper.PRETRAINED_FILES["s2D"])
+    g = GPTTrain(GPTTrainParams(project_dir=str(tmp_path), output_model_name="c"))
+    assert g.config["pretrained_s1"] == str(root / helper.PRETRAINED_FILES["s1"])
+    g = GPTTrain(GPTTrainParams(project_dir=str(tmp_path), output_model_name="d", model_path="/y/s1.ckpt"))
+    assert g.config["pretrained_s1"] == "/y/s1.ckpt"
+    # ./models/pretrained of the working directory (the service starts the trainer inside its checkout)
+    monkeypatch.delenv("EVT_PRETRAINED_DIR")
+    cw = tmp_path / "models" / "pretrained" / helper.PRETRAINED_FILES["s1"]
+    cw.parent.mkdir(parents=True)
+    cw.write_bytes(b"x")
+    assert helper.default_pretrained("s1") == str(cw)
