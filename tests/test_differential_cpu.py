@@ -410,3 +410,54 @@ def test_params_files_and_configs_equal_reference():
     assert PH.PRETRAINED_FILES["s2D"] == PH.PRETRAINED_FILES["s2G"].replace("s2G", "s2D")
     ours_cfg = yaml.safe_load(open(os.path.join(repo, "configs", "gpt.yaml")))
     assert ours_cfg == yaml.safe_load(open(os.path.join(root, "configs", "gpt.yaml")))
+
+
+def test_scaled_adam_random_trajectories():
+    """ScaledAdam host logic (batching by shape, scalar branch, size update every 4 steps, gradient clipping from the
+    running median with different update periods, lr changes) against the reference's optimiser on random problems"""
+    from cpu_emu import cpu_emulation_s1
+    from easevoice_trainer_amd.auto_reg.optim import ScaledAdam
+    from easevoice_trainer_amd.runtime import ParamArena
+    from src.easevoice.soundstorm.auto_reg.modules.optim import ScaledAdam as RefScaledAdam
+
+    rng = random.Random(12)
+    g = torch.Generator().manual_seed(12)
+    for case in range(6):
+        shapes = {}
+        for i in range(rng.randint(3, 9)):
+            kind = rng.choice(["mat", "mat", "vec", "scalar", "dup"])
+            shapes[f"p{i}"] = {"mat": (rng.randint(2, 9), rng.randint(2, 17)), "vec": (rng.randint(2, 20),), "scalar": (1,),
+                               "dup": (4, 6)}[kind]
+        init = {k: torch.randn(v, generator=g) * (0.5 if len(v) > 1 else 0.2) for k, v in shapes.items()}
+        period = rng.choice([3, 4, 7])
+        cs = rng.choice([2.0, 1.2])
+        ref_p = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+        ropt = RefScaledAdam(list(ref_p.values()), lr=0.01, betas=(0.9, 0.95), clipping_scale=cs, clipping_update_period=period,
+                             parameters_names=[list(ref_p.keys())], show_dominant_parameters=False)
+
+        class Holder(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                for k, v in init.items():
+                    setattr(self, k, torch.nn.Parameter(v.clone()))
+
+        with cpu_emulation_s1():
+            h = Holder()
+            arena = ParamArena(h, "cpu")
+            opt = ScaledAdam(arena, lr=0.01, betas=(0.9, 0.95), clipping_scale=cs, clipping_update_period=period)
+            params = dict(h.named_parameters())
+            for step in range(26):
+                scale = 8.0 if rng.random() < 0.15 else 1.0           # spikes so that clipping engages
+                arena.zero_grad()
+                for k in shapes:
+                    gr = torch.randn(shapes[k], generator=g) * 0.1 * scale
+                    ref_p[k].grad = gr.clone()
+                    params[k].grad.copy_(gr)
+                ropt.step()
+                opt.step()
+                lr = 0.002 if step > 2 else 0.01                      # the scheduler pins the lr after its first steps
+                for grp in ropt.param_groups:
+                    grp["lr"] = lr
+                opt.param_groups[0]["lr"] = lr
+                for k in shapes:
+                    assert torch.allclose(params[k].detach(), ref_p[k].detach(), rtol=1e-4, atol=3e-6), (case, step, k)
