@@ -101,3 +101,50 @@ def split_subgroups(ranks_a, ranks_b):
     ga = dist.new_group(ranks=list(ranks_a))
     gb = dist.new_group(ranks=list(ranks_b))
     return ga, gb
+
+
+def parse_gpu_ids(gpu_ids: str):
+    """"0-1-2" (SovitsTrainParams / GPTTrainParams.gpu_ids, src/train/sovits.py:47) -> [0, 1, 2]"""
+    return [int(t) for t in str(gpu_ids).replace(",", "-").split("-") if t.strip() != ""]
+
+
+def spawn_ranks(argv, gpu_ids, poll_s=0.2):
+    """One process per listed GPU on this node: re-runs `argv` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set (LOCAL_RANK = the GPU id, so "0-2" uses devices 0 and 2).  Every child inherits stdout/stderr: only
+    rank 0 prints protocol lines (the trainers print on rank 0, the cmd entry points answer on rank 0).  When a child
+    exits non-zero the others are terminated (by PID) -- a rank stuck in a collective would otherwise wait forever.
+    Returns the list of exit codes.  This is what `mp.spawn` / Lightning's launcher do for the reference
+    (src/train/sovits.py:199-211, src/train/gpt.py:147-162), as a plain process group."""
+    import socket
+    import subprocess
+    import time
+
+    ids = list(gpu_ids)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank, dev in enumerate(ids):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(dev), WORLD_SIZE=str(len(ids)), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   EVT_SPAWNED="1")
+        procs.append(subprocess.Popen(list(argv), env=env))
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[i] = pr.wait()
+            break
+        time.sleep(poll_s)
+    return codes

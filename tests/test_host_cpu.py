@@ -174,3 +174,36 @@ def test_stock_pretrained_fallback(tmp_path, monkeypatch):
     cw.parent.mkdir(parents=True)
     cw.write_bytes(b"x")
     assert helper.default_pretrained("s1") == str(cw)
+
+
+def test_spawn_ranks_runs_one_process_per_gpu_and_stops_on_failure(tmp_path):
+    """the launcher behind `gpu_ids = "0-1"`: env per rank, a gloo all-reduce across the children, and termination of
+    the surviving ranks when one fails"""
+    import sys
+    import time
+    from easevoice_trainer_amd.dist import parse_gpu_ids, spawn_ranks
+
+    assert parse_gpu_ids("0-2-5") == [0, 2, 5] and parse_gpu_ids("3") == [3] and parse_gpu_ids("0,1") == [0, 1]
+    ok = tmp_path / "ok.py"
+    ok.write_text("""
+import os, sys, torch, torch.distributed as dist
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+t = torch.tensor([float(os.environ['LOCAL_RANK'])])
+dist.all_reduce(t)
+with open(sys.argv[1] + os.environ['RANK'], 'w') as f:
+    f.write(os.environ['LOCAL_RANK'] + ' ' + os.environ['MASTER_ADDR'] + ' ' + str(t.item()))
+dist.destroy_process_group()
+""")
+    codes = spawn_ranks([sys.executable, str(ok), str(tmp_path / "out")], [0, 2])
+    assert codes == [0, 0]
+    assert (tmp_path / "out0").read_text() == "0 127.0.0.1 2.0" and (tmp_path / "out1").read_text() == "2 127.0.0.1 2.0"
+    bad = tmp_path / "bad.py"
+    bad.write_text("""
+import os, sys, time
+if os.environ['RANK'] == '1':
+    sys.exit(3)
+time.sleep(60)
+""")
+    t0 = time.time()
+    codes = spawn_ranks([sys.executable, str(bad)], [0, 1])
+    assert codes[1] == 3 and codes[0] not in (None, 0) and time.time() - t0 < 30
