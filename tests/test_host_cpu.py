@@ -207,3 +207,22 @@ time.sleep(60)
     t0 = time.time()
     codes = spawn_ranks([sys.executable, str(bad)], [0, 1])
     assert codes[1] == 3 and codes[0] not in (None, 0) and time.time() - t0 < 30
+
+
+def test_s1_engine_data_parallel_gloo(tmp_path):
+    """two ranks of the s1 engine (emulated launches, gloo): gradients accumulated locally over the accumulation window and
+    exchanged ONCE at the optimiser step give the parameters of a single process that saw both ranks' micro-batches
+    (the reference all-reduces on every micro-batch; the sum is the same)"""
+    import sys
+    from easevoice_trainer_amd.dist import spawn_ranks
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker_s1.py")
+    codes = spawn_ranks([sys.executable, worker, str(tmp_path / "dp")], [0, 1])
+    assert codes == [0, 0]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    import subprocess
+    subprocess.run([sys.executable, worker, str(tmp_path / "single")], check=True, env=env)
+    a, b = torch.load(tmp_path / "dp0"), torch.load(tmp_path / "dp1")
+    one = torch.load(tmp_path / "single0")
+    assert torch.equal(a, b)                                   # replicas stay identical
+    assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a))
