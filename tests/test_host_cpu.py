@@ -226,3 +226,31 @@ def test_s1_engine_data_parallel_gloo(tmp_path):
     one = torch.load(tmp_path / "single0")
     assert torch.equal(a, b)                                   # replicas stay identical
     assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a))
+
+
+def test_split_subgroups_gloo(tmp_path):
+    """BASELINE config 5's layout: one world, two sub-communicators (s1 ranks / s2 ranks), each reducing only its own
+    gradients through GradReducer(group=...)"""
+    import sys
+    from easevoice_trainer_amd.dist import spawn_ranks
+
+    w = tmp_path / "sub.py"
+    w.write_text("""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from easevoice_trainer_amd.dist import GradReducer, split_subgroups
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+ga, gb = split_subgroups([0], [1, 2])
+mine, n = (ga, 1) if rank == 0 else (gb, 2)
+red = GradReducer(n, bucket_bytes=64, group=mine)
+g = torch.full((50,), float(rank + 1))
+red.all_reduce(g, average=True)
+with open(sys.argv[1] + str(rank), 'w') as f:
+    f.write(str(g[0].item()) + ' ' + str(g[-1].item()))
+dist.destroy_process_group()
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    codes = spawn_ranks([sys.executable, str(w), str(tmp_path / "o")], [0, 1, 2])
+    assert codes == [0, 0, 0]
+    assert (tmp_path / "o0").read_text() == "1.0 1.0"            # a group of one is left alone
+    assert (tmp_path / "o1").read_text() == "2.5 2.5" and (tmp_path / "o2").read_text() == "2.5 2.5"
