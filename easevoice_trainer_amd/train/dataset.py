@@ -68,8 +68,9 @@ def read_name2text(path):
 # ---------------------------------------------------------------------------------------------------------------------
 # 5-wav32k reader
 # ---------------------------------------------------------------------------------------------------------------------
-def read_wav_pcm16(path, sampling_rate):
-    """float32 mono samples in [-1, 1) of a RIFF/WAVE PCM16 file whose rate is already `sampling_rate`.
+def read_wav_pcm16(path, sampling_rate, raw=False):
+    """float32 mono samples in [-1, 1) of a RIFF/WAVE PCM16 file whose rate is already `sampling_rate` (raw=True: the int16
+    samples themselves for mono files -- the caller scales them by 1/32768 later, e.g. on the GPU; exact either way).
 
     Equals what load_audio (src/utils/audio/__init__.py:13-32: ffmpeg -> f32le, ac=1, ar=sr) returns for the files the
     reference's normalisation step writes into 5-wav32k: no resampling happens there and s16 -> f32 is x/32768.  Other
@@ -96,6 +97,8 @@ def read_wav_pcm16(path, sampling_rate):
     if rate != sampling_rate:
         raise ValueError(f"{path}: sample rate {rate} != {sampling_rate} (5-wav32k is written at the training rate)")
     pcm = np.frombuffer(data[:len(data) // (2 * channels) * 2 * channels], dtype="<i2")
+    if raw and channels == 1:
+        return pcm
     x = pcm.astype(np.float32) * np.float32(1.0 / 32768.0)
     if channels > 1:
         x = x.reshape(-1, channels).mean(axis=1, dtype=np.float32)
@@ -161,21 +164,24 @@ class S2FeatureDir:
     def __len__(self):
         return len(self.items)
 
-    def load(self, index):
+    def load(self, index, raw=False):
         """(ssl [1,768,T'], wav [1,L], text float [n], frames, ok) of one item, data_utils.py:101-121 minus the
         spectrogram (computed on the GPU by S2Reader); a failed read gives the reference's all-zero placeholder item
-        (ok=False: its spectrogram stays exactly zero, as there)."""
+        (ok=False: its spectrogram stays exactly zero, as there).  raw=True keeps the file dtypes (int16 samples, the
+        hubert tensor as stored): the reader converts after the copy to the device, with the same values."""
         name, ids = self.items[index]
         text, ok = torch.tensor(ids, dtype=torch.float32), True
         try:
-            wav = torch.from_numpy(read_wav_pcm16("%s/%s" % (self.path5, name), self.sampling_rate)).unsqueeze(0)
+            wav = torch.from_numpy(np.array(read_wav_pcm16("%s/%s" % (self.path5, name), self.sampling_rate, raw=raw))
+                                   ).unsqueeze(0)
             pad = (self.filter_length - self.hop_length) // 2
             if wav.size(1) <= pad:
                 raise ValueError(f"{name}: {wav.size(1)} samples cannot be reflect-padded by {pad}")
             frames = spec_frames(wav.size(1), self.filter_length, self.hop_length)
             ssl = torch.load("%s/%s.pt" % (self.path4, name), map_location="cpu")
             if ssl.shape[-1] != frames:
-                ssl = torch.nn.functional.pad(ssl.float(), (0, 1), mode="replicate").to(ssl.dtype)
+                ssl = torch.cat([ssl, ssl[..., -1:]], dim=-1) if raw else \
+                    torch.nn.functional.pad(ssl.float(), (0, 1), mode="replicate").to(ssl.dtype)
             ssl.requires_grad = False
         except Exception:
             traceback.print_exc()
@@ -251,14 +257,16 @@ def _round_up(n, k):
     return -(-n // k) * k
 
 
-def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640):
+def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=True):
     """TextAudioSpeakerCollate (data_utils.py:167-226) for items (ssl, wav, text, frames, ...): rows sorted by spectrogram
     length, longest first; ssl and spec time axes padded to 2*(max//2+1); everything else to the batch maximum.
     Returns the reference's 8-tuple with `spec_padded` zero-filled plus `order` (source index of each row): the caller
     writes row i's spectrogram into spec_padded[i, :, :spec_lengths[i]].
     pad_frames > 0 (not in the reference) rounds the padded time axes up to a multiple of that many frames (samples: x hop):
     every consumer masks by the lengths, so the step's result does not change, but the batches of a run then repeat a
-    few dozen shapes instead of several hundred -- what the trainer's per-shape HIP-graph replay needs."""
+    few dozen shapes instead of several hundred -- what the trainer's per-shape HIP-graph replay needs.
+    with_spec=False leaves `spec_padded` out (None; its shape is returned as the third element instead): the reader
+    creates it on the device, there is nothing in it to copy from the host."""
     n = len(items)
     _, order = torch.sort(torch.tensor([it[3] for it in items], dtype=torch.long), dim=0, descending=True)
     order = order.tolist()
@@ -273,9 +281,16 @@ def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640):
     def buf(shape, dtype):
         return torch.zeros(shape, dtype=dtype, pin_memory=pin)
 
-    ssl_p = buf((n, items[0][0].size(1), max_ssl), torch.float32)
-    spec_p = buf((n, spec_bins, max_spec), torch.float32)
-    wav_p = buf((n, 1, max_wav), torch.float32)
+    def buffer_dtype(k):
+        """float32 like the reference's collate; on the reader's path (with_spec=False) the items' own dtype when they
+        agree (int16 samples / fp16 features: half the bytes to pin and copy, converted on the device)"""
+        dts = {it[k].dtype for it in items if len(it) < 5 or it[4]}        # placeholder items do not vote
+        return next(iter(dts)) if (not with_spec and len(dts) == 1) else torch.float32
+
+    ssl_dt, wav_dt = buffer_dtype(0), buffer_dtype(1)
+    ssl_p = buf((n, items[0][0].size(1), max_ssl), ssl_dt)
+    spec_p = buf((n, spec_bins, max_spec), torch.float32) if with_spec else (n, spec_bins, max_spec)
+    wav_p = buf((n, 1, max_wav), wav_dt)
     text_p = buf((n, max_text), torch.long)
     ssl_l, spec_l, wav_l, text_l = (torch.zeros(n, dtype=torch.long) for _ in range(4))
     for i, src in enumerate(order):
@@ -332,11 +347,18 @@ class S2Reader:
     """Iterable of device batches with the layout of the reference's s2 DataLoader (src/train/sovits.py:229-267)."""
 
     def __init__(self, exp_dir, data_cfg, batch_size, device, rank=0, world=1, boundaries=None, prefetch=4,
-                 symbol_to_id=None, spec_fn=None, pad_frames=None):
+                 symbol_to_id=None, spec_fn=None, pad_frames=None, loader_threads=1):
         self.ds = S2FeatureDir(exp_dir, data_cfg, symbol_to_id=symbol_to_id)
         self.sampler = S2BucketSampler(self.ds.lengths, batch_size, boundaries, num_replicas=world, rank=rank)
         self.device, self.prefetch = torch.device(device), prefetch
         self.pad_frames = int(os.environ.get("EVT_PAD_FRAMES", "0")) if pad_frames is None else int(pad_frames)
+        # one host thread reads ~830 items/s from the page cache (8 cores of this container; a B=16 step every 32 ms needs
+        # 500): threads on top of it only fight over the interpreter lock (2: 620, 4: 475 items/s measured), so the option
+        # stays off; the cheap part -- sample and feature conversion to float32 -- runs on the GPU after the copy instead
+        self._pool = None
+        if loader_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=loader_threads, thread_name_prefix="evt-read")
         self.spec_bins = self.ds.filter_length // 2 + 1
         if spec_fn is None:
             from ..module.mel_processing import spectrogram_torch as spec_fn
@@ -349,16 +371,21 @@ class S2Reader:
         return len(self.sampler)
 
     def _host_batch(self, indices):
-        items = [self.ds.load(i) for i in indices]
+        ld = lambda i: self.ds.load(i, raw=True)
+        items = list(self._pool.map(ld, indices)) if self._pool is not None else [ld(i) for i in indices]
         batch, order = collate_s2(items, self.spec_bins, pin=self.device.type == "cuda", pad_frames=self.pad_frames,
-                                  hop=self.ds.hop_length)
+                                  hop=self.ds.hop_length, with_spec=False)
         return batch, [items[src][4] for src in order]
 
     def __iter__(self):
         ds, dev = self.ds, self.device
         for (ssl, ssl_l, spec, spec_l, wav, wav_l, text, text_l), ok in _Prefetch(self._host_batch, iter(self.sampler),
                                                                                  self.prefetch):
-            ssl, spec, wav, text = (t.to(dev, non_blocking=True) for t in (ssl, spec, wav, text))
+            ssl, wav, text = (t.to(dev, non_blocking=True) for t in (ssl, wav, text))
+            ssl = ssl.float()                                              # file dtype (fp16) -> float32, as the collate there
+            if wav.dtype == torch.int16:
+                wav = wav.float() * (1.0 / 32768.0)                        # what ffmpeg's s16 -> flt does, exactly
+            spec = torch.zeros(spec, dtype=torch.float32, device=dev)      # `spec` came as the shape (with_spec=False)
             for i in range(wav.size(0)):
                 if not ok[i]:
                     continue

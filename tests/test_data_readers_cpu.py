@@ -149,6 +149,27 @@ def test_s2_collate_matches_reference(feature_dir, gold):
                 assert tstat(t) == g[k]["stat"], k
 
 
+def test_s2_reader_batches_match_reference_collate(feature_dir, gold):
+    """the reader's own path (file dtypes on the host, conversion after the copy, spectrogram buffer created on the device)
+    gives the reference collate's batch for the same items"""
+    rd = D.S2Reader(feature_dir, CFG, batch_size=4, device="cpu", spec_fn=oracle_spec)
+    first = {}
+    for i, (name, _) in enumerate(rd.ds.items):
+        first.setdefault(name, i)
+    keys = ["ssl", "ssl_len", "spec", "spec_len", "wav", "wav_len", "text", "text_len"]
+    for g in gold["s2_collate"]:
+        rd.sampler = [[first[n] for n in g["names"]]]
+        (batch,) = list(rd)
+        for k, t in zip(keys, batch):
+            assert list(t.shape) == g[k]["shape"] and str(t.dtype) == g[k]["dtype"], k
+            if "values" in g[k]:
+                assert t.tolist() == g[k]["values"], k
+            elif k == "spec":
+                assert close(tstat(t), g[k]["stat"], rel=2e-5), k
+            else:
+                assert tstat(t) == g[k]["stat"], k
+
+
 def test_s2_bucket_sampler_matches_reference(gold):
     lengths = F.sampler_lengths()
     for g in gold["s2_sampler"]:
