@@ -6,7 +6,6 @@ Arithmetic of src/easevoice/soundstorm/auto_reg/modules/optim.py:206-251 (step),
 over the whole model per optimiser step plus O(#tensors) vector ops, instead of 11 stacked batches of torch ops with
 stack/unstack copies of every parameter and gradient."""
 import ctypes as C
-import math
 
 import torch
 

@@ -3,8 +3,6 @@
 `mel_spectrogram_torch` (needs a backward: it is applied to the generated waveform) is the fused HIP
 STFT->magnitude->mel->log kernel with an analytic backward; `spec_to_mel_torch` (target side, no grad) is a
 plain GEMM; `spectrogram_torch` (dataset side) reuses the HIP kernel's magnitude output."""
-import ctypes as C
-
 import numpy as np
 import torch
 

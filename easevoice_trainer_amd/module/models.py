@@ -13,7 +13,6 @@ mrte_model.py:9-61, core_vq.py:172-228), re-laid-out for the hardware:
 
 There is no CPU / eager fallback: the modules need a WeightBank (hip/conv.py) and a GPU.
 """
-import math
 
 import torch
 from torch import nn
@@ -23,7 +22,7 @@ from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
 from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
 from . import commons
-from .attentions import Encoder, LayerNorm, MultiHeadAttention, PointwiseConv, pointwise
+from .attentions import Encoder, MultiHeadAttention, PointwiseConv, pointwise
 
 LRELU_SLOPE = 0.1
 N_SYMBOLS = 732  # len(SYMBOLS), src/easevoice/text/symbols.py:410-412 (pinned by tests/easevoice/text_test.py)

@@ -125,7 +125,7 @@ def cpu_emulation():
 @contextlib.contextmanager
 def cpu_emulation_s1():
     """substitutes the three s1 autograd Functions and ScaledAdam's two kernel calls by torch CPU equivalents"""
-    from easevoice_trainer_amd.auto_reg import ops as AO, optim as OPT, t2s_model as TM
+    from easevoice_trainer_amd.auto_reg import optim as OPT, t2s_model as TM
     from oracle import s1_step as OS
 
     saved = (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,

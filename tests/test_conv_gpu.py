@@ -5,7 +5,6 @@ checked at 3e-2 against the fp32 oracle evaluated on bf16-rounded inputs.
 """
 import pytest
 import torch
-from torch import nn
 
 from oracle import ops as O
 
@@ -60,7 +59,7 @@ FUSIONS = [
 
 
 def _run_case(gpu, case, fusion, dtype, impl):
-    from easevoice_trainer_amd.hip import conv as HC, lib as HL
+    from easevoice_trainer_amd.hip import conv as HC
 
     cin, cout, k, stride, pad, dil, groups, transposed, wn, Lin, nseq = case
     torch.manual_seed(hash(case) % 100000)

@@ -1,7 +1,6 @@
 """CPU: the product's s1 module wiring and ScaledAdam host logic vs fixtures generated from the reference's own
 Text2SemanticDecoder / ScaledAdam.  HIP launches are substituted by torch CPU ops (tests/cpu_emu.py); the kernels are
 covered by the -m gpu tests."""
-import json
 import os
 
 import pytest

@@ -14,7 +14,6 @@ this box's host cores on a bounded sample of the same workload (2 clips of 4 s i
 """
 import json
 import os
-import time
 
 import torch
 

@@ -1,7 +1,6 @@
 """bench.py --workload s1: the s1 AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th
 micro-batch as in the reference) at BASELINE configs[2]: batch 32, x_len 256 + y_len 768 = 1024, bf16.
 metric: tokens/sec = N * B * 1024 / micro-step time."""
-import json
 import os
 import time
 
