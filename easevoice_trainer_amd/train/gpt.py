@@ -12,6 +12,7 @@ import torch
 import yaml
 
 from ..dist import GradReducer, init_process_group_from_env
+from ..utils import tb
 from ..utils.connector import MultiProcessOutputConnector
 from .data import SyntheticS1Batches, open_source
 from .helper import TrainOutput, default_pretrained, get_gpt_train_dir, repo_root, train_logs_path
@@ -98,14 +99,23 @@ class GPTTrain:
                              rank=rank, world=world)
         connector = MultiProcessOutputConnector()
         step_no = 0
+        writer = None
+        if rank == 0:       # TensorBoardLogger(name=<model name>, save_dir=<tb_logs>) of src/train/gpt.py:143: version_<n> below it
+            base = tb.tensorboard_log_dir(self.params.output_model_name or "gpt")
+            n = 0
+            while os.path.isdir(os.path.join(base, f"version_{n}")):
+                n += 1
+            writer = tb.open_writer(os.path.join(base, f"version_{n}"))
         for epoch in range(start_epoch, c["epochs"]):
             source.set_epoch(epoch)
             for batch_idx, batch in enumerate(source):
                 loss, acc, stepped = eng.micro_step(batch, batch_idx)
                 self.global_step += int(stepped)
                 if rank == 0:
-                    connector.write_loss(step_no, loss=float(loss), other={
-                        "acc": float(acc), "lr": eng.scheduler.get_last_lr()[0], "epoch": epoch})
+                    lv, av, lr = float(loss), float(acc), eng.scheduler.get_last_lr()[0]
+                    connector.write_loss(step_no, loss=lv, other={"acc": av, "lr": lr, "epoch": epoch})
+                    # the three self.log() scalars of t2s_lightning_module.py:58-80 (Lightning's per-step tag names)
+                    tb.log_scalars(writer, step_no, {"total_loss_step": lv, "lr": lr, "top_3_acc_step": av})
                 step_no += 1
             if (epoch + 1) % c["save_every_n_epoch"] == 0 and rank == 0:
                 if c["if_save_latest"]:

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import torch
 
 from ..dist import GradReducer, init_process_group_from_env
-from ..utils import ckpt
+from ..utils import ckpt, tb
 from ..utils.connector import MultiProcessOutputConnector
 from .data import SyntheticS2Batches, open_source
 from .helper import TrainOutput, default_pretrained, get_sovits_train_dir, repo_root, train_logs_path
@@ -122,6 +122,7 @@ class SovitsTrain:
         sched_epoch = epoch_str
         set_lr(sched_epoch)
         connector = MultiProcessOutputConnector()
+        writer = tb.open_writer(tb.tensorboard_log_dir(hps["name"])) if rank == 0 else None   # sovits.py:220
         for epoch in range(epoch_str, t["epochs"] + 1):
             source.set_epoch(epoch)
             for batch_idx, (ssl, _ssl_len, spec, spec_len, y, _y_len, text, text_len) in enumerate(source):
@@ -131,6 +132,17 @@ class SovitsTrain:
                     connector.write_loss(self.global_step, loss=loss, other={
                         "loss/g/total": loss, "loss/d/total": float(out.disc),
                         "learning_rate": optim_g.param_groups[0]["lr"]})
+                if self.global_step % 5 == 0 and writer is not None:     # the scalars of sovits.py:539-565
+                    try:
+                        tb.log_scalars(writer, self.global_step, {
+                            "loss/g/total": float(out.gen_all), "loss/d/total": float(out.disc),
+                            "learning_rate": optim_g.param_groups[0]["lr"],
+                            "grad_norm_d": float(out.grad_sumsq_d) ** 0.5, "grad_norm_g": float(out.grad_sumsq_g) ** 0.5,
+                            "loss/g/fm": float(out.fm), "loss/g/mel": float(out.mel),
+                            "loss/g/kl_ssl": float(out.kl_ssl), "loss/g/kl": float(out.kl)})
+                    except Exception as e:      # summaries never take a training run down
+                        logger.warning(f"tensorboard summary skipped: {e}")
+                        writer = None
                 self.global_step += 1
             if epoch % t["save_every_epoch"] == 0 and rank == 0:
                 tag = "latest" if t["if_save_latest"] else str(self.global_step)

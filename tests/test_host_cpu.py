@@ -254,3 +254,49 @@ dist.destroy_process_group()
     assert codes == [0, 0, 0]
     assert (tmp_path / "o0").read_text() == "1.0 1.0"            # a group of one is left alone
     assert (tmp_path / "o1").read_text() == "2.5 2.5" and (tmp_path / "o2").read_text() == "2.5 2.5"
+
+
+def test_tensorboard_event_files_decode_with_protobuf(tmp_path):
+    """the hand-encoded event records parse with the protobuf runtime against the Event/Summary schema, the TFRecord
+    framing carries the masked CRC-32C of length and payload, and CRC-32C matches its published check value"""
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from easevoice_trainer_amd.utils import tb
+
+    assert tb.crc32c(b"123456789") == 0xE3069283
+    fd = descriptor_pb2.FileDescriptorProto(name="evt_event.proto", package="evt", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    val.field.add(name="simple_value", number=2, type=T.TYPE_FLOAT, label=T.LABEL_OPTIONAL)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=T.TYPE_MESSAGE, type_name=".evt.Value", label=T.LABEL_REPEATED)
+    ev = fd.message_type.add(name="Event")
+    ev.field.add(name="wall_time", number=1, type=T.TYPE_DOUBLE, label=T.LABEL_OPTIONAL)
+    ev.field.add(name="step", number=2, type=T.TYPE_INT64, label=T.LABEL_OPTIONAL)
+    ev.field.add(name="file_version", number=3, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    ev.field.add(name="summary", number=5, type=T.TYPE_MESSAGE, type_name=".evt.Summary", label=T.LABEL_OPTIONAL)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("evt.Event"))
+
+    w = tb.ScalarWriter(str(tmp_path / "run"))
+    w.add_scalars(5, {"loss/g/total": 1.25, "learning_rate": 1e-4})
+    w.add_scalars(300000, {"loss/d/total": -2.5})
+    w.close()
+    blob = open(w.path, "rb").read()
+    assert os.path.basename(w.path).startswith("events.out.tfevents.")
+    events, pos = [], 0
+    while pos < len(blob):
+        (n,) = struct.unpack_from("<Q", blob, pos)
+        assert struct.unpack_from("<I", blob, pos + 8)[0] == tb._masked(blob[pos:pos + 8])
+        rec = blob[pos + 12:pos + 12 + n]
+        assert struct.unpack_from("<I", blob, pos + 12 + n)[0] == tb._masked(rec)
+        e = Event()
+        e.ParseFromString(rec)
+        events.append(e)
+        pos += 16 + n
+    assert [e.step for e in events] == [0, 5, 300000] and events[0].file_version == "brain.Event:2"
+    assert [(v.tag, round(v.simple_value, 6)) for v in events[1].summary.value] == [("loss/g/total", 1.25), ("learning_rate", 1e-4)]
+    assert events[2].summary.value[0].tag == "loss/d/total" and events[2].summary.value[0].simple_value == -2.5
+    assert all(e.wall_time > 1.6e9 for e in events)
