@@ -72,12 +72,18 @@ class GPTTrain:
         torch.save(od, path)
         return path
 
+    @staticmethod
+    def _device(local):
+        """the rank's GPU (the only place the trainer names a device)"""
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        return device
+
     def train(self):
         world, rank, local = init_process_group_from_env()
         cfg, c = self.config, self.config["train"]
         torch.manual_seed(c["seed"])
-        device = torch.device("cuda", local)
-        torch.cuda.set_device(device)
+        device = self._device(local)
         reducer = GradReducer(world) if world > 1 else None
         eng = S1Engine(cfg, device, self.dtype, reducer=reducer)
         if cfg.get("pretrained_s1") and os.path.exists(cfg["pretrained_s1"]):

@@ -74,11 +74,17 @@ class SovitsTrain:
         self._run(rank, world, local)
         return TrainOutput(model_path=self.hps["train"]["output_dir"])
 
+    @staticmethod
+    def _device(local):
+        """the rank's GPU (the only place the trainer names a device)"""
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        return device
+
     def _run(self, rank, world, local):
         hps, t = self.hps, self.hps["train"]
         torch.manual_seed(t["seed"])
-        device = torch.device("cuda", local)
-        torch.cuda.set_device(device)
+        device = self._device(local)
         reducer = GradReducer(world) if world > 1 else None
         eng = S2Engine(hps, device, self.dtype, reducer=reducer)
         optim_g, optim_d = eng.build_optimizers()
