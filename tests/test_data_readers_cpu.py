@@ -319,3 +319,43 @@ def test_semantic_tsv_matches_reference_token_step(feature_dir, gold, tmp_path):
     # and the file is what the s1 reader parses
     tab = D.S1SemanticTable(os.path.join(feature_dir, "2-name2text.txt"), out, symbol_to_id={s: i for i, s in enumerate(gold["symbols"])})
     assert len(tab) >= 1
+
+
+def test_wav_reader_against_stdlib_wave_random_files(tmp_path):
+    """random RIFF layouts (extra chunks of odd and even size before fmt / data, truncated data chunk) decode to the same
+    samples the stdlib `wave` module reads"""
+    import random
+    import struct
+    import wave
+    import numpy as np
+
+    rng = random.Random(13)
+    nrng = np.random.RandomState(13)
+    for case in range(40):
+        ch = rng.choice([1, 1, 1, 2])
+        n = rng.randint(0, 3000)
+        pcm = nrng.randint(-32768, 32768, size=(n, ch)).astype("<i2")
+        body = pcm.tobytes()
+
+        def chunk(cid, payload):
+            return cid + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"")
+
+        parts = []
+        for _ in range(rng.randint(0, 2)):
+            parts.append(chunk(rng.choice([b"LIST", b"bext", b"junk"]), bytes(rng.randint(0, 255) for _ in range(rng.randint(0, 9)))))
+        parts.append(chunk(b"fmt ", struct.pack("<HHIIHH", 1, ch, 32000, 32000 * 2 * ch, 2 * ch, 16)))
+        if rng.random() < 0.5:
+            parts.append(chunk(b"fact", struct.pack("<I", n)))
+        parts.append(chunk(b"data", body))
+        blob = b"".join(parts)
+        p = tmp_path / f"r{case}.wav"
+        p.write_bytes(b"RIFF" + struct.pack("<I", 4 + len(blob)) + b"WAVE" + blob)
+        with wave.open(str(p), "rb") as w:
+            ref = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, ch)
+        want = (ref.astype(np.float32) / np.float32(32768.0)).mean(axis=1, dtype=np.float32) if ch > 1 else \
+            ref[:, 0].astype(np.float32) / np.float32(32768.0)
+        got = D.read_wav_pcm16(str(p), 32000)
+        assert got.dtype == np.float32 and np.array_equal(got, want), case
+        if ch == 1:
+            raw = D.read_wav_pcm16(str(p), 32000, raw=True)
+            assert raw.dtype == np.dtype("<i2") and np.array_equal(raw, ref[:, 0])
