@@ -298,6 +298,8 @@ def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=Tru
         ssl_p[i, :, :ssl.size(2)] = ssl[0]
         ssl_l[i] = ssl.size(2)
         spec_l[i] = frames
+        if wav.dtype == torch.int16 and wav_p.dtype != torch.int16:      # mixed batch (a non-mono file came as float)
+            wav = wav.float() * (1.0 / 32768.0)
         wav_p[i, :, :wav.size(1)] = wav
         wav_l[i] = wav.size(1)
         text_p[i, :text.size(0)] = text

@@ -359,3 +359,15 @@ def test_wav_reader_against_stdlib_wave_random_files(tmp_path):
         if ch == 1:
             raw = D.read_wav_pcm16(str(p), 32000, raw=True)
             assert raw.dtype == np.dtype("<i2") and np.array_equal(raw, ref[:, 0])
+
+
+def test_collate_mixed_sample_dtypes():
+    """a batch mixing raw int16 items with a float item (non-mono file) is scaled on the host, not copied as integers"""
+    a = (torch.zeros(1, 8, 40, dtype=torch.float16), torch.tensor([[16384, -32768, 0, 1] * 6400], dtype=torch.int16),
+         torch.tensor([1.0, 2.0]), 40, True)
+    b = (torch.zeros(1, 8, 35, dtype=torch.float16), torch.full((1, 22400), 0.25), torch.tensor([3.0]), 35, True)
+    (ssl, _, shape, _, wav, wav_l, _, _), order = D.collate_s2([a, b], 5, with_spec=False)
+    assert wav.dtype == torch.float32 and ssl.dtype == torch.float16 and order == [0, 1]
+    assert wav[0, 0, :4].tolist() == [0.5, -1.0, 0.0, 1.0 / 32768.0] and float(wav[1, 0, 0]) == 0.25
+    (_, _, _, _, wav2, _, _, _), _ = D.collate_s2([a, a], 5, with_spec=False)
+    assert wav2.dtype == torch.int16
