@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime loads: easevoice_trainer_amd/__init__.py
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

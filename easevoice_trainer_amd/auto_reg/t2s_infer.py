@@ -214,7 +214,9 @@ class T2SInfer:
         S._gemv(W.wpred, None, S.xb, None, None, None, 0.0, None, S.logits)
         S._sample_embed_advance(W, sp, noise, pe, 0)
         # ---- token steps: one graph replay each ----
-        use_graph = os.environ.get("EVT_DECODE_GRAPH", "1") != "0"
+        from .. import hip_graphs_safe
+
+        use_graph = os.environ.get("EVT_DECODE_GRAPH", "1") != "0" and hip_graphs_safe()
         gkey = (bytes(sp), None if noise is None else noise.data_ptr(), pe.data_ptr(), id(W), padded, x_len)
         if use_graph and S.graph_key != gkey:
             # warm-up launches outside the capture, on throw-away counters: restore the state afterwards

@@ -174,9 +174,17 @@ class S2Engine:
         """Capture the three phases per distinct batch shape after `warmup_steps` eager steps of that shape and replay
         them afterwards.  Every captured shape keeps its own activation pool in HBM (a few GB each; 288 GB holds the
         bucketed shapes of a run), `max_shapes` bounds it -- further shapes run eagerly."""
-        self.graphs_enabled = True
+        from .. import hip_graphs_safe
+
         self._graph_warmup, self._graph_max = warmup_steps, max_shapes
         self._graph_cache = {}
+        if not hip_graphs_safe():
+            import warnings
+
+            warnings.warn("HIP-graph replay of the s2 step is off: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in the "
+                          "environment before torch was imported (see easevoice_trainer_amd/__init__.py); launching eagerly")
+            return
+        self.graphs_enabled = True
 
     def _step_graphed(self, inputs) -> S2Losses:
         key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in inputs)
@@ -238,4 +246,6 @@ class S2Engine:
         # capture records the optimiser launches without running them: undo the python-side counters it bumped
         self.optim_d.step_count -= 1
         self.optim_g.step_count -= 1
-        ent.update(graphs=tuple(graphs), static=static, st=st, result=self._result(st))
+        # only detached results are kept: a live autograd graph would pin its AccumulateGrad nodes (created on the capture
+        # stream) and later eager steps of other shapes would run their gradient accumulation on that stream
+        ent.update(graphs=tuple(graphs), static=static, result=self._result(st))

@@ -1,5 +1,5 @@
 """GPU: the feature-directory readers with the HIP STFT in the loop, against the golden outputs of the
-reference's readers, and both trainers fed from a feature directory instead of synthetic batches."""
+reference's readers.  (The trainer loops over such a directory: tests/test_zz_readers_train_gpu.py.)"""
 import io
 import json
 import os
@@ -76,60 +76,3 @@ def test_reader_batches_match_reference_collate(gpu, feature_dir, gold):
         if F.BROKEN in g["names"]:
             row = [i for i in range(4) if int(batch[5][i]) == 100 * F.HOP and not batch[4][i].any()]
             assert len(row) == 1 and not batch[2][row[0]].any()
-
-
-@pytest.fixture(scope="module")
-def train_dir(gold, tmp_path_factory):
-    """the feature directory without a_007: its hubert features are longer than its spectrogram, which the readers
-    handle like the reference does (one more replicate pad) but which no model step accepts, there or here"""
-    root = str(tmp_path_factory.mktemp("exp_train"))
-    F.build_feature_dir(root, gold["symbols"])
-    os.remove(os.path.join(root, "5-wav32k", "a_007.wav"))
-    with open(os.path.join(root, "symbols.json"), "w") as f:
-        json.dump(gold["symbols"], f)
-    return root
-
-
-def _fake_pretrained_g(path):
-    g = torch.Generator().manual_seed(3)
-    pre = "quantizer.vq.layers.0._codebook."
-    torch.save({"weight": {pre + "inited": torch.ones(1), pre + "embed": torch.randn(1024, 768, generator=g),
-                           pre + "embed_avg": torch.randn(1024, 768, generator=g), pre + "cluster_size": torch.ones(1024)}},
-               path)
-
-
-def test_sovits_train_from_feature_dir(gpu, train_dir, tmp_path, monkeypatch):
-    from easevoice_trainer_amd.train.sovits import SovitsTrain, SovitsTrainParams
-
-    monkeypatch.delenv("EVT_SYNTHETIC_STEPS", raising=False)
-    _fake_pretrained_g(str(tmp_path / "s2G.pth"))
-    p = SovitsTrainParams(batch_size=4, total_epochs=1, save_every_epoch=1, output_model_name="fd", project_dir=str(tmp_path),
-                          train_input_dir=train_dir, pretrained_s2G=str(tmp_path / "s2G.pth"))
-    buf = io.StringIO()
-    with redirect_stdout(buf):
-        t = SovitsTrain(p)
-        out = t.train()
-    steps = len(D.S2BucketSampler(D.S2FeatureDir(train_dir, CFG).lengths, 4))
-    assert steps == 20 and t.global_step == steps
-    assert os.path.isfile(os.path.join(out.model_path, f"fd_e1_s{steps}.pth"))
-    lines = [l for l in buf.getvalue().splitlines() if l.startswith("loss-of-easevoice")]
-    assert len(lines) == 2
-    for l in lines:
-        v = json.loads(l.split(" ", 1)[1])
-        assert v["loss"] == v["loss"] and abs(v["loss"]) < 1e4
-
-
-def test_gpt_train_from_feature_dir(gpu, feature_dir, tmp_path, monkeypatch):
-    from easevoice_trainer_amd.train.gpt import GPTTrain, GPTTrainParams
-
-    monkeypatch.delenv("EVT_SYNTHETIC_STEPS", raising=False)
-    p = GPTTrainParams(batch_size=8, total_epochs=1, save_every_epoch=1, output_model_name="gd", project_dir=str(tmp_path),
-                       train_input_dir=feature_dir)
-    buf = io.StringIO()
-    with redirect_stdout(buf):
-        out = GPTTrain(p).train()
-    lines = [l for l in buf.getvalue().splitlines() if l.startswith("loss-of-easevoice")]
-    assert len(lines) == 12                                   # 96 items / batch 8
-    losses = [json.loads(l.split(" ", 1)[1])["loss"] for l in lines]
-    assert all(v == v and v > 0 for v in losses)
-    assert os.path.isfile(os.path.join(out.model_path, "gd-e1.ckpt"))

@@ -70,3 +70,86 @@ def test_graph_replay_matches_eager(gpu):
     for a, b in zip(final["eager"][:2], final["graph"][:2]):
         d = (a - b).abs().max().item()
         assert d < 5e-3, d     # six AdamW updates of lr 1e-4: identical up to sign flips of near-zero gradients
+
+
+def test_graph_replay_ragged_batches_match_eager(gpu):
+    """Round-1 regression (driver suite red): replaying the captured step on RAGGED batches at T = 172 returned stale
+    multi-block reductions from the second replay on (KL sum, bias gradients -> NaN weights).  Root cause: the HIP
+    runtime's graph packet capture (easevoice_trainer_amd/__init__.py).  Eight steps with a different ragged batch each
+    (injected eps / slice ids, dropout off, so eager and graph runs are comparable): every term finite and equal to the
+    eager run's."""
+    from easevoice_trainer_amd import hip_graphs_safe
+    from easevoice_trainer_amd.module.mel_processing import spectrogram_torch
+
+    assert hip_graphs_safe(), "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be set before torch is imported (tests/conftest.py)"
+    B, T, Tt = 4, 172, 30
+    lens_tab = [(170, 100, 100, 47), (170, 102, 102, 40), (170, 65, 47, 40), (150, 170, 99, 64)]
+    tl_tab = [(30, 1, 1, 8), (30, 18, 18, 7), (30, 11, 8, 7), (29, 30, 5, 9)]
+    batches = []
+    for it in range(8):
+        g = torch.Generator().manual_seed(100 + it)
+        lens, tl = torch.tensor(lens_tab[it % 4]), torch.tensor(tl_tab[it % 4])
+        wav = (torch.rand(B, 1, T * 640, generator=g) - 0.5) * 0.4
+        ssl = torch.randn(B, 768, T, generator=g)
+        text = torch.randint(0, 732, (B, Tt), generator=g)
+        for b in range(B):
+            wav[b, :, lens[b] * 640:] = 0
+            ssl[b, :, lens[b]:] = 0
+            text[b, tl[b]:] = 0
+        spec = torch.zeros(B, 1025, T, device=gpu)
+        for b in range(B):
+            s = spectrogram_torch(wav[b, :, :lens[b] * 640].to(gpu), 2048, 32000, 640, 2048)
+            spec[b, :, :s.size(2)] = s[0]
+        eps = torch.randn(B, 192, T, generator=g).to(gpu)
+        ids = torch.tensor([min(int(l) - 32, 3 + 7 * j) for j, l in enumerate(lens)], device=gpu)
+        batches.append(((ssl.to(gpu), spec, lens.to(gpu), wav.to(gpu), text.to(gpu), tl.to(gpu)), eps, ids))
+    hist = {}
+    for mode in ("eager", "graph"):
+        eng, _ = _engine(gpu, 1234)
+        if mode == "graph":
+            eng.enable_graphs(warmup_steps=2)
+        rows = []
+        for a, eps, ids in batches:
+            out = eng.step(*a, eps=eps, ids_slice=ids)
+            rows.append([float(out.disc), float(out.gen), float(out.fm), float(out.mel), float(out.kl),
+                         float(out.grad_sumsq_d), float(out.grad_sumsq_g)])
+        hist[mode] = torch.tensor(rows)
+        assert all(bool(torch.isfinite(p).all()) for p in eng.net_g.parameters()), mode
+        if mode == "graph":
+            assert any(e["graphs"] is not None for e in eng._graph_cache.values()), "no graph was captured"
+    assert torch.isfinite(hist["graph"]).all(), hist["graph"]
+    rel = ((hist["graph"] - hist["eager"]).abs() / (hist["eager"].abs() + 1e-6)).max(dim=0).values
+    assert (rel[:5] < 3e-2).all() and (rel[5:] < 1.5e-1).all(), (rel, hist["eager"], hist["graph"])
+
+
+def test_torch_reductions_survive_large_graph_replay(gpu):
+    """Canary for the HIP runtime switch: 600 multi-block ATen reductions in ONE captured graph (a few thousand nodes,
+    like the s2 step), replayed with changing inputs.  With the runtime's default packet capture 134 of them return
+    stale values from the second replay on."""
+    x = torch.randn(4, 172, 192, device=gpu)
+
+    def body(outs):
+        xt = x.transpose(1, 2)
+        for i in range(600):
+            km = xt * (1.0 + i)
+            outs.append(torch.sum(km))
+            torch.empty(1000 + 37 * i, device=gpu).fill_(float(i))      # churn the small-block pool between reductions
+            w = torch.randn(576, 192, device=gpu)
+            outs.append(torch.nn.functional.linear(x.reshape(-1, 192), w).sum(0).sum())
+        return outs
+
+    body([])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    outs = []
+    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        body(outs)
+    for r in range(3):
+        x.copy_(torch.randn(4, 172, 192, device=gpu) * (r + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        total = float(x.sum())
+        got = torch.stack(outs[0::2]).cpu()
+        ref = torch.tensor([total * (1.0 + i) for i in range(600)])
+        bad = ((got - ref).abs() > 1e-3 * ref.abs() + 0.5).sum().item()
+        assert bad == 0, f"replay {r}: {bad} of 600 reductions returned stale values"
