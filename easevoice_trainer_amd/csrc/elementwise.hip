@@ -337,8 +337,11 @@ inline int grid_for(long n, int cap = 8192) {
 
 #include <stdarg.h>
 #include <stdio.h>
+// profiling aid (evt.h: evt_debug_kernel_tags): nothing is recorded unless a profiler switched it on
+static bool g_tags_on = false;
 static thread_local char g_last_tag[128] = "";
 extern "C" void evt_set_last_tag(const char* fmt, ...) {
+  if (!g_tags_on) return;
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_last_tag, sizeof(g_last_tag), fmt, ap);
@@ -348,6 +351,7 @@ extern "C" void evt_set_last_tag(const char* fmt, ...) {
 extern "C" {
 
 const char* evt_last_kernel_tag(void) { return g_last_tag; }
+void evt_debug_kernel_tags(int32_t enable) { g_tags_on = enable != 0; }
 
 const char* evt_version(void) { return "evt-hip 0.1 (gfx950)"; }
 

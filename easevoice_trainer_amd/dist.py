@@ -77,11 +77,19 @@ class GradReducer:
         return t
 
 
-def init_process_group_from_env(backend=None):
-    """one process per GPU; rendezvous over 127.0.0.1 (single node), RCCL when a GPU is present"""
+def init_process_group_from_env(backend=None, gpu_ids=None):
+    """one process per GPU; rendezvous over 127.0.0.1 (single node), RCCL when a GPU is present.
+    Returns (world, rank, local device index).  A single-process run without a launcher takes its device from
+    `gpu_ids` (the reference exports CUDA_VISIBLE_DEVICES=gpu_ids, src/train/sovits.py:168: gpu_ids="2" trains on
+    card 2, not on card 0)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 or dist.is_initialized():
-        return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        if "LOCAL_RANK" in os.environ:
+            local = int(os.environ["LOCAL_RANK"])
+        else:
+            ids = parse_gpu_ids(gpu_ids) if gpu_ids is not None else []
+            local = ids[0] if ids else 0
+        return world, int(os.environ.get("RANK", "0")), local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

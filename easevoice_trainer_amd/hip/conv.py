@@ -186,7 +186,15 @@ class WeightBank:
                 "evt_wn_grad_multi")
 
 
-TRACE = None   # bench.py's roofline leg sets this to a list: (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch
+TRACE = None   # profiling only (set_trace): (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch
+
+
+def set_trace(rec):
+    """profiling aid of bench.py's roofline leg: a list switches per-launch records (and the library's kernel-name tags)
+    on, None switches both off (the product state)"""
+    global TRACE
+    TRACE = rec
+    L.lib().evt_debug_kernel_tags(1 if rec is not None else 0)
 
 
 def _t0():
@@ -205,7 +213,6 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
     sz = 2 if m._slot.bank.dtype == torch.bfloat16 else 4
     act = nseq * (lin * m.cin + m.lout(lin) * m.cout) + extra_elems
     wbytes = m.v.numel() * (4 if kind == "bwd_weight" else sz)
-    L.lib().evt_last_kernel_tag.restype = C.c_char_p
     shape = (f"{'T' if m.transposed else ''}{m.cin}>{m.cout} k{m.k} s{m.stride} d{m.dil} g{m.groups} "
              f"n{nseq} L{lin}")
     TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape, m))

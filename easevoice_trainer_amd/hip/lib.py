@@ -52,6 +52,11 @@ class Seg(C.Structure):
                 ("scale", C.c_float), ("pad_", C.c_int32)]
 
 
+class KlParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("time_inner", C.c_int32),
+                ("dt_z_p", C.c_int32), ("dt_logs_q", C.c_int32), ("dt_m_p", C.c_int32), ("dt_logs_p", C.c_int32)]
+
+
 class AdamWSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
@@ -104,8 +109,10 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.evt_version.restype = C.c_char_p
         _lib.evt_conv1d_lout.restype = C.c_int32
-        if hasattr(_lib, "evt_mel_workspace_floats"):
-            _lib.evt_mel_workspace_floats.restype = C.c_int64
+        _lib.evt_mel_workspace_floats.restype = C.c_int64
+        _lib.evt_workspace_bytes.restype = C.c_int64
+        _lib.evt_last_kernel_tag.restype = C.c_char_p
+        _lib.evt_debug_kernel_tags.restype = None
     return _lib
 
 

@@ -82,9 +82,46 @@ def generator_loss(disc_outputs):
     return _SegLossFn.apply(1, 1.0, [1.0 / t.numel() for t in disc_outputs], len(disc_outputs), *disc_outputs)
 
 
-def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
-    """losses.py:46-61 (layout-agnostic: any matching shapes, mask broadcastable)."""
-    z_p, logs_q, m_p, logs_p, z_mask = z_p.float(), logs_q.float(), m_p.float(), logs_p.float(), z_mask.float()
-    kl = logs_p - logs_q - 0.5
-    kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
-    return torch.sum(kl * z_mask) / torch.sum(z_mask)
+class _MaskedKLFn(torch.autograd.Function):
+    """sum(kl * z_mask) / sum(z_mask), one streaming HIP pass each way (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, z_p, logs_q, m_p, logs_p, lens, time_inner):
+        ts = (z_p, logs_q, m_p, logs_p)
+        if any(t.shape != z_p.shape or not t.is_contiguous() for t in ts):
+            raise L.EvtError("masked_kl: four contiguous tensors of one shape expected")
+        B, d1, d2 = z_p.shape
+        T, Cc = (d2, d1) if time_inner else (d1, d2)
+        prm = L.KlParams(B, T, Cc, int(time_inner), *[L.dt_of(t) for t in ts])
+        out2 = torch.zeros(2, dtype=torch.float32, device=z_p.device)
+        L.check(L.lib().evt_masked_kl_fwd(C.byref(prm), *[L.ptr(t) for t in ts], L.ptr(lens), L.ptr(out2),
+                                          L.stream_ptr()), "evt_masked_kl_fwd")
+        ctx.save_for_backward(z_p, logs_q, m_p, logs_p, lens, out2)
+        ctx.prm = prm
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z_p, logs_q, m_p, logs_p, lens, out2 = ctx.saved_tensors
+        ts = (z_p, logs_q, m_p, logs_p)
+        grads = [torch.empty_like(t) if ctx.needs_input_grad[i] else None for i, t in enumerate(ts)]
+        dl = dloss.reshape(1).float().contiguous()
+        L.check(L.lib().evt_masked_kl_bwd(C.byref(ctx.prm), *[L.ptr(t) for t in ts], L.ptr(lens), L.ptr(dl),
+                                          L.ptr(out2[1:]), *[L.ptr(g) for g in grads], L.stream_ptr()),
+                "evt_masked_kl_bwd")
+        return (*grads, None, None)
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
+    """losses.py:46-61.  The four tensors share one layout, either [B, C, T] views of channels-last storage (what
+    SynthesizerTrn returns), contiguous [B, T, C], or contiguous [B, C, T]; z_mask [B, 1, T] is the sequence mask of
+    `lens` (passed directly by the engine; recovered as the per-row mask sums otherwise)."""
+    ts = [z_p, logs_q, m_p, logs_p]
+    if lens is None:
+        lens = z_mask.reshape(z_mask.size(0), -1).sum(1)
+    lens = lens.to(torch.int32).contiguous()
+    if all((not t.is_contiguous()) and t.transpose(1, 2).is_contiguous() for t in ts):
+        return _MaskedKLFn.apply(*[t.transpose(1, 2) for t in ts], lens, False)
+    if z_mask.size(-1) == z_p.size(-1) and z_mask.size(1) == 1:
+        return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, True)
+    return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, False)

@@ -192,11 +192,13 @@ class ModelRuntime:
 
     def prepare(self, force: bool = False):
         """fold the prepared conv weight images -- only when the parameters changed since the last fold: an optimiser
-        step of this arena (FlatAdamW bumps `arena.updates`) or an in-place write that torch versions (load_state_dict,
-        broadcast).  The discriminator is refolded right after its update for the generator step, so the fold at the
+        step of this arena (FlatAdamW bumps `arena.updates`) or an in-place write that torch versions, through the arena
+        (broadcast) or through a parameter (load_state_dict, p.copy_).  The discriminator is refolded right after its update for the generator step, so the fold at the
         top of the next step would rebuild identical images."""
         a = self.arena
-        stamp = (a.updates, a.param._version)
+        # each Parameter carries its own version counter (p.data = view): load_state_dict / p.copy_ bump the parameter's,
+        # not the arena's, so both are in the stamp
+        stamp = (a.updates, a.param._version, sum(p._version for p in self.model.parameters()))
         if force or stamp != self._fold_stamp:
             self.bank.fold()
             self._fold_stamp = stamp

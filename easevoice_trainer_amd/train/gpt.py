@@ -12,7 +12,7 @@ import torch
 import yaml
 
 from ..dist import GradReducer, init_process_group_from_env
-from ..utils import tb
+from ..utils import ckpt, tb
 from ..utils.connector import MultiProcessOutputConnector
 from .data import SyntheticS1Batches, open_source
 from .helper import TrainOutput, default_pretrained, get_gpt_train_dir, repo_root, train_logs_path
@@ -80,7 +80,7 @@ class GPTTrain:
         return device
 
     def train(self):
-        world, rank, local = init_process_group_from_env()
+        world, rank, local = init_process_group_from_env(gpu_ids=self.params.gpu_ids)
         cfg, c = self.config, self.config["train"]
         torch.manual_seed(c["seed"])
         device = self._device(local)
@@ -124,17 +124,21 @@ class GPTTrain:
                     tb.log_scalars(writer, step_no, {"total_loss_step": lv, "lr": lr, "top_3_acc_step": av})
                 step_no += 1
             if (epoch + 1) % c["save_every_n_epoch"] == 0 and rank == 0:
-                if c["if_save_latest"]:
-                    for name in os.listdir(self.train_ckpts_output):
+                # save first, then drop the files that were there before (src/train/gpt.py:66-78): a failed write leaves
+                # the previous resume point in place
+                before = os.listdir(self.train_ckpts_output) if c["if_save_latest"] else []
+                sd = OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in eng.model.state_dict().items())
+                opt_sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in eng.optimizer.state_dict().items()}
+                new_name = f"epoch={epoch}-step={self.global_step}.ckpt"
+                ckpt.save_with_torch({"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
+                                      "optimizer_states": [opt_sd], "hyper_parameters": {"config": cfg}},
+                                     os.path.join(self.train_ckpts_output, new_name))
+                for name in before:
+                    if name != new_name:
                         try:
                             os.remove(os.path.join(self.train_ckpts_output, name))
                         except OSError:
                             pass
-                sd = OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in eng.model.state_dict().items())
-                opt_sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in eng.optimizer.state_dict().items()}
-                torch.save({"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
-                            "optimizer_states": [opt_sd], "hyper_parameters": {"config": cfg}},
-                           os.path.join(self.train_ckpts_output, f"epoch={epoch}-step={self.global_step}.ckpt"))
                 if c["if_save_every_weights"]:
                     self._export(eng.model, epoch + 1)
         self.engine = eng

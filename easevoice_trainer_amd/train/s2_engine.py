@@ -114,7 +114,7 @@ class S2Engine:
     def _phase_b(self, st):
         t = self.hps["train"]
         net_d, rt_g, rt_d = self.net_d, self.rt_g, self.rt_d
-        st.gss_d = rt_d.grad_sumsq().clone()
+        st.gss_d = rt_d.grad_sumsq() * (st.inv_world * st.inv_world)   # norm of the AVERAGED gradient, as DDP logs it
         if st.hook_after_d is not None:
             st.hook_after_d()
         if st.do_opt:
@@ -127,7 +127,7 @@ class S2Engine:
         st.y_d_hat_g, fmap_g = net_d.forward_single(st.y_hat)
         z, z_p, m_p, logs_p, m_q, logs_q = st.lat
         st.loss_mel = F.l1_loss(st.y_mel, st.y_hat_mel) * t["c_mel"]
-        st.loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, st.z_mask) * t["c_kl"]
+        st.loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, st.z_mask, lens=st.spec_lengths) * t["c_kl"]
         st.loss_fm = feature_loss(fmap_r, fmap_g)
         st.loss_gen = generator_loss(st.y_d_hat_g)
         st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
@@ -136,7 +136,7 @@ class S2Engine:
         rt_g.finish_grads()
 
     def _phase_c(self, st):
-        st.gss_g = self.rt_g.grad_sumsq().clone()
+        st.gss_g = self.rt_g.grad_sumsq() * (st.inv_world * st.inv_world)
         if st.do_opt:
             self.optim_g.step(grad_scale=st.inv_world)
 

@@ -70,7 +70,7 @@ class SovitsTrain:
         return path
 
     def train(self):
-        world, rank, local = init_process_group_from_env()
+        world, rank, local = init_process_group_from_env(gpu_ids=self.params.gpu_ids)
         self._run(rank, world, local)
         return TrainOutput(model_path=self.hps["train"]["output_dir"])
 

@@ -35,8 +35,26 @@ extern "C" {
 #define EVT_IMPL_IGEMM 2 /* LDS-tiled implicit-GEMM on MFMA */
 
 const char* evt_version(void);
-/* name of the kernel instantiation launched by the last conv entry point on this host thread (profiling aid) */
+/* Profiling aid, OUTSIDE the contract above and off by default: after evt_debug_kernel_tags(1) every dispatcher
+ * records the name of the kernel instantiation it launched in a per-thread buffer that evt_last_kernel_tag() returns
+ * (bench.py's roofline leg groups its timings by these names, the same names rocprofv3 prints).  With tags off (the
+ * product path) nothing is recorded and the library keeps no mutable state. */
+void evt_debug_kernel_tags(int32_t enable);
 const char* evt_last_kernel_tag(void);
+
+/* Scratch memory the caller must provide, in bytes, for the ops that take a workspace pointer; -1 for an unknown op or
+ * a wrong dims count.  The library never allocates.
+ *   EVT_WS_MEL          dims = {nseq, wav_len, n_fft, hop, n_mels}   ws of evt_mel_fwd / evt_mel_bwd
+ *   EVT_WS_ATTN_BWD     dims = {B, H, L}                             delta_ws of evt_attn_prefixlm_bwd
+ *   EVT_WS_RELATTN_BWD  dims = {B, H, T}                             delta_ws of evt_relattn_bwd
+ *   EVT_WS_MASKED_KL    dims = {}                                    out2 of evt_masked_kl_fwd (sum, live frames)
+ *   EVT_WS_NONE         every other entry point: 0 */
+#define EVT_WS_NONE 0
+#define EVT_WS_MEL 1
+#define EVT_WS_ATTN_BWD 2
+#define EVT_WS_RELATTN_BWD 3
+#define EVT_WS_MASKED_KL 4
+int64_t evt_workspace_bytes(int32_t op, const int64_t* dims, int32_t ndims);
 
 /* ---------------------------------------------------------------------------------------
  * Conv1d / ConvTranspose1d family.
@@ -173,6 +191,23 @@ int evt_l1_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, const flo
 int evt_lsgan_multi_fwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, float* out, void* stream);
 int evt_lsgan_multi_bwd(int32_t dtype, const evt_seg* segs, int32_t nseg, float target, const float* dloss,
                         void* stream);
+
+/* Masked KL term of the generator loss, src/easevoice/module/losses.py:46-61:
+ *   kl = logs_p - logs_q - 0.5 + 0.5 (z_p - m_p)^2 exp(-2 logs_p);  loss = sum(kl * z_mask) / sum(z_mask)
+ * with z_mask[b][t] = (t < lens[b]) (lens NULL = all live).  The four tensors share one layout: [B][T][C] (time_inner
+ * = 0, channels-last) or [B][C][T] (time_inner = 1, the reference's); each has its own dtype.
+ * fwd: out2[0] += sum(kl * z_mask) (caller zeroes it), out2[1] = sum(z_mask) = live frames; loss = out2[0] / out2[1].
+ * bwd: gradients of loss * dloss[0] w.r.t. the four inputs (dtype of the input; any may be NULL), masked positions
+ * get zeros; `count` points at out2[1]. */
+typedef struct evt_kl_params {
+  int32_t B, T, C, time_inner;
+  int32_t dt_z_p, dt_logs_q, dt_m_p, dt_logs_p;
+} evt_kl_params;
+int evt_masked_kl_fwd(const evt_kl_params* p, const void* z_p, const void* logs_q, const void* m_p, const void* logs_p,
+                      const int32_t* lens, float* out2, void* stream);
+int evt_masked_kl_bwd(const evt_kl_params* p, const void* z_p, const void* logs_q, const void* m_p, const void* logs_p,
+                      const int32_t* lens, const float* dloss, const float* count, void* dz_p, void* dlogs_q, void* dm_p,
+                      void* dlogs_p, void* stream);
 
 /* Multi-segment AdamW over a flat fp32 arena (torch.optim.AdamW at sovits.py:294-319: decoupled
  * weight decay, bias correction, eps outside the sqrt).  seg table is a DEVICE array (<= 64 segments);

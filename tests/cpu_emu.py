@@ -109,6 +109,13 @@ def cpu_emulation():
     def spectrogram_torch(y, n_fft, sr, hop, win, center=False):
         return _stft_mag(y.float(), n_fft, hop)
 
+    def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
+        z_p, logs_q, m_p, logs_p, z_mask = z_p.float(), logs_q.float(), m_p.float(), logs_p.float(), z_mask.float()
+        kl = logs_p - logs_q - 0.5 + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+        return torch.sum(kl * z_mask) / torch.sum(z_mask)
+
+    saved_kl = (PL.kl_loss, PE.kl_loss)
+    PL.kl_loss = PE.kl_loss = kl_loss
     HC.EvtConv1d.forward = _conv_forward
     PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn = res_unit, _Add3, _Gated
     PL.feature_loss, PL.discriminator_loss, PL.generator_loss = feature_loss, discriminator_loss, generator_loss
@@ -119,6 +126,7 @@ def cpu_emulation():
         (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
          PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch) = saved
         PA.res_drop_ln, PE.bump_rng = saved_enc
+        PL.kl_loss, PE.kl_loss = saved_kl
         PMod.wn_residual, PMod.wn_residual_last = saved_wn
 
 

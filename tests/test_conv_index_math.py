@@ -141,3 +141,21 @@ def test_library_exports_header_symbols():
     lib = L.lib()
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, f"declared in evt.h but not exported: {missing}"
+
+
+def test_workspace_bytes_query():
+    """evt_workspace_bytes: host-only arithmetic, no launch"""
+    import ctypes as C
+
+    lib = L.lib()
+
+    def ws(op, *dims):
+        arr = (C.c_int64 * max(len(dims), 1))(*dims)
+        return lib.evt_workspace_bytes(op, arr, len(dims))
+
+    assert ws(0) == 0                                               # EVT_WS_NONE
+    assert ws(1, 16, 20480, 2048, 640, 128) == 4 * lib.evt_mel_workspace_floats(16, 20480, 2048, 640, 128) > 0
+    assert ws(2, 32, 16, 1024) == 4 * 32 * 16 * 1024                # attention backward delta
+    assert ws(3, 16, 2, 200) == 4 * 16 * 2 * 200                    # relative attention backward delta
+    assert ws(4) == 8                                               # masked KL: (sum, live frames)
+    assert ws(1, 16, 20480) == -1 and ws(99) == -1                  # wrong arity / unknown op

@@ -300,3 +300,17 @@ def test_tensorboard_event_files_decode_with_protobuf(tmp_path):
     assert [(v.tag, round(v.simple_value, 6)) for v in events[1].summary.value] == [("loss/g/total", 1.25), ("learning_rate", 1e-4)]
     assert events[2].summary.value[0].tag == "loss/d/total" and events[2].summary.value[0].simple_value == -2.5
     assert all(e.wall_time > 1.6e9 for e in events)
+
+
+def test_single_gpu_id_selects_that_device(monkeypatch):
+    """gpu_ids="2" without a launcher trains on card 2 (the reference exports CUDA_VISIBLE_DEVICES=gpu_ids,
+    src/train/sovits.py:168); under a launcher LOCAL_RANK wins"""
+    from easevoice_trainer_amd.dist import init_process_group_from_env
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert init_process_group_from_env(gpu_ids="2") == (1, 0, 2)
+    assert init_process_group_from_env(gpu_ids="1-3") == (1, 0, 1)
+    assert init_process_group_from_env() == (1, 0, 0)
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert init_process_group_from_env(gpu_ids="2") == (1, 0, 5)

@@ -25,7 +25,7 @@ MFMA_F32_PEAK_TF = 157.3
 def roofline_s2(args, eng, step_fn, n_steps=2):
     from easevoice_trainer_amd.hip import conv as HC
 
-    HC.TRACE = []
+    HC.set_trace([])
     graphs, eng.graphs_enabled = eng.graphs_enabled, False   # per-launch events need the eager path
     try:
         for _ in range(n_steps):
@@ -33,7 +33,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         torch.cuda.synchronize()
         rec = HC.TRACE
     finally:
-        HC.TRACE = None
+        HC.set_trace(None)
         eng.graphs_enabled = graphs
     agg = {}
     dec_mods = {id(m) for m in eng.net_g.dec.modules()}

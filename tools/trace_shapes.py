@@ -28,12 +28,13 @@ def main():
 
     world, rank, local = bench.init_dist(1)
     res, eng, step = bench.run_s2(args, world, rank, local)
-    HC.TRACE = []
+    HC.set_trace([])
     n = 2
     for _ in range(n):
         step()
     torch.cuda.synchronize()
-    rec, HC.TRACE = HC.TRACE, None
+    rec = HC.TRACE
+    HC.set_trace(None)
     agg = {}
     for tag, kind, flops, nbytes, e0, e1, shape, _m in rec:
         a = agg.setdefault((tag, kind, shape), [0.0, 0, 0.0, 0.0])
