@@ -44,7 +44,7 @@ def grad_stats(module):
     return out
 
 
-def make_s2(B=2, T=100, t_text=40, tag="c1"):
+def make_s2(B=2, T=100, t_text=40, tag="c1", hook=None, hook_d=None):
     from src.easevoice.module import commons, models
     from src.easevoice.module.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
     from src.easevoice.module.mel_processing import mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch
@@ -82,6 +82,8 @@ def make_s2(B=2, T=100, t_text=40, tag="c1"):
     net_d.zero_grad()
     loss_disc.backward()
     d_grads = grad_stats(net_d)
+    if hook_d is not None:    # round-2 fixtures: the discriminator's gradients as its optimiser sees them (sovits.py:504-507)
+        hook_d(net_d)
     d_slices = {n: p.grad.flatten()[:64].clone() for n, p in net_d.named_parameters()
                 if n in ("discriminators.0.convs.1.weight_v", "discriminators.1.convs.3.weight_g",
                          "discriminators.5.convs.0.weight_v", "discriminators.3.conv_post.bias",
@@ -121,6 +123,8 @@ def make_s2(B=2, T=100, t_text=40, tag="c1"):
         g_grad_slices=g_slices,
         fmap_shapes=[[tuple(t.shape) for t in f] for f in fmap_g],
     )
+    if hook is not None:      # round-2 fixtures (make_golden_r2.py) extend the same run; s2_c1.pt itself is unchanged
+        hook(net_g, net_d, out)
     if tag == "_noise":
         return out
     # fp32 noise floor of the REFERENCE itself: same computation on a different CPU conv backend / thread count

@@ -1,7 +1,6 @@
-"""GPU parity of the fused relative-position attention (csrc/relattn.hip) against the torch formulation of
-src/easevoice/module/attentions.py:214-292 evaluated in fp32 on bf16-rounded inputs."""
-import math
-
+"""GPU parity of the fused relative-position attention (csrc/relattn.hip) against the ORACLE's restatement of
+src/easevoice/module/attentions.py:243-292 (oracle/s2_step.py::mha, pinned to the reference's own outputs by
+tests/test_oracle_cpu.py), evaluated in fp32 on the CPU on bf16-rounded inputs."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -10,26 +9,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _reference(qkv, ek, ev, lens, H, w):
-    """the product's torch path (module/attentions.py) on fp32 tensors; rows >= len zeroed like the kernel"""
-    from easevoice_trainer_amd.module.attentions import MultiHeadAttention as M
+    """oracle/s2_step.py::mha (the pinned CPU restatement of MultiHeadAttention.attention, attentions.py:243-292) on
+    the packed projection: identity / selector 1x1 projections expose the attention core; evaluated in fp32 on the CPU
+    on the bf16-rounded inputs.  qkv [B, T, 3C] -> out [B, T, C] with rows >= len zeroed like the kernel writes them."""
+    from oracle.s2_step import SD, mha
 
     B, T, C3 = qkv.shape
     C = C3 // 3
-    d = C // H
-    q, k, v = [t.reshape(B, T, H, d).transpose(1, 2) for t in qkv.split(C, dim=-1)]
-    live = (torch.arange(T, device=qkv.device)[None, :] < lens[:, None]).float()
-    mask = (live[:, None, :, None] * live[:, None, None, :])
-    helper = M.__new__(M)
-    helper.window_size = w
-    qs = q / math.sqrt(d)
-    scores = qs @ k.transpose(-2, -1)
-    qe = qs @ ek.unsqueeze(0).transpose(-2, -1)
-    scores = scores + M._rel_to_abs(helper._band_to_full(qe, T))
-    scores = scores.masked_fill(mask == 0, -1e4)
-    p = F.softmax(scores, dim=-1)
-    out = p @ v + helper._full_to_band(M._abs_to_rel(p), T) @ ev.unsqueeze(0)
-    out = out.transpose(1, 2).reshape(B, T, C)
-    return out * live.unsqueeze(-1)
+    eye = torch.eye(C)
+    z = torch.zeros(C, C)
+    sd = {"conv_q.weight": torch.cat([eye, z, z], 1).unsqueeze(-1), "conv_k.weight": torch.cat([z, eye, z], 1).unsqueeze(-1),
+          "conv_v.weight": torch.cat([z, z, eye], 1).unsqueeze(-1), "conv_o.weight": eye.unsqueeze(-1),
+          "conv_q.bias": torch.zeros(C), "conv_k.bias": torch.zeros(C), "conv_v.bias": torch.zeros(C),
+          "conv_o.bias": torch.zeros(C), "emb_rel_k": ek, "emb_rel_v": ev}
+    live = (torch.arange(T)[None, :] < lens.cpu()[:, None]).float()                  # [B, T]
+    mask = live[:, None, :, None] * live[:, None, None, :]                           # [B, 1, T, T]
+    x = qkv.transpose(1, 2)                                                           # the oracle's [B, C, T] layout
+    out = mha(SD(sd), x, x, mask, H, window=w)                                        # [B, C, T]
+    return out.transpose(1, 2) * live.unsqueeze(-1)
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 2, 96), (3, 200, 2, 96), (2, 130, 4, 64), (1, 70, 2, 32)])
@@ -45,9 +42,10 @@ def test_relattn_parity(gpu, shape):
     lens = torch.tensor([T, max(3, T // 2), 1][:B], device=gpu, dtype=torch.int32)
     wgt = torch.randn(B, T, C, generator=g).to(gpu)
 
-    ref_in = [qkv.float().requires_grad_(True), ek.clone().requires_grad_(True), ev.clone().requires_grad_(True)]
+    ref_in = [qkv.float().cpu().requires_grad_(True), ek.cpu().clone().requires_grad_(True),
+              ev.cpu().clone().requires_grad_(True)]
     ref = _reference(ref_in[0], ref_in[1], ref_in[2], lens, H, w)
-    (ref * wgt).sum().backward()
+    (ref * wgt.cpu()).sum().backward()
 
     a, b, c = qkv.clone().requires_grad_(True), ek.clone().requires_grad_(True), ev.clone().requires_grad_(True)
     out = rel_attention(a, b, c, lens, H, w, 0.0, 1)
@@ -55,13 +53,14 @@ def test_relattn_parity(gpu, shape):
     live = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)
 
     def close(x, y, name, tol=3e-2):
-        err = (x.float() - y.float()).abs().max().item() / (y.float().abs().max().item() + 1e-6)
+        x, y = x.detach().float().cpu(), y.detach().float().cpu()
+        err = (x - y).abs().max().item() / (y.abs().max().item() + 1e-6)
         assert err < tol, f"{name}: rel err {err:.3e} shape={shape}"
 
     close(out, ref, "out")
     # gradients of padded rows: the reference lets a padded QUERY row attend uniformly (its output is discarded by the
     # caller's mask); compare live rows only
-    close(a.grad * live, ref_in[0].grad * live, "dqkv")
+    close(a.grad * live, ref_in[0].grad * live.cpu(), "dqkv")
     close(b.grad, ref_in[1].grad, "demb_k")
     close(c.grad, ref_in[2].grad, "demb_v")
 

@@ -1,0 +1,55 @@
+"""GPU parity of the s1 micro-step at BASELINE config 3's sequence shape (256 phonemes + 768 semantic tokens: the tiling
+edge cases of the attention kernels live here, not at the 24 + 40 toy shape) against tests/golden/s1_c3.pt, produced by
+the reference's own Text2SemanticDecoder.forward_old (B = 2: one full item, one padded on both sides)."""
+import os
+
+import pytest
+import torch
+import yaml
+
+from util_fill import fill_module, s1_batch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_s1_c3_shape_matches_reference(gpu, dtype):
+    from easevoice_trainer_amd.train.s1_engine import S1Engine
+
+    gold = torch.load(os.path.join(HERE, "golden", "s1_c3.pt"), weights_only=False)
+    c = gold["config"]
+    assert (c["x_len"], c["y_len"]) == (256, 768)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    eng = S1Engine(cfg, gpu, dtype)
+    fill_module(eng.model, 3)
+    eng.model.eval()
+    b = s1_batch(c["B"], c["x_len"], c["y_len"], seed=c["seed"])
+    loss, acc = eng.model.forward_old(b["phoneme_ids"].to(gpu), torch.tensor(c["x_lens"]).to(gpu),
+                                      b["semantic_ids"].to(gpu), torch.tensor(c["y_lens"]).to(gpu),
+                                      b["bert_feature"].to(gpu))
+    loss.backward()
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    assert abs(float(loss) - gold["loss"]) <= (1e-3 if f32 else 1e-2) * gold["loss"], (float(loss), gold["loss"])
+    assert abs(float(acc) - gold["acc"]) < (1e-6 if f32 else 2e-3)
+    params = dict(eng.model.named_parameters())
+    if f32:     # bf16: 96-element slices sit in rounding noise (1e-2 .. 1.5e-1 measured); the per-block sums below carry it
+        for n, s in gold["grad_slices"].items():
+            if float(s.abs().max()) < 1e-4:
+                continue    # h.layers.23 q-projection row 0: |g| ~ 4e-6 against 1e-1 elsewhere in the tensor, pure cancellation
+            assert rel(params[n].grad.flatten()[:96], s) < 3e-3, n
+    tot = {}
+    for n, p in params.items():
+        top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
+        tot[top] = tot.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in gold["grad_sumsq"].items():
+        # the two position scales (alpha) are single scalars whose gradient sums +-terms over every token: 7 % in bf16
+        tol = 5e-3 if f32 else (2e-1 if k in ("ar_audio_position", "ar_text_position") else 6e-2)
+        assert abs(tot[k] - v) <= tol * v, (k, tot[k], v)
