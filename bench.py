@@ -6,8 +6,10 @@ torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line
 Workload (BASELINE.json configs[1]): batch 16 per GPU, 4 s clips (T = 200 frames, 128000
 samples, text 60), bf16 compute, random-init weights of configs/s2.json, synthetic data.  Weak scaling: the per-GPU
 batch is fixed, gradients are all-reduced over RCCL.
-metric: audio-seconds/sec trained (s2) = N * B * clip_seconds / step_time.  The s1 tokens/s figure of the combined
-BASELINE metric is reported by `--workload s1` (secondary line, same contract).
+metric: audio-seconds/sec trained (s2) = N * B * clip_seconds / step_time (`value`); the s1 half of the combined
+BASELINE metric (tokens/sec of the AR GPT micro-step at batch 32 x 1024, configs[2]) is measured in the same run and
+reported as the `s1` sub-object with its own roofline (attention kernel vs the MFMA peak) and CPU baseline.
+Started bare with --gpus N > 1 (no WORLD_SIZE) it launches its own N ranks.
 """
 import argparse
 import json
@@ -118,15 +120,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="s2", choices=["s2", "s1"])
+    ap.add_argument("--workload", default="both", choices=["both", "s2", "s1"],
+                    help="both (default): the s2 line with the s1 leg as its `s1` sub-object")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=16, help="s2 batch per GPU (BASELINE config 2: 16)")
+    ap.add_argument("--s1-batch", type=int, default=32, help="s1 batch per GPU (BASELINE config 3: 32)")
     ap.add_argument("--clip-seconds", type=int, default=4)
-    ap.add_argument("--graphs", type=int, default=1, help="1: replay the step as HIP graphs (default), 0: eager launches")
-    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
+    ap.add_argument("--graphs", type=int, default=1, help="1: replay the s2 step as HIP graphs (default), 0: eager launches")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs (use under rocprofv3)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): become the launcher, one rank per GPU over RCCL on 127.0.0.1
+        from easevoice_trainer_amd.dist import spawn_ranks
+
+        codes = spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], list(range(args.gpus)))
+        sys.exit(max(int(c or 0) != 0 for c in codes))
     world, rank, local = init_dist(args.gpus)
-    if args.workload == "s2":
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or start it bare so that it spawns them")
+    res = None
+    if args.workload in ("both", "s2"):
         res, eng, step_fn = run_s2(args, world, rank, local)
         if not args.no_extras:
             try:
@@ -135,10 +149,22 @@ def main():
                 res.update(bench_extras.s2_extras(args, eng, world, rank, step_fn))
             except Exception as e:  # the headline number must still be printed
                 res["extras_error"] = repr(e)
-    else:
+        del eng, step_fn
+        torch.cuda.empty_cache()
+    if args.workload in ("both", "s1"):
         from tools import bench_s1
 
-        res = bench_s1.run(args, world, rank, local)
+        try:
+            s1 = bench_s1.run(args, world, rank, local, extras=not args.no_extras)
+        except Exception as e:
+            if res is None:
+                raise
+            s1 = {"error": repr(e)}
+        if res is None:
+            res = s1
+        else:
+            res["metric"] = "audio-seconds/sec trained (s2) [value]; tokens/sec (s1) in `s1`"
+            res["s1"] = s1
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

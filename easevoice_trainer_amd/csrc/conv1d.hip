@@ -1199,7 +1199,7 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   const int lout = evt_conv1d_lout(c);
   evt_wlayout l; evt_conv1d_layout(c, &l);
-  evt_set_last_tag("conv_other_fwd");
+  evt_set_last_tag("conv_naive_fwd");
   if (c->impl != EVT_IMPL_NAIVE && !res && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
     evt_set_last_tag("grouped_fwd");
@@ -1265,7 +1265,7 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
   evt_wlayout l; evt_conv1d_layout(c, &l);
   const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
   const void* gate = c->in_slope != 1.f ? x : nullptr;
-  evt_set_last_tag("conv_other_bwd_data");
+  evt_set_last_tag("conv_naive_bwd_data");
   if (c->impl != EVT_IMPL_NAIVE && !gate && !dx_add && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
     evt_set_last_tag("grouped_bwd_data");
@@ -1377,8 +1377,11 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     rc = evt_check_launch();
     if (rc) return rc;
   }
-  evt_set_last_tag("conv_other_bwd_weight");
-  if (grouped) return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
+  evt_set_last_tag("conv_naive_bwd_weight");
+  if (grouped) {
+    evt_set_last_tag("grouped_bwd_weight");
+    return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
+  }
   if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, stream);
   if (cin1) return evt_cin1_bwd_weight(c, x, dy, y, dw, dbias, stream);
   const bool use_igemm = igemm_path;

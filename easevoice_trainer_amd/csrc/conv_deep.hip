@@ -1139,7 +1139,7 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
         return EVT_ELAUNCH;
       attr32 = true;
     }
-    evt_set_last_tag("conv_deep<bf16, 128, 128, 32>");
+    evt_set_last_tag("conv_deep32<bf16, 128, 128, 32>");
     hipLaunchKernelGGL(conv_deep32, dim3(8 * ((p.P + 7) / 8) * p.Y, nphase), dim3(256), lds32, st, p);
     return evt_check_launch();
   }

@@ -189,25 +189,38 @@ class WeightBank:
 TRACE = None   # profiling only (set_trace): (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch
 
 
-def set_trace(rec):
+TRACE_RANGES = False   # each traced launch also opens a torch.profiler range "evt#<record index>"
+
+
+def set_trace(rec, ranges=False):
     """profiling aid of bench.py's roofline leg: a list switches per-launch records (and the library's kernel-name tags)
-    on, None switches both off (the product state)"""
-    global TRACE
+    on, None switches both off (the product state).  ranges=True wraps every traced launch in a torch.profiler
+    record_function range, so that a surrounding torch.profiler session attributes the launch's kernels (durations from
+    the same tracer rocprofv3 uses) to the record -- HIP-event pairs add a few microseconds to every small launch."""
+    global TRACE, TRACE_RANGES
     TRACE = rec
+    TRACE_RANGES = bool(ranges) and rec is not None
     L.lib().evt_debug_kernel_tags(1 if rec is not None else 0)
 
 
 def _t0():
     if TRACE is None:
         return None
+    rf = None
+    if TRACE_RANGES:
+        rf = torch.profiler.record_function(f"evt#{len(TRACE)}")
+        rf.__enter__()
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    return e
+    return e, rf
 
 
 def _t1(e0, kind, m, nseq, lin, extra_elems):
+    e0, rf = e0
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
     lq = lin if m.transposed else m.lout(lin)
     macs = nseq * lq * m.cin * m.cout * m.k // m.groups
     sz = 2 if m._slot.bank.dtype == torch.bfloat16 else 4

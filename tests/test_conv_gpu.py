@@ -164,12 +164,12 @@ def test_conv_narrow_parity(gpu, ci):
 
     case = NARROW_CASES[ci]
     for fusion in (FUSIONS[0], FUSIONS[2], FUSIONS[1]):
-        HC.TRACE = []
+        HC.set_trace([])
         try:
             _run_case(gpu, case, fusion, torch.bfloat16, 0)
             tags = {(r[1], r[0].split(",")[0]) for r in HC.TRACE}
         finally:
-            HC.TRACE = None
+            HC.set_trace(None)
         if fusion["in_slope"] == 1.0:
             assert ("fwd", "conv_narrow<bf16") in tags, tags
         assert ("bwd_data", "conv_narrow<bf16") in tags, tags
@@ -181,12 +181,12 @@ def test_conv_ring_parity(gpu, ci):
 
     case = RING_CASES[ci]
     for fusion in (FUSIONS[2], FUSIONS[0]):
-        HC.TRACE = []
+        HC.set_trace([])
         try:
             _run_case(gpu, case, fusion, torch.bfloat16, 0)
             tags = {(r[1], r[0]) for r in HC.TRACE}
         finally:
-            HC.TRACE = None
+            HC.set_trace(None)
         assert ("fwd", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
         if case[0] % 64 == 0 and case[1] % 64 == 0:
             assert ("bwd_data", "conv_ring<bf16, 64, 64, 64, x4>") in tags, tags
@@ -199,13 +199,13 @@ def test_conv_deep_parity(gpu, ci):
 
     case = DEEP_CASES[ci]
     for fusion in (FUSIONS[2], FUSIONS[0]):
-        HC.TRACE = []
+        HC.set_trace([])
         try:
             _run_case(gpu, case, fusion, torch.bfloat16, 0)
             tags = {(r[1], r[0]) for r in HC.TRACE}
         finally:
-            HC.TRACE = None
-        deep = {"conv_deep<bf16, 128, 128, 64>", "conv_deep<bf16, 128, 128, 32>"}
+            HC.set_trace(None)
+        deep = {"conv_deep<bf16, 128, 128, 64>", "conv_deep32<bf16, 128, 128, 32>"}
         assert any(k == "fwd" and t in deep for k, t in tags), tags
         if case[0] % 128 == 0:
             assert any(k == "bwd_data" and t in deep for k, t in tags), tags

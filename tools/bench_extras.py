@@ -1,60 +1,159 @@
-"""bench.py's `roofline` and `cpu_baseline` legs for the s2 workload.
+"""bench.py's measurement legs beside the headline throughput: per-kernel timing, roofline objects, CPU baselines.
 
-roofline: after the timed region, two more steps run with per-launch HIP events (torch.cuda.Event on the stream the
-kernels are launched on) around every conv entry point; launches are grouped by the kernel instantiation the C++
-dispatcher actually launched (evt_last_kernel_tag(), same names as rocprofv3 --kernel-trace).  The dominant
-instantiation by total time is reported: achieved = sum(algorithmic flops or bytes of its launches) / sum(duration).
-Algorithmic bytes of one conv launch = every operand tensor once (inputs + outputs in the compute dtype + the weight
-image) — the unfused-per-conv figure of SURVEY §8(d); flops = 2 * MACs.  Peaks: 8 TB/s HBM, 2.5 PFLOP/s dense bf16
-MFMA (/opt/skills/guides/MI355X_MICROARCH.md).  `traffic` (PMC HBM bytes) is collected in a separate rocprofv3 --pmc
-pass (profiles/), not inside bench.py.
-
-cpu_baseline: the oracle's s2 step (oracle/s2_step.py: forward, both backward passes, AdamW on every tensor) timed on
-this box's host cores on a bounded sample of the same workload (2 clips of 4 s instead of 16).
+Per-kernel durations come from torch.profiler (kineto -> roctracer/rocprofiler activity records: the same tracer and
+clock `rocprofv3 --kernel-trace` reads), collected inside bench.py over eager steps of the timed workload.  The
+rocprofv3 summaries of the same command are committed under profiles/ (run with --no-extras: two tracers do not share
+a process); the average duration bench.py reports for the dominant kernel is the figure those files show.
+Algorithmic flops / bytes per launch: hip/conv.py's trace records (every operand tensor of a launch once).
 """
 import json
 import os
+import re
 
 import torch
 
-HBM_PEAK_GBS = 8000.0
-MFMA_BF16_PEAK_TF = 2500.0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a copy kernel)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
 MFMA_F32_PEAK_TF = 157.3
+
+
+def short_name(sym: str) -> str:
+    """'void evt_conv::(anonymous namespace)::conv_ring<2, 2, 4>(evt_conv::ConvP)' -> 'conv_ring<2, 2, 4>'"""
+    s = re.sub(r"^void ", "", sym)
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):          # strip the argument list: the first '(' at template depth 0 that is not "(anonymous"
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not s.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    s = s[:cut]
+    return s.split("::")[-1] if "::" in s else s
+
+
+def kernel_profile(run):
+    """run() under torch.profiler.  Returns (kernels, seq): kernels = {symbol: [calls, total_us]} over every GPU kernel
+    of the run; seq = [(start, symbol, us)] in execution order."""
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        run()
+        torch.cuda.synchronize()
+    kernels, seq = {}, []
+    dev = torch.autograd.DeviceType.CUDA
+    for e in prof.events():
+        if e.device_type == dev:
+            if e.name.startswith(("Memcpy", "Memset")):
+                continue
+            us = float(e.time_range.elapsed_us())
+            k = kernels.setdefault(e.name, [0, 0.0])
+            k[0] += 1
+            k[1] += us
+            seq.append((e.time_range.start, e.name, us))
+    seq.sort(key=lambda t: t[0])
+    dump = os.environ.get("EVT_BENCH_DUMP")
+    if dump:
+        with open(dump, "a") as f:
+            for name, (c, us) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{us / 1e3:10.3f} ms {c:6d} calls {us / c:9.2f} us  {name[:160]}\n")
+            f.write("\n")
+    return kernels, seq
+
+
+_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_)")
+
+
+def align_records(rec, seq):
+    """{record index: kernel microseconds}: trace records (launch order) against the profiler's kernel records (start
+    order; one stream, so the same order).  Every traced entry point launches exactly one kernel of the conv family
+    (plus, for some weight gradients, a column-sum helper), and the library's tags start with that kernel's function
+    name -- so the i-th record is the i-th conv-family kernel; the names are cross-checked."""
+    base = lambda n: n.split("<")[0].strip()
+    main = [(base(short_name(n)), us) for _t, n, us in seq if _MAIN.match(base(short_name(n)))]
+    if len(main) != len(rec):
+        return {}
+    out = {}
+    for i, (r, (kb, us)) in enumerate(zip(rec, main)):
+        tb = base(r[0])
+        if not (kb == tb or kb.startswith(tb) or tb.startswith(kb)):
+            return {}
+        out[i] = us
+    return out
+
+
+def _empty_event_pair_us(n=200):
+    """HIP-event pair overhead (fallback timing only): elapsed time between two back-to-back event records"""
+    vals = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        vals.append((a, b))
+    torch.cuda.synchronize()
+    v = sorted(x.elapsed_time(y) * 1e3 for x, y in vals)
+    return v[len(v) // 2]
+
+
+def dec_algorithmic_bytes(B, elem_size):
+    """HiFi-GAN `dec`, forward + backward, unfused-per-conv accounting: 3 x (52.98 M activation elements
+    per item x B + 14.66 M weight elements) x sizeof(dtype)  ->  5.17 GB at B = 16 in bf16"""
+    return 3.0 * (52.98e6 * B + 14.66e6) * elem_size
 
 
 def roofline_s2(args, eng, step_fn, n_steps=2):
     from easevoice_trainer_amd.hip import conv as HC
 
-    HC.set_trace([])
-    graphs, eng.graphs_enabled = eng.graphs_enabled, False   # per-launch events need the eager path
+    rec = []
+    graphs, eng.graphs_enabled = eng.graphs_enabled, False   # per-launch records need the eager path
+    timing = "torch.profiler kernel records (roctracer, the clock rocprofv3 uses)"
     try:
-        for _ in range(n_steps):
-            step_fn()
-        torch.cuda.synchronize()
-        rec = HC.TRACE
+        HC.set_trace(rec)
+        try:
+            kernels, seq = kernel_profile(lambda: [step_fn() for _ in range(n_steps)])
+            ranges = align_records(rec, seq)
+        except Exception as e:     # no tracer in this environment: HIP events minus the measured event-pair overhead
+            kernels, ranges, timing = {}, {}, f"hip events minus empty-pair overhead (profiler unavailable: {e!r})"
+            del rec[:]
+            for _ in range(n_steps):
+                step_fn()
+            torch.cuda.synchronize()
     finally:
         HC.set_trace(None)
         eng.graphs_enabled = graphs
+    if not rec:
+        return None
+    have = len(ranges) >= 0.98 * len(rec) and sum(ranges.values()) > 0
+    ovh = 0.0 if have else _empty_event_pair_us()
+    if not have and kernels:
+        timing = "hip events minus empty-pair overhead (trace records could not be aligned with the kernel records)"
+
+    def dur_us(i, r):
+        if have:
+            return ranges.get(i, 0.0)
+        return max(r[4].elapsed_time(r[5]) * 1e3 - ovh, 0.5)
+
     agg = {}
     dec_mods = {id(m) for m in eng.net_g.dec.modules()}
-    voc = dict(ms=0.0, bytes=0.0, flops=0.0, calls=0)
-    for tag, kind, flops, nbytes, e0, e1, _shape, mod in rec:
+    voc = dict(us=0.0, bytes=0.0, flops=0.0, calls=0)
+    for i, r in enumerate(rec):
+        tag, kind, flops, nbytes, _e0, _e1, _shape, mod = r
+        us = dur_us(i, r)
         if id(mod) in dec_mods:
-            voc["ms"] += e0.elapsed_time(e1)
+            voc["us"] += us
             voc["bytes"] += nbytes
             voc["flops"] += flops
             voc["calls"] += 1
-        a = agg.setdefault(tag, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
-        a["ms"] += e0.elapsed_time(e1)
+        a = agg.setdefault(tag, dict(us=0.0, calls=0, flops=0.0, bytes=0.0))
+        a["us"] += us
         a["calls"] += 1
         a["flops"] += flops
         a["bytes"] += nbytes
-    if not agg:
-        return None
-    tag, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
-    sec = a["ms"] / 1e3
-    tf = a["flops"] / sec / 1e12
-    gbs = a["bytes"] / sec / 1e9
+    tag, a = max(agg.items(), key=lambda kv: kv[1]["us"])
+    sec = a["us"] / 1e6
+    tf, gbs = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
     peak_tf = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
     ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = a["flops"] / max(a["bytes"], 1.0)
@@ -62,45 +161,48 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         r = dict(bound="mfma", achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf)
     else:
         r = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
-    # the HiFi-GAN vocoder (`dec`) convolutions forward + backward against the HBM roofline, with the
-    # per-launch algorithmic bytes (every operand tensor once) summed over its 91 convs x (fwd, bwd-data, bwd-weight)
+    r_voc = None
     if voc["calls"]:
-        vsec = voc["ms"] / 1e3
-        r_voc = dict(bound="hbm", achieved=voc["bytes"] / vsec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                     frac=voc["bytes"] / vsec / 1e9 / HBM_PEAK_GBS, ms_per_step=voc["ms"] / n_steps,
-                     launches_per_step=voc["calls"] / n_steps, algorithmic_gb_per_step=voc["bytes"] / n_steps / 1e9,
-                     tflops=voc["flops"] / vsec / 1e12,
-                     note="late stages (C <= 64) are HBM/launch-bound, the k=7/11 convs at C >= 64 are MFMA-bound")
-    else:
-        r_voc = None
-    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; they come from the
-    # separate rocprofv3 --pmc passes recorded in profiles/r01_pmc_traffic.json (same command, same shapes)
+        vsec = voc["us"] / 1e6
+        esz = 2 if args.dtype == "bf16" else 4
+        alg = dec_algorithmic_bytes(args.batch, esz) * n_steps
+        r_voc = dict(bound="hbm", achieved=alg / vsec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=alg / vsec / 1e9 / HBM_PEAK_GBS, ms_per_step=voc["us"] / 1e3 / n_steps,
+                     launches_per_step=voc["calls"] / n_steps, algorithmic_gb_per_step=alg / n_steps / 1e9,
+                     bytes_with_saved_reads_gb_per_step=voc["bytes"] / n_steps / 1e9,
+                     gbs_with_saved_reads=voc["bytes"] / vsec / 1e9, tflops=voc["flops"] / vsec / 1e12,
+                     note="algorithmic bytes = SURVEY 8(d): 3 x (52.98 M x B + 14.66 M) elements, every conv's input "
+                          "and output once per direction; conv launches of `dec` only (its element-wise launches are "
+                          "in the step time, not in this sum)")
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                                          "r01_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if tag in pmc:
             traffic = pmc[tag]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    r.update(traffic=traffic, traffic_unit="bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate pass)",
-             kernel=tag, hifigan_dec=r_voc, launches_per_step=a["calls"] / n_steps,
-             avg_launch_us=a["ms"] * 1e3 / a["calls"], ms_per_step=a["ms"] / n_steps,
+    top = sorted(kernels.items(), key=lambda kv: -kv[1][1])[:10]
+    r.update(traffic=traffic,
+             traffic_unit="bytes per launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                          "passes, FETCH doubled per the gfx950 note), null when not collected for this kernel",
+             kernel=tag, timing=timing, hifigan_dec=r_voc, launches_per_step=a["calls"] / n_steps,
+             avg_launch_us=a["us"] / a["calls"], ms_per_step=a["us"] / 1e3 / n_steps,
              algorithmic_gflop_per_launch=a["flops"] / a["calls"] / 1e9,
              algorithmic_mb_per_launch=a["bytes"] / a["calls"] / 1e6, intensity_flop_per_byte=intensity,
-             also={k: dict(ms_per_step=round(v["ms"] / n_steps, 3), tflops=round(v["flops"] / (v["ms"] / 1e3) / 1e12, 1),
-                           gbs=round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1))
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]})
+             also={k: dict(ms_per_step=round(v["us"] / 1e3 / n_steps, 3), avg_us=round(v["us"] / v["calls"], 2),
+                           tflops=round(v["flops"] / (v["us"] / 1e6) / 1e12, 1), gbs=round(v["bytes"] / (v["us"] / 1e6) / 1e9, 1))
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])[:8]},
+             gpu_kernels_top=[dict(kernel=short_name(k), calls_per_step=v[0] / n_steps, avg_us=round(v[1] / v[0], 2),
+                                   ms_per_step=round(v[1] / 1e3 / n_steps, 3)) for k, v in top],
+             gpu_kernel_ms_per_step=round(sum(v[1] for v in kernels.values()) / 1e3 / n_steps, 3) if kernels else None,
+             at_native_share=(round(sum(v[1] for k, v in kernels.items() if "at::native" in k) /
+                                    max(sum(v[1] for v in kernels.values()), 1e-9), 4) if kernels else None))
     return r
 
 
-def cpu_baseline_s2(args, hps, hard_timeout_s=150.0):
-    """runs tools/cpu_baseline.py in a subprocess; whatever it printed before the hard timeout is reported"""
+def _cpu_subprocess(cmd, hard_timeout_s, unit, what):
     import subprocess
-    import sys
 
-    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_baseline.py"),
-           "--batch", "2", "--clip-seconds", str(args.clip_seconds), "--budget", "40"]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env)
@@ -109,9 +211,25 @@ def cpu_baseline_s2(args, hps, hard_timeout_s=150.0):
         out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
     lines = [l for l in out.splitlines() if l.startswith("{")]
     if not lines:
-        return dict(value=None, unit="audio-s/s", cores=None, kind="port",
-                    sample=f"oracle s2 step did not finish one timed step within {hard_timeout_s:.0f} s on this host")
+        return dict(value=None, unit=unit, cores=None, kind="port",
+                    sample=f"{what} did not finish one timed step within {hard_timeout_s:.0f} s on this host")
     return json.loads(lines[-1])
+
+
+def cpu_baseline_s2(args, hard_timeout_s=170.0):
+    """oracle s2 step at the BENCH shape (B = 16 x 4 s by default) in a subprocess with a hard timeout"""
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--stage", "s2", "--batch", str(args.batch),
+           "--clip-seconds", str(args.clip_seconds), "--budget", "60"]
+    return _cpu_subprocess(cmd, hard_timeout_s, "audio-s/s", "oracle s2 step")
+
+
+def cpu_baseline_s1(hard_timeout_s=170.0):
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--stage", "s1", "--budget", "60"]
+    return _cpu_subprocess(cmd, hard_timeout_s, "tokens/s", "oracle s1 micro-step")
 
 
 def s2_extras(args, eng, world, rank, step_fn=None):
@@ -121,5 +239,5 @@ def s2_extras(args, eng, world, rank, step_fn=None):
         if r is not None:
             out["roofline"] = r
     if world == 1 and rank == 0:
-        out["cpu_baseline"] = cpu_baseline_s2(args, eng.hps)
+        out["cpu_baseline"] = cpu_baseline_s2(args)
     return out

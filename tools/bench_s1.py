@@ -1,6 +1,8 @@
-"""bench.py --workload s1: the s1 AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th
-micro-batch as in the reference) at BASELINE configs[2]: batch 32, x_len 256 + y_len 768 = 1024, bf16.
-metric: tokens/sec = N * B * 1024 / micro-step time."""
+"""The s1 leg of bench.py: the AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th micro-batch
+as in the reference) at BASELINE configs[2]: batch 32, x_len 256 + y_len 768 = 1024, bf16.
+metric: tokens/sec = N * B * 1024 / micro-step time.  Roofline: the attention forward kernel against the dense bf16
+MFMA peak (4 * L^2 * D * H * B flops per layer, the skippable upper triangle of the y x y block is NOT
+credited), its duration from torch.profiler's kernel records; north_star's "attention at batch 16" point is timed too."""
 import os
 import time
 
@@ -8,9 +10,73 @@ import torch
 import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_F32_PEAK_TF = 157.3
 
 
-def run(args, world, rank, local):
+def _batch(B, x_len, y_len, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    return dict(phoneme_ids=torch.randint(0, 732, (B, x_len), generator=g).to(dev),
+                phoneme_ids_len=torch.full((B,), x_len, dtype=torch.long, device=dev),
+                semantic_ids=torch.randint(0, 1024, (B, y_len), generator=g).to(dev),
+                semantic_ids_len=torch.full((B,), y_len, dtype=torch.long, device=dev),
+                bert_feature=torch.randn(B, 1024, x_len, generator=g).to(dev))
+
+
+def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2):
+    """per-kernel records of `n_micro` micro-steps -> roofline object of the attention forward kernel (+ the two
+    backward kernels and the GEMM kernels in `also`)"""
+    from tools.bench_extras import kernel_profile, short_name
+
+    m = eng.config["model"]
+    H, E, nl = m["head"], m["hidden_dim"], m["n_layer"]
+    D = E // H
+
+    def run():
+        for i in range(n_micro):
+            eng.micro_step(batch, 1 + i)      # indices 1..: no optimiser step inside the profiled region
+
+    try:
+        kernels, _ = kernel_profile(run)
+    except Exception as e:
+        return dict(bound="mfma", achieved=None, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=None, traffic=None,
+                    note=f"profiler unavailable: {e!r}")
+    def pick(sub):
+        v = [(k, c) for k, c in kernels.items() if sub in k]
+        return (sum(c[0] for _, c in v), sum(c[1] for _, c in v)) if v else (0, 0.0)
+
+    peak = MFMA_BF16_PEAK_TF if dtype_name == "bf16" else MFMA_F32_PEAK_TF
+    flops_fwd = 4.0 * Lq * Lq * D * H * B                  # QK^T and PV, per layer
+    calls, us = pick("attn_fwd")
+    total_us = sum(c[1] for c in kernels.values())
+    out = dict(bound="mfma", peak=peak, unit="TFLOP/s", traffic=None, kernel="attn_fwd_" + ("bf16" if dtype_name == "bf16" else "f32"),
+               timing="torch.profiler kernel records (roctracer, the clock rocprofv3 uses)",
+               flops_per_launch=flops_fwd, causal_skip_credited=False, batch=B, seq_len=Lq, head_dim=D, heads=H)
+    if calls:
+        avg = us / calls
+        out.update(achieved=flops_fwd / (avg * 1e-6) / 1e12, frac=flops_fwd / (avg * 1e-6) / 1e12 / peak, avg_launch_us=avg,
+                   launches_per_micro_step=calls / n_micro)
+    else:
+        out.update(achieved=None, frac=None)
+    also = {}
+    for name, mult in (("attn_bwd_dq", 2.0), ("attn_bwd_dkv", 2.0)):     # each recomputes S and does two more products
+        c, u = pick(name)
+        if c:
+            also[name] = dict(avg_us=round(u / c, 1), tflops=round(mult * flops_fwd / (u / c * 1e-6) / 1e12, 1))
+    att_us = sum(pick(n)[1] for n in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_delta"))
+    gemm = sorted(((k, c) for k, c in kernels.items() if k.startswith("Cijk_") or "gemm_bf16" in k), key=lambda kv: -kv[1][1])
+    out["also"] = also
+    out["attention_ms_per_micro_step"] = round(att_us / 1e3 / n_micro, 3)
+    out["gemm_ms_per_micro_step"] = round(sum(c[1] for _, c in gemm) / 1e3 / n_micro, 3)
+    out["vendor_gemm_kernels"] = sum(1 for k, _ in gemm if k.startswith("Cijk_"))
+    out["gpu_kernel_ms_per_micro_step"] = round(total_us / 1e3 / n_micro, 3)
+    out["gpu_kernels_top"] = [dict(kernel=short_name(k)[:60], calls=c[0] // n_micro, avg_us=round(c[1] / c[0], 1),
+                                   ms=round(c[1] / 1e3 / n_micro, 3))
+                              for k, c in sorted(kernels.items(), key=lambda kv: -kv[1][1])[:8]]
+    return out
+
+
+def run(args, world, rank, local, extras=True):
     from easevoice_trainer_amd.train.s1_engine import S1Engine
 
     dev = torch.device("cuda", local)
@@ -25,16 +91,11 @@ def run(args, world, rank, local):
     eng = S1Engine(cfg, dev, dtype, reducer=reducer)
     if world > 1:
         reducer.broadcast_params(eng.arena.param)
-    B = 32 if args.batch == 16 else args.batch   # bench.py's default --batch is the s2 one
+    B = args.s1_batch
     x_len, y_len = 256, 768
-    g = torch.Generator().manual_seed(1234 + rank)
-    batch = dict(phoneme_ids=torch.randint(0, 732, (B, x_len), generator=g).to(dev),
-                 phoneme_ids_len=torch.full((B,), x_len, dtype=torch.long, device=dev),
-                 semantic_ids=torch.randint(0, 1024, (B, y_len), generator=g).to(dev),
-                 semantic_ids_len=torch.full((B,), y_len, dtype=torch.long, device=dev),
-                 bert_feature=torch.randn(B, 1024, x_len, generator=g).to(dev))
+    batch = _batch(B, x_len, y_len, dev, 1234 + rank)
     idx = 0
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         loss, acc, _ = eng.micro_step(batch, idx)
         idx += 1
     if world > 1:
@@ -53,7 +114,7 @@ def run(args, world, rank, local):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     tok = world * B * (x_len + y_len)
-    return {
+    res = {
         "metric": "tokens/sec (s1)", "value": tok / (dt / args.steps), "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -62,3 +123,21 @@ def run(args, world, rank, local):
                    "global_batch": world * B, "seq_len": x_len + y_len, "parallelism": f"dp{world}"},
         "loss_per_token_last": float(loss) / (B * y_len), "top3_acc_last": float(acc),
     }
+    if extras:
+        try:
+            res["roofline"] = attention_roofline(eng, batch, B, x_len + y_len, args.dtype)
+            if B != 16:       # north_star quotes MFMA utilisation of the attention "at batch 16"
+                b16 = _batch(16, x_len, y_len, dev, 99)
+                eng.micro_step(b16, 1)
+                r16 = attention_roofline(eng, b16, 16, x_len + y_len, args.dtype)
+                res["roofline"]["at_batch_16"] = {k: r16.get(k) for k in ("achieved", "frac", "avg_launch_us", "also",
+                                                                          "attention_ms_per_micro_step")}
+        except Exception as e:
+            res["roofline_error"] = repr(e)
+        if world == 1 and rank == 0:
+            from tools.bench_extras import cpu_baseline_s1
+
+            res["cpu_baseline"] = cpu_baseline_s1()
+    del eng
+    torch.cuda.empty_cache()
+    return res

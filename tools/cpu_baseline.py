@@ -1,6 +1,6 @@
-"""Times the oracle's s2 step (oracle/s2_step.py) on the host cores; run by bench.py as a SUBPROCESS with a hard
-timeout so the GPU bench line never waits on a slow host.  Prints one JSON line after every timed step (the parent
-keeps the last one)."""
+"""Times the oracle's s2 step (oracle/s2_step.py) or s1 micro-step (oracle/s1_step.py) on the host cores; run by
+bench.py as a SUBPROCESS with a hard timeout so the GPU bench line never waits on a slow host.  Prints one JSON line
+after every timed step (the parent keeps the last one)."""
 import argparse
 import json
 import os
@@ -11,9 +11,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def main_s1(a, threads):
+    """one s1 micro-step (forward_old + backward through autograd) at L = 256 + 768.  The CPU math path keeps the
+    [B*16, L, L] probabilities of all 24 layers: ~6.5 GB per item (B = 8 is 52.7 GB), so the batch is
+    sized to the host's free memory: 8 (BASELINE.md's figure) with >= 120 GB free, else 2."""
+    import torch
+    import yaml
+
+    torch.set_num_threads(threads)
+    from easevoice_trainer_amd.auto_reg.t2s_model import Text2SemanticDecoder
+    from oracle import s1_step as O
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    B = a.batch if a.batch > 0 else (8 if _mem_available_gb() >= 120 else 2)
+    x_len, y_len = 256, 768
+    torch.manual_seed(1234)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point())
+          for k, v in Text2SemanticDecoder(cfg).state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randint(0, 732, (B, x_len), generator=g)
+    y = torch.randint(0, 1024, (B, y_len), generator=g)
+    bert = torch.randn(B, 1024, x_len, generator=g)
+    xl, yl = torch.full((B,), x_len), torch.full((B,), y_len)
+    t_start, times = time.perf_counter(), []
+    while len(times) < 3 and (not times or (time.perf_counter() - t_start) + min(times) < a.budget):
+        t0 = time.perf_counter()
+        loss, _acc, _ = O.forward_old(sd, cfg, x, xl, y, yl, bert)
+        grads = torch.autograd.grad(loss, [v for v in sd.values() if v.requires_grad], allow_unused=True)
+        del grads, loss
+        times.append(time.perf_counter() - t0)
+        best = min(times)
+        print(json.dumps(dict(
+            value=B * (x_len + y_len) / best, unit="tokens/s", cores=threads, kind="port", seconds_per_step=best,
+            sample=f"oracle s1 micro-step (forward_old + backward, no optimiser), batch {B} x (256 + 768) tokens, fp32, "
+                   f"{threads} threads, best of {len(times)} step(s), {best:.2f} s/step "
+                   f"(batch sized to {_mem_available_gb():.0f} GB of free host memory)")), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--stage", default="s2", choices=["s2", "s1"])
+    ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--clip-seconds", type=int, default=4)
     ap.add_argument("--budget", type=float, default=40.0)
     ap.add_argument("--threads", type=int, default=0)
@@ -24,6 +72,9 @@ def main():
         avail = os.cpu_count() or 1
     threads = a.threads or max(1, min(avail, 32))
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    if a.stage == "s1":
+        return main_s1(a, threads)
+    a.batch = a.batch or 16
     import torch
 
     torch.set_num_threads(threads)
