@@ -87,16 +87,18 @@ class CrossEntropySumFn(torch.autograd.Function):
     the same pass (t2s_model.py:486-489).  Returns (loss, hits int32[2] = (hits, counted rows))."""
 
     @staticmethod
-    def forward(ctx, logits, targets, topk, ignore_index):
+    def forward(ctx, logits, targets, topk, ignore_index, V=None):
+        """logits [rows, ld] with ld >= V (columns >= V are padding of the GEMM that produced them)"""
         logits = logits.contiguous()
-        rows, V = logits.shape
+        rows, ld = logits.shape
+        V = ld if V is None else int(V)
         dlogits = torch.empty_like(logits)
         loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
         hits = torch.zeros(2, dtype=torch.int32, device=logits.device)
-        L.check(L.lib().evt_ce_sum_fwd_bwd(L.dt_of(logits), L.ptr(logits), L.ptr(targets.contiguous()), L.ptr(dlogits),
-                                           L.ptr(loss), L.ptr(hits), C.c_int64(rows), V, int(topk),
-                                           C.c_int64(int(ignore_index)), C.c_float(1.0), L.stream_ptr()),
-                "evt_ce_sum_fwd_bwd")
+        L.check(L.lib().evt_ce_sum_fwd_bwd_ld(L.dt_of(logits), L.ptr(logits), L.ptr(targets.contiguous()), L.ptr(dlogits),
+                                              L.ptr(loss), L.ptr(hits), C.c_int64(rows), V, C.c_int64(ld), int(topk),
+                                              C.c_int64(int(ignore_index)), C.c_float(1.0), L.stream_ptr()),
+                "evt_ce_sum_fwd_bwd_ld")
         ctx.save_for_backward(dlogits)
         ctx.mark_non_differentiable(hits)
         return loss[0], hits
@@ -104,7 +106,7 @@ class CrossEntropySumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * dloss.to(dlogits.dtype), None, None, None
+        return dlogits * dloss.to(dlogits.dtype), None, None, None, None
 
 
 class CrossEntropyRowsFn(torch.autograd.Function):
@@ -113,15 +115,16 @@ class CrossEntropyRowsFn(torch.autograd.Function):
     get_batch_logps models/utils.py:176-183).  Returns (row_loss fp32 [rows], hits int32[2])."""
 
     @staticmethod
-    def forward(ctx, logits, targets, topk, ignore_index):
+    def forward(ctx, logits, targets, topk, ignore_index, V=None):
         logits = logits.contiguous()
-        rows, V = logits.shape
+        rows, ld = logits.shape
+        V = ld if V is None else int(V)
         dlogits = torch.empty_like(logits)
         row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
         hits = torch.zeros(2, dtype=torch.int32, device=logits.device)
-        L.check(L.lib().evt_ce_rows_fwd_bwd(L.dt_of(logits), L.ptr(logits), L.ptr(targets.contiguous()), L.ptr(dlogits),
-                                            L.ptr(row_loss), L.ptr(hits), C.c_int64(rows), V, int(topk),
-                                            C.c_int64(int(ignore_index)), L.stream_ptr()), "evt_ce_rows_fwd_bwd")
+        L.check(L.lib().evt_ce_rows_fwd_bwd_ld(L.dt_of(logits), L.ptr(logits), L.ptr(targets.contiguous()), L.ptr(dlogits),
+                                               L.ptr(row_loss), L.ptr(hits), C.c_int64(rows), V, C.c_int64(ld), int(topk),
+                                               C.c_int64(int(ignore_index)), L.stream_ptr()), "evt_ce_rows_fwd_bwd_ld")
         ctx.save_for_backward(dlogits)
         ctx.mark_non_differentiable(hits)
         return row_loss, hits
@@ -129,4 +132,4 @@ class CrossEntropyRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drow, _):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * drow.to(dlogits.dtype).unsqueeze(1), None, None, None
+        return dlogits * drow.to(dlogits.dtype).unsqueeze(1), None, None, None, None

@@ -8,7 +8,8 @@ TransformerEncoder / TransformerEncoderLayer (modules/transformer.py:106-339), M
   * the [B*16, L, L] float mask is never built: the flash-attention kernel evaluates the prefix-LM + padding rule from
     (x_len, x_lens, y_lens);
   * post-LN residuals, cross-entropy(sum) + top-3 accuracy are single fused HIP launches;
-  * Linear layers are plain GEMMs (hipBLASLt via F.linear) in the compute dtype.
+  * Linear layers run on the library's own MFMA GEMM kernels (hip/linear.py -> evt_gemm_bf16_*), from bf16 weight
+    images that a LinearBank rebuilds once per optimiser step (no per-call weight casts, no vendor BLAS).
 `forward` is the DPO branch (t2s_model.py:393-429), `forward_old` the plain one the default config trains with;
 `infer_panel*` (KV-cache decoding, t2s_model.py:732-878) lives in t2s_infer.py.
 """
@@ -20,8 +21,15 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.enc import bump_rng, new_site, relu_dropout, res_drop_ln
+from ..hip.linear import LinearBank, linear as _hip_linear
 from .ops import AddLayerNormFn, CrossEntropyRowsFn, CrossEntropySumFn, PrefixLMAttentionFn
 from .utils import dpo_loss, make_reject_y
+
+
+def linear(x, weight, bias=None, relu=False):
+    """F.linear (+ relu) on the HIP GEMM kernels; the weight must be attached to a LinearBank (S1Engine does it).
+    (A module-level name so that the CPU wiring tests can substitute it: tests/cpu_emu.py.)"""
+    return _hip_linear(x, weight, bias, relu)
 
 
 class TokenEmbedding(nn.Module):
@@ -80,10 +88,10 @@ class MultiheadAttention(nn.Module):
         nn.init.constant_(self.out_proj.bias, 0.0)
 
     def forward(self, x, x_lens, y_lens, x_len, seed):
-        qkv = F.linear(x, self.in_proj_weight.to(x.dtype), self.in_proj_bias.to(x.dtype))
+        qkv = linear(x, self.in_proj_weight, self.in_proj_bias)
         p = self.dropout if self.training else 0.0
         o = PrefixLMAttentionFn.apply(qkv.contiguous(), x_lens, y_lens, x_len, self.num_heads, p, seed)
-        return F.linear(o, self.out_proj.weight.to(x.dtype), self.out_proj.bias.to(x.dtype))
+        return linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
 class LayerNorm(nn.Module):
@@ -116,13 +124,13 @@ class TransformerEncoderLayer(nn.Module):
             # training: dropout1 / dropout2 ride in the residual+LayerNorm launch, the inner dropout in the relu launch
             # (masks from the device-counter hash stream of hip/enc.py, one stream id per site)
             x = res_drop_ln(x, sa.contiguous(), self.norm1.weight, self.norm1.bias, None, p, self._sites[0], self.norm1.eps)
-            h = relu_dropout(F.linear(x, self.linear1.weight.to(x.dtype), self.linear1.bias.to(x.dtype)), p, self._sites[1])
-            ff = F.linear(h, self.linear2.weight.to(x.dtype), self.linear2.bias.to(x.dtype))
+            h = relu_dropout(linear(x, self.linear1.weight, self.linear1.bias), p, self._sites[1])
+            ff = linear(h, self.linear2.weight, self.linear2.bias)
             return res_drop_ln(x, ff.contiguous(), self.norm2.weight, self.norm2.bias, None, p, self._sites[2], self.norm2.eps)
         sa = self.dropout1(sa)
         x = AddLayerNormFn.apply(x, sa, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        h = F.relu(F.linear(x, self.linear1.weight.to(x.dtype), self.linear1.bias.to(x.dtype)))
-        ff = self.dropout2(F.linear(self.dropout(h), self.linear2.weight.to(x.dtype), self.linear2.bias.to(x.dtype)))
+        h = linear(x, self.linear1.weight, self.linear1.bias, relu=True)       # relu = the GEMM's epilogue
+        ff = self.dropout2(linear(self.dropout(h), self.linear2.weight, self.linear2.bias))
         return AddLayerNormFn.apply(x, ff, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 
@@ -165,6 +173,22 @@ class Text2SemanticDecoder(nn.Module):
         self.cd = torch.float32
         self._seed = 0
 
+    def dense_specs(self):
+        """(name, weight, bias) of every Linear of the training forward, for hip/linear.LinearBank"""
+        specs = [("bert_proj", self.bert_proj.weight, self.bert_proj.bias)]
+        for i, l in enumerate(self.h.layers):
+            specs += [(f"h.{i}.in_proj", l.self_attn.in_proj_weight, l.self_attn.in_proj_bias),
+                      (f"h.{i}.out_proj", l.self_attn.out_proj.weight, l.self_attn.out_proj.bias),
+                      (f"h.{i}.linear1", l.linear1.weight, l.linear1.bias),
+                      (f"h.{i}.linear2", l.linear2.weight, l.linear2.bias)]
+        specs.append(("ar_predict_layer", self.ar_predict_layer.weight, None))
+        return specs
+
+    def attach_bank(self, dtype, device):
+        """prepared weight images for the HIP GEMMs; call after the parameters have reached their final storage"""
+        self._bank = LinearBank(self.dense_specs(), dtype, device)
+        return self._bank
+
     def pad_y_eos(self, y, y_mask_int, eos_id):
         targets = F.pad(y, (0, 1), value=0) + eos_id * F.pad(y_mask_int, (0, 1), value=1)
         return targets[:, :-1], targets[:, 1:]
@@ -172,9 +196,13 @@ class Text2SemanticDecoder(nn.Module):
     def _logits(self, x, x_lens, y, y_lens, bert_feature):
         """embeddings -> 24 post-LN blocks -> predict layer over the y positions; returns (logits [B, Ty, V], targets)"""
         cd = self.cd
+        bank = getattr(self, "_bank", None)
+        if bank is not None:
+            bank.prepare()       # weight images of all dense layers: one launch, only when the weights changed
         xe = self.ar_text_embedding(x)
-        xe = xe + F.linear(bert_feature.transpose(1, 2).to(cd), self.bert_proj.weight.to(cd), self.bert_proj.bias.to(cd)
-                           ).to(xe.dtype)
+        bf = torch.empty((x.size(0), x.size(1), bert_feature.size(1)), dtype=cd, device=bert_feature.device)
+        bf.copy_(bert_feature.transpose(1, 2))          # [B, 1024, Tx] -> [B, Tx, 1024] in the compute dtype, one pass
+        xe = xe + linear(bf, self.bert_proj.weight, self.bert_proj.bias).to(xe.dtype)
         xe = self.ar_text_position(xe)
         y_mask_int = make_pad_mask(y_lens, y.size(1)).to(torch.int64)
         codes = y.to(torch.int64) * (1 - y_mask_int)
@@ -186,13 +214,14 @@ class Text2SemanticDecoder(nn.Module):
         if xy.is_cuda:
             bump_rng(xy.device)      # new dropout masks for the fused residual/LayerNorm and relu launches
         xy_dec = self.h(xy, x_lens.to(torch.int32).contiguous(), y_lens.to(torch.int32).contiguous(), x_len, self._seed)
-        return F.linear(xy_dec[:, x_len:], self.ar_predict_layer.weight.to(cd)), targets
+        # [B, Ty, ld]: ld = 1152 on the HIP path (the 1025-entry vocabulary padded to the GEMM tile, zero columns)
+        logits = linear(xy_dec[:, x_len:].contiguous(), self.ar_predict_layer.weight)
+        return logits.reshape(-1, logits.size(-1)), targets
 
     def forward_old(self, x, x_lens, y, y_lens, bert_feature):
         """x phoneme ids [B, Tx], y semantic ids [B, Ty], bert_feature [B, 1024, Tx] -> (loss sum, top-3 acc)"""
         logits, targets = self._logits(x, x_lens, y, y_lens, bert_feature)
-        loss, hits = CrossEntropySumFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k,
-                                             self.EOS)
+        loss, hits = CrossEntropySumFn.apply(logits, targets.reshape(-1), self.top_k, self.EOS, self.vocab_size)
         acc = hits[0].float() / hits[1].clamp(min=1).float()
         return loss, acc
 
@@ -205,10 +234,9 @@ class Text2SemanticDecoder(nn.Module):
         reject_y, reject_y_lens = make_reject_y(y, y_lens)
         B = x.size(0)
         logits, targets = self._logits(x, x_lens, y, y_lens, bert_feature)
-        row, hits = CrossEntropyRowsFn.apply(logits.reshape(-1, self.vocab_size), targets.reshape(-1), self.top_k, self.EOS)
+        row, hits = CrossEntropyRowsFn.apply(logits, targets.reshape(-1), self.top_k, self.EOS, self.vocab_size)
         r_logits, r_targets = self._logits(x, x_lens, reject_y, reject_y_lens, bert_feature)
-        r_row, _ = CrossEntropyRowsFn.apply(r_logits.reshape(-1, self.vocab_size), r_targets.reshape(-1), self.top_k,
-                                            self.EOS)
+        r_row, _ = CrossEntropyRowsFn.apply(r_logits, r_targets.reshape(-1), self.top_k, self.EOS, self.vocab_size)
         chosen_logps, rejected_logps = -row.view(B, -1).sum(-1), -r_row.view(B, -1).sum(-1)
         loss = row.sum() + dpo_loss(chosen_logps, rejected_logps, 0.2)
         acc = hits[0].float() / hits[1].clamp(min=1).float()

@@ -1345,7 +1345,9 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   }
   p.dbias = nullptr;
   // wide layers with plain operands: LDS-DMA GEMM kernel (conv_deep.hip); its dbias comes from the column-sum kernel
-  const bool deep_w = igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
+  // dense layers (k = 1, long reductions): the 128 x 128 weight-gradient GEMM tile
+  const bool gemm_w = igemm_path && c->impl == EVT_IMPL_AUTO && !c->transposed && evt_conv::wgrad_gemm_eligible(p, c->dtype);
+  const bool deep_w = !gemm_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
   // latency-bound mid-size layers: ring-pipelined LDS-DMA kernel (fuses dbias when A is dy)
   const bool ring_w = !deep_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
@@ -1403,6 +1405,10 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     else
       hipLaunchKernelGGL(conv_naive_bwd_weight<float>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
     return evt_check_launch();
+  }
+  if (gemm_w) {
+    p.dbias = fuse_bias ? dbias : nullptr;
+    return evt_conv::launch_wgrad_gemm(p, st);
   }
   if (deep_w) {
     p.dbias = fuse_bias ? dbias : nullptr;

@@ -644,6 +644,186 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// wgrad_gemm: the weight gradient of a dense layer (k = 1), dW[N][K] += dy[M][N]^T . x[M][K], as a 128 x 128 GEMM tile.
+// Same structure as wgrad_deep -- both operands position-major, LDS-DMA staging, ds_read_b64_tr_b16 fragments, K stage of
+// 64 positions, split over blockIdx.y with fp32 atomics -- but the B tile is FOUR 32-channel chunks of the SAME rows
+// instead of five taps of one chunk: a 5-tap x 32-channel tile degenerates to 128 x 32 for k = 1 (the s1 Linear layers
+// ran at 117 TFLOP/s on wgrad_ring<4, 1, 4> for that reason).  A wave owns 64 dy-channels x (16 x-channels of each of
+// the 4 chunks): 4 x 4 MFMA tiles per K = 32 step, 16 transpose reads behind one wait.
+// Reference call sites: the backward of F.linear at transformer.py:207-224,330-334, patched_mha_with_cache.py:242,460.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int GKT = 4;                                   // 32-channel chunks of x per block (128 channels)
+constexpr int GSTAGE = WA_BYTES + GKT * WB_BYTES;        // 32 KiB
+
+template <int KS>
+__device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[GKT]) {
+  uint2 al[4], ah[4], bl[GKT], bh[GKT];
+  if constexpr (KS == 0) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16 offset:0\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %17 offset:0\n\t"
+        "ds_read_b64_tr_b16 %5, %17 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %18 offset:0\n\t"
+        "ds_read_b64_tr_b16 %6, %18 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %19 offset:0\n\t"
+        "ds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %8, %20 offset:0\n\t"
+        "ds_read_b64_tr_b16 %12, %20 offset:256\n\t"
+        "ds_read_b64_tr_b16 %9, %20 offset:4096\n\t"
+        "ds_read_b64_tr_b16 %13, %20 offset:4352\n\t"
+        "ds_read_b64_tr_b16 %10, %20 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %14, %20 offset:8448\n\t"
+        "ds_read_b64_tr_b16 %11, %20 offset:12288\n\t"
+        "ds_read_b64_tr_b16 %15, %20 offset:12544\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]),
+          "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %1, %17 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %5, %17 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %2, %18 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %6, %18 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %3, %19 offset:8192\n\t"
+        "ds_read_b64_tr_b16 %7, %19 offset:9216\n\t"
+        "ds_read_b64_tr_b16 %8, %20 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %12, %20 offset:2304\n\t"
+        "ds_read_b64_tr_b16 %9, %20 offset:6144\n\t"
+        "ds_read_b64_tr_b16 %13, %20 offset:6400\n\t"
+        "ds_read_b64_tr_b16 %10, %20 offset:10240\n\t"
+        "ds_read_b64_tr_b16 %14, %20 offset:10496\n\t"
+        "ds_read_b64_tr_b16 %11, %20 offset:14336\n\t"
+        "ds_read_b64_tr_b16 %15, %20 offset:14592\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(al[0]), "=&v"(al[1]), "=&v"(al[2]), "=&v"(al[3]), "=&v"(ah[0]), "=&v"(ah[1]), "=&v"(ah[2]), "=&v"(ah[3]),
+          "=&v"(bl[0]), "=&v"(bl[1]), "=&v"(bl[2]), "=&v"(bl[3]), "=&v"(bh[0]), "=&v"(bh[1]), "=&v"(bh[2]), "=&v"(bh[3])
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
+        : "memory");
+  }
+  union { uint4 u; bf16x8 v; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
+#pragma unroll
+  for (int t = 0; t < GKT; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_gemm(WgP p, int stages_per_split) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j16 = lane & 15, g8 = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int ngrp = p.nchunk / GKT;                       // 128-channel groups of x
+  const int cg = blockIdx.x % ngrp;
+  const int atile = blockIdx.x / ngrp;
+  const int a0 = atile * 128;
+
+  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const int total_units = p.nseq * p.Q;
+  const int nstages = (total_units + WPOS - 1) / WPOS;
+  const int st_begin = blockIdx.y * stages_per_split;
+  const int st_end = min(nstages, st_begin + stages_per_split);
+  if (st_begin >= st_end) return;
+
+  // DMA roles as in wgrad_deep: wave w stages rows [16w, 16w+16) of every tile
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  int arow[4], acol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    arow[i] = wave * 16 + i * 4 + (lane >> 4);
+    const int f = 2 * ((arow[i] & 3) | (((arow[i] >> 3) & 1) << 2));
+    acol[i] = a0 + (((lane & 15) ^ f) * 8);
+  }
+  const int brow = wave * 16 + (lane >> 2);
+  const int bcol = cg * 128 + (((lane & 3) ^ (2 * ((brow >> 3) & 1))) * 8);      // + 32 * t per chunk
+
+  auto issue = [&](int st, int buf) {
+    unsigned char* base = smem + buf * GSTAGE;
+    const int u0 = st * WPOS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = u0 + arow[i];
+      const bf16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
+      glds16(src, base + wave * 4096 + i * 1024);
+    }
+    const int u = u0 + brow;
+    const bool uok = u < total_units;
+    const bf16_t* rsrc = Bg + (long)(uok ? u : 0) * p.CB + bcol;
+#pragma unroll
+    for (int t = 0; t < GKT; ++t) glds16(uok ? rsrc + t * 32 : zsrc, base + WA_BYTES + t * WB_BYTES + wave * 1024);
+  };
+
+  f32x4 acc[4][GKT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < GKT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.dbias != nullptr && cg == 0 && tid < 128;
+  float bsum = 0.f;
+
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int frow = g8 * 8 + (j16 >> 2);
+  const int fa = 2 * ((frow & 3) | (((frow >> 3) & 1) << 2));
+  const int fb = 2 * ((frow >> 3) & 1);
+  const int half = (j16 & 1) * 8;
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = frow * 256 + (((wr * 8 + i * 2 + ((j16 & 3) >> 1)) ^ fa) * 16) + half;
+  const int b_off = WA_BYTES + frow * 64 + (((wc * 2 + ((j16 & 3) >> 1)) ^ fb) * 16) + half;
+
+  issue(st_begin, 0);
+  for (int st = st_begin; st < st_end; ++st) {
+    const int buf = (st - st_begin) & 1;
+    __syncthreads();
+    if (st + 1 < st_end) issue(st + 1, buf ^ 1);
+    const unsigned sbase = lds0 + buf * GSTAGE;
+    unsigned aa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aa[i] = sbase + a_off[i];
+    const unsigned ba = sbase + b_off;
+    bf16x8 a[4], b[GKT];
+    tr_load_step_g<0>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < GKT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    tr_load_step_g<1>(aa, ba, a, b);
+#pragma unroll
+    for (int t = 0; t < GKT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    if (do_bias) {
+      const unsigned char* at = smem + buf * GSTAGE;
+      const int slot = tid >> 3, sub = (tid & 7) * 2;
+      for (int r = 0; r < WPOS; ++r) {
+        const int f = 2 * ((r & 3) | (((r >> 3) & 1) << 2));
+        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * 256 + ((slot ^ f) * 16) + sub));
+      }
+    }
+  }
+  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
+
+  // lane holds dy-channels g8*4..+3 (rows) x x-channel j16 (column) of each tile; image [CA][nchunk][1][32]
+#pragma unroll
+  for (int t = 0; t < GKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wr * 64 + i * 16 + g8 * 4 + r;
+        const long off = ((long)a * p.nchunk + cg * GKT + t) * 32 + wc * 16 + j16;
+        atomicAdd(p.dw + off, acc[i][t][r]);
+      }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // wgrad_ring<MA, KT, NS>: wgrad_deep's GEMM with a block tile of 32*MA A-channels x (KT taps x 32 B-channels) and an
 // NS-deep ring of 64-position K stages with counted waits and one raw barrier per stage (see conv_ring): the weight
 // gradients of the WN / FFN / mid-width vocoder layers are 3200..20000-position reductions that were bound by one
@@ -1196,6 +1376,47 @@ int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
   }
   evt_set_last_tag("wgrad_deep<bf16, 128, 5x32, 64>");
   hipLaunchKernelGGL(wgrad_deep, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
+  return evt_check_launch();
+}
+
+bool wgrad_gemm_eligible(const WgP& p, int dtype) {
+  static const bool off = getenv("EVT_NO_WGRAD_GEMM") != nullptr;    // A/B switch for measurements
+  if (off || dtype != EVT_DT_BF16) return false;
+  if (p.KH != 1 || p.KHp != 1 || p.s != 1 || p.off != 0) return false;
+  if (p.CA % 128 || p.CB % 128) return false;
+  if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
+  if (p.LA != p.Q || p.LB != p.Q) return false;             // both operands addressed by the flat position
+  const long units = (long)p.nseq * p.Q;
+  if (units >= (1L << 31) - WPOS) return false;
+  return units >= 2048;                                      // long reductions only: the dense layers of s1
+}
+
+int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
+  WgP p = p_in;
+  if (!wgrad_gemm_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  p.nchunk = p.CB / 32;
+  p.ntapgrp = 1;
+  const long tiles = (long)(p.CA / 128) * (p.CB / 128);
+  const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
+  // one resident wave of blocks (2 per CU): more splits only add fp32 atomics (46 MB of them per launch was a third of
+  // wgrad_deep's traffic in round 1)
+  static const long target = getenv("EVT_WGRAD_GEMM_BLOCKS") ? atol(getenv("EVT_WGRAD_GEMM_BLOCKS")) : 512;
+  long split = (target + tiles - 1) / tiles;
+  if (split > nstages / 8) split = nstages / 8;
+  if (split < 1) split = 1;
+  const int per = (int)((nstages + split - 1) / split);
+  split = (nstages + per - 1) / per;
+  p.nsplit = (int)split;
+  static bool attr = false;
+  const size_t lds = 2 * GSTAGE;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  evt_set_last_tag("wgrad_gemm<bf16, 128, 128, 64>");
+  hipLaunchKernelGGL(wgrad_gemm, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
   return evt_check_launch();
 }
 

@@ -57,6 +57,9 @@ int launch_conv_narrow(const ConvP& p, int out_ch, int k_ch, int nphase, hipStre
 // weight gradient on the same LDS-DMA structure (A channels % 128 == 0, B channels % 32 == 0, plain operands, no dbias)
 bool wgrad_deep_eligible(const WgP& p, int dtype);
 int launch_wgrad_deep(const WgP& p, hipStream_t st);
+// dense-layer (k = 1) weight gradient as a 128 x 128 GEMM tile (A, B channels % 128 == 0, long reductions); fuses dbias
+bool wgrad_gemm_eligible(const WgP& p, int dtype);
+int launch_wgrad_gemm(const WgP& p, hipStream_t st);
 // ring-pipelined variant for the latency-bound mid-size layers (A channels % 64 == 0); fuses dbias
 bool wgrad_ring_eligible(const WgP& p, int dtype);
 int launch_wgrad_ring(const WgP& p, hipStream_t st);

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd(const T* x, const T* r, const 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_sum_kernel(const T* logits, const long* targets, T* dlogits, float* loss,
                                                      int* hits, long rows, int V, int topk, long ignore_index,
-                                                     float dloss, float* row_loss) {
+                                                     float dloss, float* row_loss, long ld) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* lr = logits + row * V;
+  const T* lr = logits + row * ld;
   const long tgt = targets[row];
   float mx = -INFINITY;
   for (int c = lane; c < V; c += 64) mx = fmaxf(mx, to_f<T>(lr[c]));
@@ -162,13 +162,14 @@ __global__ __launch_bounds__(256) void ce_sum_kernel(const T* logits, const long
   for (int c = lane; c < V; c += 64) gt += (to_f<T>(lr[c]) > lt) ? 1.f : 0.f;
   gt = wave_reduce_sum(gt);
   if (dlogits) {
-    T* dr = dlogits + row * V;
+    T* dr = dlogits + row * ld;
     const float inv = dloss / se;
     for (int c = lane; c < V; c += 64) {
       float g = expf(to_f<T>(lr[c]) - mx) * inv;
       if (c == tgt) g -= dloss;
       dr[c] = from_f<T>(g);
     }
+    for (long c = V + lane; c < ld; c += 64) dr[c] = from_f<T>(0.f);     // padding columns of a strided logits buffer
   }
   if (lane == 0) {
     if (loss) atomicAdd(loss, lse - lt);
@@ -273,17 +274,19 @@ int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const flo
 
 static int launch_ce(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
                      float* row_loss, int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index,
-                     float dloss, void* stream) {
+                     float dloss, void* stream, int64_t ld = 0) {
   if (!logits || !targets || (!loss && !row_loss) || rows <= 0 || V <= 0) return EVT_EINVAL;
+  if (ld == 0) ld = V;
+  if (ld < V) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)((rows + 3) / 4);
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL(ce_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)logits,
                        (const long*)targets, (bf16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
-                       row_loss);
+                       row_loss, (long)ld);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(ce_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)logits, (const long*)targets,
-                       (float*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss, row_loss);
+                       (float*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss, row_loss, (long)ld);
   else return EVT_EINVAL;
   return evt_check_launch();
 }
@@ -299,6 +302,20 @@ int evt_ce_rows_fwd_bwd(int32_t dtype, const void* logits, const int64_t* target
                         int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, void* stream) {
   if (!row_loss) return EVT_EINVAL;
   return launch_ce(dtype, logits, targets, dlogits, nullptr, row_loss, hits, rows, V, topk, ignore_index, 1.0f, stream);
+}
+
+int evt_ce_sum_fwd_bwd_ld(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
+                          int32_t* hits, int64_t rows, int32_t V, int64_t ld, int32_t topk, int64_t ignore_index,
+                          float dloss, void* stream) {
+  if (!loss) return EVT_EINVAL;
+  return launch_ce(dtype, logits, targets, dlogits, loss, nullptr, hits, rows, V, topk, ignore_index, dloss, stream, ld);
+}
+
+int evt_ce_rows_fwd_bwd_ld(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
+                           int32_t* hits, int64_t rows, int32_t V, int64_t ld, int32_t topk, int64_t ignore_index,
+                           void* stream) {
+  if (!row_loss) return EVT_EINVAL;
+  return launch_ce(dtype, logits, targets, dlogits, nullptr, row_loss, hits, rows, V, topk, ignore_index, 1.0f, stream, ld);
 }
 
 int evt_scaled_adam_stats(const float* param, const float* grad, const evt_sa_chunk* chunks, int32_t nchunks,

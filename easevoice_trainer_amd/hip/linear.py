@@ -1,0 +1,159 @@
+"""Host side of the dense-layer GEMMs (C ABI: evt_gemm_bf16_*, csrc/gemm.hip): a bank of prepared weight images for
+all Linear layers of a model and the autograd Function that calls the three entry points.
+
+Reference modules mirrored: torch.nn.Linear / the packed `in_proj_weight` of MultiheadAttention, called through
+F.linear at src/easevoice/soundstorm/auto_reg/modules/transformer.py:207-224,330-334,
+patched_mha_with_cache.py:242,460 and models/t2s_model.py:276,486.  The parameters stay what they are in the
+reference (fp32 `weight` [N, K] / `bias` [N] with the same state_dict keys); what is added is a bf16 (or fp32) image of
+W and of W^T per layer, rebuilt by ONE multi-tensor launch whenever the optimiser has touched the weights -- instead of
+the per-call `weight.to(bf16)` casts of a torch-level implementation.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+N_ALIGN = 128      # an output width that is not a multiple of 128 is padded up to it (zero rows / columns)
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("relu", C.c_int32)]
+
+
+class LinearSlot:
+    __slots__ = ("name", "weight", "bias", "N", "Np", "K", "layout", "reg", "alt", "bank", "_pcache")
+
+    def __init__(self, name, weight, bias, bank):
+        self.name, self.weight, self.bias, self.bank = name, weight, bias, bank
+        self.N, self.K = weight.shape
+        self.Np = (self.N + N_ALIGN - 1) // N_ALIGN * N_ALIGN if self.N % 8 else self.N
+        if self.Np != self.N and bias is not None:
+            raise L.EvtError(f"linear {name}: a padded output width ({self.N} -> {self.Np}) with a bias is not supported")
+        self._pcache = {}
+
+    def params(self, M, relu):
+        p = self._pcache.get((M, relu))
+        if p is None:
+            p = self._pcache[(M, relu)] = GemmParams(self.bank.dt, M, self.Np, self.K, 1 if relu else 0)
+        return p
+
+
+class LinearBank:
+    """Prepared weight images of a set of Linear weights.  `specs`: iterable of (name, weight Parameter [N, K], bias
+    Parameter [N] or None).  A weight whose N is padded (slot.Np > N) must sit in storage that is readable -- and zero
+    -- up to Np rows (runtime.ParamArena(reserve=...))."""
+
+    def __init__(self, specs, dtype: torch.dtype, device):
+        self.dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
+        self.dtype, self.device = dtype, torch.device(device)
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.slots = []
+        reg_n = alt_n = 0
+        offs = []
+        for name, w, b in specs:
+            s = LinearSlot(name, w, b, self)
+            lay = L.WLayout()
+            g = GemmParams(self.dt, 128, s.Np, s.K, 0)
+            L.check(L.lib().evt_gemm_bf16_layout(C.byref(g), C.byref(lay)), "evt_gemm_bf16_layout")
+            s.layout = lay
+            self.slots.append(s)
+            offs.append((reg_n, alt_n))
+            reg_n += (lay.reg_elems + 127) // 128 * 128
+            alt_n += (lay.alt_elems + 127) // 128 * 128
+            w._evt_slot = s
+        self.reg_arena = torch.zeros(max(reg_n, 1), dtype=dtype, device=device)
+        self.alt_arena = torch.zeros(max(alt_n, 1), dtype=dtype, device=device)
+        for s, (ro, ao) in zip(self.slots, offs):
+            s.reg = self.reg_arena[ro: ro + s.layout.reg_elems]
+            s.alt = self.alt_arena[ao: ao + s.layout.alt_elems]
+        self._items = self._rows = None
+        self._stamp = None
+        self.dirty = True
+
+    def _tables(self):
+        items, rows = [], []
+        for i, s in enumerate(self.slots):
+            it = L.WPrepItem()
+            it.v, it.g = s.weight.data_ptr(), None
+            it.reg, it.alt = s.reg.data_ptr(), s.alt.data_ptr()
+            it.dw = it.dv = it.dg = None
+            it.lay, it.dtype = s.layout, self.dt
+            items.append(it)
+            rows.extend((i, r) for r in range(s.layout.d0))
+        self._items = L.struct_to_device(items, self.device)
+        self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+        self._nrows = len(rows)
+        self._ptrs = [s.weight.data_ptr() for s in self.slots]
+
+    def mark_dirty(self):
+        """the optimiser wrote the weights through raw pointers"""
+        self.dirty = True
+
+    def prepare(self, force=False):
+        """rebuild the images when the weights changed: after an optimiser step (mark_dirty) or an in-place write torch
+        versions (load_state_dict, copy_)"""
+        stamp = sum(s.weight._version for s in self.slots)
+        if self._items is None or self._ptrs != [s.weight.data_ptr() for s in self.slots]:
+            self._tables()
+            force = True
+        if force or self.dirty or stamp != self._stamp:
+            L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
+                    "evt_wn_fold_multi")
+            self._stamp, self.dirty = stamp, False
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) on the last dimension; x [..., K] contiguous in the bank's dtype -> y [..., Np]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, anchor, slot, relu):
+        if x.dtype != slot.bank.dtype or not x.is_contiguous() or x.size(-1) != slot.K:
+            raise L.EvtError(f"linear {slot.name}: contiguous [..., {slot.K}] {slot.bank.dtype} expected, got "
+                             f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
+        M = x.numel() // slot.K
+        y = torch.empty(x.shape[:-1] + (slot.Np,), dtype=x.dtype, device=x.device)
+        L.check(L.lib().evt_gemm_bf16_fwd(C.byref(slot.params(M, relu)), L.ptr(x), L.ptr(slot.reg), L.ptr(slot.alt),
+                                          L.ptr(bias.data if bias is not None else None), L.ptr(y), L.stream_ptr()),
+                "evt_gemm_bf16_fwd")
+        ctx.slot, ctx.relu, ctx.M = slot, relu, M
+        ctx.save_for_backward(x, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        slot, M = ctx.slot, ctx.M
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy_eff = torch.empty_like(dy)
+            L.check(L.lib().evt_dact_mul(L.dt_of(dy), L.ptr(dy), L.ptr(y), L.ACT_LRELU, C.c_float(0.0), L.ptr(dy_eff),
+                                         C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
+            dy = dy_eff
+        p = slot.params(M, False)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
+            if slot.bias is not None and ctx.needs_input_grad[2]:
+                db = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device)
+            L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db),
+                                                     L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
+            if slot.Np != slot.N:
+                dw = dw[:slot.N]
+                db = db[:slot.N] if db is not None else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(L.lib().evt_gemm_bf16_bwd_data(C.byref(p), L.ptr(dy), L.ptr(slot.reg), L.ptr(slot.alt), L.ptr(dx),
+                                                   L.stream_ptr()), "evt_gemm_bf16_bwd_data")
+        return dx, dw, db, None, None, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) (+ relu) through the bank the weight is attached to.  Returns [..., Np]: the output
+    width padded to a multiple of 128 when N is not a multiple of 8 (only the 1025-entry vocabulary projection), columns
+    >= N being zero.  There is no fallback: a weight without a bank raises."""
+    slot = getattr(weight, "_evt_slot", None)
+    if slot is None:
+        raise L.EvtError("linear(): the weight is not attached to a LinearBank (S1Engine builds it); no eager fallback")
+    return LinearFn.apply(x, weight, bias, slot.bank.anchor, slot, bool(relu))

@@ -22,13 +22,16 @@ class ParamArena:
     """Moves every parameter of `model` into one contiguous fp32 buffer (views keep their names/shapes, so
     state_dict()/load_state_dict() are unchanged) and gives each a `.grad` view into a matching grad buffer."""
 
-    def __init__(self, model: nn.Module, device):
+    def __init__(self, model: nn.Module, device, reserve=None):
+        """reserve: {parameter name: floats} -- room kept (and left zero) behind a parameter, e.g. for a weight whose
+        GEMM image is padded to more rows than the parameter has (hip/linear.py)"""
         self.device = torch.device(device)
         params = [(n, p) for n, p in model.named_parameters()]
         offs, total = {}, 0
+        reserve = reserve or {}
         for n, p in params:
             offs[n] = total
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            total += (max(p.numel(), int(reserve.get(n, 0))) + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = total
         self.updates = 0          # bumped by every optimiser launch on this arena (raw-pointer writes torch cannot see)
         self.param = torch.zeros(total, dtype=torch.float32, device=self.device)

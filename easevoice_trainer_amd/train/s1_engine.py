@@ -17,7 +17,12 @@ class S1Engine:
         self.config, self.device, self.dtype, self.reducer = config, torch.device(device), dtype, reducer
         self.model = Text2SemanticDecoder(config=config, top_k=3).to(self.device)
         self.model.cd = dtype
-        self.arena = ParamArena(self.model, self.device)
+        # the vocabulary projection (1025 x 512) is run as a 1152-row GEMM: its zero padding rows live behind the parameter
+        from ..hip.linear import N_ALIGN
+        w = self.model.ar_predict_layer.weight
+        pad_rows = (w.size(0) + N_ALIGN - 1) // N_ALIGN * N_ALIGN
+        self.arena = ParamArena(self.model, self.device, reserve={"ar_predict_layer.weight": pad_rows * w.size(1)})
+        self.bank = self.model.attach_bank(dtype, self.device)
         o = config["optimizer"]
         self.optimizer = ScaledAdam(self.arena, lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0,
                                     clipping_update_period=1000)
@@ -52,6 +57,7 @@ class S1Engine:
                 self.reducer.all_reduce(self.arena.grad)
                 self.arena.grad.mul_(1.0 / self.reducer.world)
             self.optimizer.step()
+            self.bank.mark_dirty()        # weights written through raw pointers: refold the GEMM images on next use
             self.optimizer.zero_grad()
             self.scheduler.step()
             stepped = True

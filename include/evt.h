@@ -228,6 +228,30 @@ int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* ---------------------------------------------------------------------------------------
  * s1 (text -> semantic GPT) kernels.
  * ------------------------------------------------------------------------------------- */
+/* Dense layers ("gemm_bf16" of SURVEY 8(b)):  y[M][N] = act(x[M][K] . W[N][K]^T + bias),  act = relu when `relu`.
+ * Replaces F.linear at transformer.py:207-224,330-334 (linear1 / linear2), patched_mha_with_cache.py:242,460 (packed
+ * in-projection, out-projection) and t2s_model.py:276,486 (bert_proj, ar_predict_layer).  dtype EVT_DT_BF16 runs on the
+ * LDS-DMA MFMA kernels (fp32 accumulation), EVT_DT_F32 is the fp32-MFMA parity path.  K % 8 == 0 and N % 8 == 0 (a
+ * caller with an odd N, e.g. the 1025-entry vocabulary, pads the weight image and the output to a multiple of 128 with
+ * zero rows / columns).
+ * The weights are passed as the two prepared images of evt_gemm_bf16_layout (same structs as the convolutions:
+ * evt_wn_fold_multi with g == NULL casts an fp32 master into both images in one launch for all layers):
+ *   REG = W row-major [N][K] in chunks of reg_ck (forward, dW geometry),  ALT = W^T [K][N] (backward-data).
+ * bwd_data: dx[M][K] = dy[M][N] . W   (dy already multiplied by the activation derivative: evt_dact_mul)
+ * bwd_weight: dw (fp32, REG geometry) += dy^T x ; dbias[N] (fp32, may be NULL) += column sums of dy. */
+typedef struct evt_gemm_params {
+  int32_t dtype;   /* EVT_DT_* */
+  int32_t M, N, K;
+  int32_t relu;    /* forward epilogue: max(0, .) */
+} evt_gemm_params;
+int evt_gemm_bf16_layout(const evt_gemm_params* g, evt_wlayout* out);
+int evt_gemm_bf16_fwd(const evt_gemm_params* g, const void* x, const void* w_reg, const void* w_alt, const float* bias,
+                      void* y, void* stream);
+int evt_gemm_bf16_bwd_data(const evt_gemm_params* g, const void* dy, const void* w_reg, const void* w_alt, void* dx,
+                           void* stream);
+int evt_gemm_bf16_bwd_weight(const evt_gemm_params* g, const void* x, const void* dy, float* dw, float* dbias,
+                             void* stream);
+
 /* Flash attention with the ANALYTIC prefix-LM + key-padding mask of
  * src/easevoice/soundstorm/auto_reg/models/t2s_model.py:456-479 (no [B*H,L,L] mask tensor):
  *   key j visible from query i  <=>  j is not padding  AND  ( j < x_len  if i < x_len  else  j <= i )
@@ -333,6 +357,14 @@ int evt_ce_sum_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets
  * upstream weight), hits as above.  The summed target log-probability of a sequence is -sum of its rows. */
 int evt_ce_rows_fwd_bwd(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
                         int32_t* hits, int64_t rows, int32_t V, int32_t topk, int64_t ignore_index, void* stream);
+/* The same two entry points for logits / dlogits with a row stride ld >= V (the GEMM above writes the 1025-entry
+ * vocabulary into rows of 1152): columns [V, ld) of the logits are ignored and written as zeros in dlogits. */
+int evt_ce_sum_fwd_bwd_ld(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* loss,
+                          int32_t* hits, int64_t rows, int32_t V, int64_t ld, int32_t topk, int64_t ignore_index,
+                          float dloss, void* stream);
+int evt_ce_rows_fwd_bwd_ld(int32_t dtype, const void* logits, const int64_t* targets, void* dlogits, float* row_loss,
+                           int32_t* hits, int64_t rows, int32_t V, int64_t ld, int32_t topk, int64_t ignore_index,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * s1 KV-cache decoding step (Text2SemanticDecoder.infer_panel_naive, t2s_model.py:762-863).

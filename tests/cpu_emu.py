@@ -150,9 +150,14 @@ def cpu_emulation_s1():
         def apply(x, r, gamma, beta, eps):
             return F.layer_norm(x + r if r is not None else x, (x.size(-1),), gamma, beta, eps)
 
+    def lin(x, weight, bias=None, relu=False):
+        y = F.linear(x, weight.to(x.dtype), bias.to(x.dtype) if bias is not None else None)
+        return F.relu(y) if relu else y
+
     class _CE:
         @staticmethod
-        def apply(logits, targets, topk, ignore_index):
+        def apply(logits, targets, topk, ignore_index, V=None):
+            logits = logits if V is None else logits[:, :V]
             loss = F.cross_entropy(logits.float(), targets, reduction="sum")
             lt = logits.detach().gather(1, targets[:, None])
             gt = (logits.detach() > lt).sum(dim=1)
@@ -162,7 +167,8 @@ def cpu_emulation_s1():
 
     class _CERows:
         @staticmethod
-        def apply(logits, targets, topk, ignore_index):
+        def apply(logits, targets, topk, ignore_index, V=None):
+            logits = logits if V is None else logits[:, :V]
             row = F.cross_entropy(logits.float(), targets, reduction="none")
             return row, _CE.apply(logits, targets, topk, ignore_index)[1]
 
@@ -193,6 +199,9 @@ def cpu_emulation_s1():
                 p.add_(d)
 
     TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn = _Attn, _LN, _CE
+    saved_lin, TM.linear = TM.linear, lin
+    from easevoice_trainer_amd.hip import linear as HL
+    saved_prep, HL.LinearBank.prepare = HL.LinearBank.prepare, (lambda self, force=False: None)   # no images on the CPU
     saved_rows, TM.CrossEntropyRowsFn = TM.CrossEntropyRowsFn, _CERows
     OPT.ScaledAdam._k_stats, OPT.ScaledAdam._k_apply = k_stats, k_apply
     try:
@@ -201,6 +210,8 @@ def cpu_emulation_s1():
         (TM.PrefixLMAttentionFn, TM.AddLayerNormFn, TM.CrossEntropySumFn, OPT.ScaledAdam._k_stats,
          OPT.ScaledAdam._k_apply) = saved
         TM.CrossEntropyRowsFn = saved_rows
+        TM.linear = saved_lin
+        HL.LinearBank.prepare = saved_prep
 
 
 @contextlib.contextmanager
