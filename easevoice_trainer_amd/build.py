@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libevt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
+EXTRA_FLAGS = {}   # per-file flags (none at present)
 
 
 def _newer(a, b):
@@ -35,7 +36,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

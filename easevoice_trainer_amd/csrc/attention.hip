@@ -16,6 +16,8 @@
 // The fp32 kernels (one thread per row) are the parity path: exact-order fp32, no MFMA.
 #include "evt_common.h"
 #include "../../include/evt.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -28,29 +30,35 @@ struct AP {
   long sb, sl, sh;     // q/k/v/dq/dk/dv element strides
   long ob, ol, oh;     // o / d_o element strides
   float scale;
-  unsigned drop_thr;   // keep iff hash >= thr ; 0 = no dropout
+  unsigned drop_thr;   // thr16 << 16: a 16-bit hash field f is kept iff (f << 16) >= drop_thr ; 0 = no dropout
   unsigned seed;
   float keep_scale;    // 1 / (1 - p)
 };
 
 // Counter-based dropout mask (attention dropout of SDPA, patched_mha_with_cache.py:452-454): a pure function of
 // (seed, b*H+h, query, key) so forward and both backward kernels regenerate the same mask with no storage.
-// Only 24-bit multiplies (full rate on CDNA; 32-bit integer multiplies are quarter rate) and xor-shifts.
+// ONE 32-bit hash decides TWO scores: keys k and k ^ 16 of a query share the hash of kp = k & ~16, key kp is kept iff
+// the low 16 bits >= thr16, key kp + 16 iff the high 16 bits >= thr16 (thr16 = round(p * 65536): p = 0.1 -> 0.100006;
+// keep_scale = 1 / (1 - thr16 / 65536) keeps the expectation exact).  The two keys are the e / e + 4 score slots of one
+// lane in the S^T tiles of forward / dQ and the two key tiles of one lane in dK/dV, so the per-score cost is half a
+// hash (an add, an xor-shift, a 24-bit multiply-xor: full-rate VALU only) plus one compare and one select.
+// The per-query part is a full avalanche hash (computed once per query and kernel, not per score).
+constexpr unsigned DROP_KC = 0x85EBCBu;
 __device__ __forceinline__ unsigned drop_row(const AP& p, unsigned bh, int qi) {
-  const unsigned a = (bh << 11) ^ (unsigned)qi;                    // < 2^24 for B*H <= 8192, L <= 2048
-  return __umul24(a & 0xFFFFFFu, 0x9E3779u) ^ p.seed ^ (a >> 7);
+  unsigned a = ((bh << 11) ^ (unsigned)qi) + p.seed * 0x9E3779B1u;
+  a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+  return a;
 }
-__device__ __forceinline__ float drop_mult2(const AP& p, unsigned row, int kj) {
-  unsigned x = row + __umul24((unsigned)kj, 0x85EBCBu);
+__device__ __forceinline__ unsigned drop_pair(unsigned x) {      // x = drop_row + umul24(kp, DROP_KC)
   x ^= x >> 15;
-  x = __umul24(x & 0xFFFFFFu, 0x2C1B3Du) ^ (x >> 9);
-  x ^= x << 13;
-  x ^= x >> 17;
-  return x >= p.drop_thr ? p.keep_scale : 0.f;
+  return __umul24(x, 0x2C1B3Du) ^ (x >> 9);
 }
+__device__ __forceinline__ bool keep_lo(unsigned h, unsigned thr_hi) { return (h << 16) >= thr_hi; }
+__device__ __forceinline__ bool keep_hi(unsigned h, unsigned thr_hi) { return h >= thr_hi; }
 __device__ __forceinline__ float drop_mult(const AP& p, unsigned bh, int qi, int kj) {
   if (p.drop_thr == 0u) return 1.f;
-  return drop_mult2(p, drop_row(p, bh, qi), kj);
+  const unsigned h = drop_pair(drop_row(p, bh, qi) + __umul24((unsigned)(kj & ~16), DROP_KC));
+  return ((kj & 16) ? keep_hi(h, p.drop_thr) : keep_lo(h, p.drop_thr)) ? p.keep_scale : 0.f;
 }
 
 __device__ __forceinline__ bool visible(int qi, int kj, int x_len, int xl, int yl) {
@@ -59,13 +67,14 @@ __device__ __forceinline__ bool visible(int qi, int kj, int x_len, int xl, int y
   return qi < x_len ? (kj < x_len) : (kj <= qi);
 }
 
+// two ds_read_b64_tr_b16 (transposing 16-bit LDS reads) -> one MFMA A fragment.  The builtin (not inline asm) lets the
+// compiler track the LDS counter, so all fragment reads of a key sub-block are in flight behind ONE wait.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 tr2(const bf16_t* p0, const bf16_t* p1) {
-  const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1;
-  uint2 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-  union { uint4 u; bf16x8 v; } r;
-  r.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  union { struct { s16x4 lo, hi; } h; bf16x8 v; } r;
+  r.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  r.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
   return r.v;
 }
 
@@ -116,13 +125,23 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // all-reduce over the four lanes {n, n+16, n+32, n+48} that hold one query's scores, with the gfx950 VALU lane-swap
 // instructions instead of LDS-pipe shuffles: v_permlane32_swap exchanges the upper half of one operand with the lower
 // half of the other, v_permlane16_swap exchanges odd 16-lane rows with even rows.
+// max(a, b) as med3(a, b, +inf): fmaxf() makes the compiler quiet possible signalling NaNs first (a v_max_f32 x, x, x
+// per operand that comes out of an MFMA -- 12 extra VALU instructions per 16 x 32 score tile); the med3 intrinsic is
+// emitted as is.  Scores are finite or -inf here, never NaN.  (Not an option: inline-asm v_max3 -- the hazard recogniser
+// does not treat an asm statement as a VALU reader of a just-issued MFMA result; -mno-amdgpu-ieee -- device-library
+// functions, blockIdx included, are then no longer inlined.)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
+__device__ __forceinline__ float max8(const float* s) {
+  return vmax(vmax3(s[0], s[1], s[2]), vmax3(vmax3(s[3], s[4], s[5]), s[6], s[7]));
+}
 __device__ __forceinline__ float quad_max(float v) {
   unsigned u = __float_as_uint(v);
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  v = vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
   u = __float_as_uint(v);
   auto r2 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+  return vmax(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
 }
 __device__ __forceinline__ float quad_sum(float v) {
   unsigned u = __float_as_uint(v);
@@ -135,26 +154,53 @@ __device__ __forceinline__ float quad_sum(float v) {
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // ---------------------------------------------------------------------------------------------------------
+// Shared structure of the three bf16 kernels: a block owns 128 rows of one (b, h) (4 waves x 2 tiles of 16) and walks
+// the other axis in blocks of 64 rows through a DOUBLE-BUFFERED LDS tile pair: the next block's global loads are issued
+// before the current block is multiplied and land in registers under it; they are written to the other buffer after
+// the multiply, ONE barrier per block.  Scale folding: scores stay raw, exp2(fma(s, scale*log2e, -m*scale*log2e));
+// the 1/(1-p) of dropout and the 1/sqrt(d) of dS are applied once to the accumulators at the end.
+// ---------------------------------------------------------------------------------------------------------
+// register staging of one 64-row tile pair (256 threads x 16 bytes per tensor); plain locals so they stay in VGPRs
+#define EVT_TILE_REGS uint4 tl_a = make_uint4(0, 0, 0, 0), tl_b = make_uint4(0, 0, 0, 0); const int tl_r = tid >> 2, tl_c8 = tid & 3
+#define EVT_TILE_LOAD(A, sa, B, sb_, row0)                                              \
+  {                                                                                     \
+    const int tl_j = min((row0) + tl_r, p.L - 1);                                       \
+    tl_a = *reinterpret_cast<const uint4*>((A) + tl_j * (sa) + tl_c8 * 8);             \
+    tl_b = *reinterpret_cast<const uint4*>((B) + tl_j * (sb_) + tl_c8 * 8);            \
+  }
+#define EVT_TILE_STORE(As, Bs)                                                          \
+  {                                                                                     \
+    *reinterpret_cast<uint4*>((As) + tl_r * PITCH + tl_c8 * 8) = tl_a;                  \
+    *reinterpret_cast<uint4*>((Bs) + tl_r * PITCH + tl_c8 * 8) = tl_b;                  \
+  }
+
+// ---------------------------------------------------------------------------------------------------------
 // forward (bf16): block = 4 waves x 2 query tiles (128 queries) of one (b, h); key blocks of 64 through LDS
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <bool JOINT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-  const int qblk = blockIdx.x * 128;
+  // 1-D grid, LONGEST BLOCKS FIRST: query block nqb-1 (walks every key) of all (b, h), then nqb-2, ... -- the short text
+  // blocks fill the tail (with the (b, h)-major order the last dispatched 16-iteration blocks ran on an empty chip)
+  const int BH = p.B * p.H;
+  const int bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int qblk = ((p.L + 127) / 128 - 1 - blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
   const float sc2 = p.scale * LOG2E;
+  const unsigned thr = p.drop_thr;
 
   bf16x8 qf[2];
   f32x4 ot[2][2];
-  float m[2], l[2];
+  float m[2], ms[2], l[2];          // running maximum (raw scores), the same times scale*log2(e), running sum
   int qi[2], qt0[2];
-  unsigned drow[2];
+  unsigned rowc[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     qt0[t] = qblk + wave * 32 + t * 16;
@@ -163,20 +209,24 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
     qf[t] = ld8(Q + qc * p.sl + g * 8);
     ot[t][0] = ot[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     m[t] = -INFINITY;
+    ms[t] = 0.f;
     l[t] = 0.f;
-    drow[t] = drop_row(p, blockIdx.y, qi[t]);
+    const unsigned row = thr ? drop_row(p, (unsigned)bh, qi[t]) : 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rowc[t][e] = row + __umul24((unsigned)(g * 4 + e), DROP_KC);
   }
   const int qlast = min(qblk + 127, p.L - 1);
   const int kmax = (qlast < p.x_len) ? p.x_len : qlast + 1;
-  for (int kb = 0; kb < kmax; kb += 64) {
-    __syncthreads();
-    {
-      const int r = tid >> 2, c8 = tid & 3;
-      const int kj = min(kb + r, p.L - 1);
-      *reinterpret_cast<uint4*>(Ks + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(K + kj * p.sl + c8 * 8);
-      *reinterpret_cast<uint4*>(Vs + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(V + kj * p.sl + c8 * 8);
-    }
-    __syncthreads();
+  EVT_TILE_REGS;
+  EVT_TILE_LOAD(K, p.sl, V, p.sl, 0);
+  EVT_TILE_STORE(Ks[0], Vs[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = 0; kb < kmax; kb += 64, buf ^= 1) {
+    const bool more = kb + 64 < kmax;
+    if (more) EVT_TILE_LOAD(K, p.sl, V, p.sl, kb + 64);
+    const bf16_t* Kc = Ks[buf];
+    const bf16_t* Vc = Vs[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int k0 = kb + sb * 32;
@@ -184,55 +234,90 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 ka0 = ld8(Ks + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 ka1 = ld8(Ks + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* vrow = Vs + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const bf16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
+      const bf16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const bf16_t* vrow = Vc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
       const bf16x8 va0 = tr2(vrow, vrow + 16 * PITCH);
       const bf16x8 va1 = tr2(vrow + 16, vrow + 16 * PITCH + 16);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (cls[t] == TILE_EMPTY) continue;
+      const unsigned k0c = __umul24((unsigned)k0, DROP_KC);
+      // both query tiles in ONE straight-line body (two independent dependency chains for the scheduler); the masked
+      // variant (diagonal / padding tiles, a few percent of the work) evaluates visible() per score in both tiles --
+      // a fully masked tile leaves every exp2 at 0 and the running statistics untouched
+      auto body = [&](auto masked_tag, auto t0_tag, auto t1_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
-        float s[8];
+        f32x4 sa[2], sb2[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = (e < 4 ? s0[e] : s1[e - 4]) * sc2;
-        if (cls[t] == TILE_MIXED) {
+        for (int t = T0; t < T1; ++t) {
+          sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
+          sb2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
+        }
+        float s[2][8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int kj = k0 + slot32(g, e);
-            if (!(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) s[e] = -INFINITY;
+        for (int t = T0; t < T1; ++t) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[t][e] = e < 4 ? sa[t][e] : sb2[t][e - 4];
+          if (MASKED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int kj = k0 + slot32(g, e);
+              if (!(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) s[t][e] = -INFINITY;
+            }
+          }
+          const float mx = quad_max(max8(s[t]));
+          // the accumulators are rescaled only when some query of the tile saw a new maximum (wave-uniform branch)
+          if (__builtin_amdgcn_ballot_w64(mx > m[t]) != 0ull) {
+            const float mn = vmax(m[t], mx);
+            const float mns = mn == -INFINITY ? 0.f : mn * sc2;   // nothing visible yet: every exp2 below gives 0
+            const float alpha = fexp2(fmaf(m[t], sc2, -mns));
+            l[t] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ot[t][0][r] *= alpha; ot[t][1][r] *= alpha; }
+            m[t] = mn;
+            ms[t] = mns;
+          }
+          float sum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[t][e] = fexp2(fmaf(s[t][e], sc2, -ms[t])); sum += s[t][e]; }
+          l[t] += quad_sum(sum);
+          if (thr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned hh = drop_pair(rowc[t][e] + k0c);
+              s[t][e] = keep_lo(hh, thr) ? s[t][e] : 0.f;
+              s[t][e + 4] = keep_hi(hh, thr) ? s[t][e + 4] : 0.f;
+            }
           }
         }
-        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = quad_max(mx);
-        const float mn = fmaxf(m[t], mx);
-        const bool dead = mn == -INFINITY;                 // nothing visible yet for this query
-        const float alpha = dead ? 1.f : fexp2(m[t] - mn);
-        float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = dead ? 0.f : fexp2(s[e] - mn); sum += s[e]; }
-        sum = quad_sum(sum);
-        l[t] = l[t] * alpha + sum;
-        m[t] = mn;
-        if (p.drop_thr) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) s[e] *= drop_mult2(p, drow[t], k0 + slot32(g, e));
+        for (int t = T0; t < T1; ++t) {
+          const bf16x8 pf = pack8(s[t]);
+          ot[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, pf, ot[t][0], 0, 0, 0);
+          ot[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, pf, ot[t][1], 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ot[t][0][r] *= alpha; ot[t][1][r] *= alpha; }
-        const bf16x8 pf = pack8(s);
-        ot[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, pf, ot[t][0], 0, 0, 0);
-        ot[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, pf, ot[t][1], 0, 0, 0);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (JOINT) {
+        if (cls[0] == TILE_FULL && cls[1] == TILE_FULL) body(std::false_type{}, I0{}, I2{});
+        else body(std::true_type{}, I0{}, I2{});
+      } else {
+        if (cls[0] == TILE_FULL) body(std::false_type{}, I0{}, I1{});
+        else if (cls[0] == TILE_MIXED) body(std::true_type{}, I0{}, I1{});
+        if (cls[1] == TILE_FULL) body(std::false_type{}, I1{}, I2{});
+        else if (cls[1] == TILE_MIXED) body(std::true_type{}, I1{}, I2{});
       }
     }
+    if (more) EVT_TILE_STORE(Ks[buf ^ 1], Vs[buf ^ 1]);
+    __syncthreads();
   }
   bf16_t* O = reinterpret_cast<bf16_t*>(p.out) + b * p.ob + h * p.oh;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (qi[t] >= p.L) continue;
-    const float inv = l[t] > 0.f ? 1.f / l[t] : 0.f;
+    const float inv = l[t] > 0.f ? p.keep_scale / l[t] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       bf16_t o4[4];
@@ -240,31 +325,39 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(AP p) {
       for (int r = 0; r < 4; ++r) o4[r] = f2bf(ot[t][mt][r] * inv);
       *reinterpret_cast<uint2*>(O + qi[t] * p.ol + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
-    if (g == 0) p.lse[((long)b * p.H + h) * p.L + qi[t]] = (m[t] + __log2f(l[t])) * LN2;
+    if (g == 0) p.lse[((long)b * p.H + h) * p.L + qi[t]] = (m[t] * sc2 + __log2f(l[t])) * LN2;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // dQ (bf16): same ownership as forward; dQ^T += K^T dS^T
+// dS = keep_scale * P o (M o dP_drop - delta / keep_scale): the constant factors go to the epilogue
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <bool JOINT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-  const int qblk = blockIdx.x * 128;
+  // 1-D grid, LONGEST BLOCKS FIRST: query block nqb-1 (walks every key) of all (b, h), then nqb-2, ... -- the short text
+  // blocks fill the tail (with the (b, h)-major order the last dispatched 16-iteration blocks ran on an empty chip)
+  const int BH = p.B * p.H;
+  const int bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int qblk = ((p.L + 127) / 128 - 1 - blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
   const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
   const float sc2 = p.scale * LOG2E;
+  const unsigned thr = p.drop_thr;
+  const float inv_ks = 1.f / p.keep_scale;
   bf16x8 qf[2], dof[2];
   f32x4 dqt[2][2];
-  float lse2[2], dl[2];
+  float lse2[2], dlk[2];
   int qi[2], qt0[2];
-  unsigned drow[2];
+  unsigned rowc[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     qt0[t] = qblk + wave * 32 + t * 16;
@@ -273,21 +366,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
     qf[t] = ld8(Q + qc * p.sl + g * 8);
     dof[t] = ld8(dO + qc * p.ol + g * 8);
     lse2[t] = p.lse[((long)b * p.H + h) * p.L + qc] * LOG2E;
-    dl[t] = p.delta[((long)b * p.H + h) * p.L + qc];
+    dlk[t] = p.delta[((long)b * p.H + h) * p.L + qc] * inv_ks;
     dqt[t][0] = dqt[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    drow[t] = drop_row(p, blockIdx.y, qi[t]);
+    const unsigned row = thr ? drop_row(p, (unsigned)bh, qi[t]) : 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rowc[t][e] = row + __umul24((unsigned)(g * 4 + e), DROP_KC);
   }
   const int qlast = min(qblk + 127, p.L - 1);
   const int kmax = (qlast < p.x_len) ? p.x_len : qlast + 1;
-  for (int kb = 0; kb < kmax; kb += 64) {
-    __syncthreads();
-    {
-      const int r = tid >> 2, c8 = tid & 3;
-      const int kj = min(kb + r, p.L - 1);
-      *reinterpret_cast<uint4*>(Ks + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(K + kj * p.sl + c8 * 8);
-      *reinterpret_cast<uint4*>(Vs + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(V + kj * p.sl + c8 * 8);
-    }
-    __syncthreads();
+  EVT_TILE_REGS;
+  EVT_TILE_LOAD(K, p.sl, V, p.sl, 0);
+  EVT_TILE_STORE(Ks[0], Vs[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = 0; kb < kmax; kb += 64, buf ^= 1) {
+    const bool more = kb + 64 < kmax;
+    if (more) EVT_TILE_LOAD(K, p.sl, V, p.sl, kb + 64);
+    const bf16_t* Kc = Ks[buf];
+    const bf16_t* Vc = Vs[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int k0 = kb + sb * 32;
@@ -295,38 +391,78 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 ka0 = ld8(Ks + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 ka1 = ld8(Ks + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16x8 va0 = ld8(Vs + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 va1 = ld8(Vs + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* krow = Ks + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const bf16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
+      const bf16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const bf16x8 va0 = ld8(Vc + (sb * 32 + n) * PITCH + g * 8);
+      const bf16x8 va1 = ld8(Vc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const bf16_t* krow = Kc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
       const bf16x8 kt0 = tr2(krow, krow + 16 * PITCH);
       const bf16x8 kt1 = tr2(krow + 16, krow + 16 * PITCH + 16);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (cls[t] == TILE_EMPTY) continue;
+      const unsigned k0c = __umul24((unsigned)k0, DROP_KC);
+      auto body = [&](auto masked_tag, auto t0_tag, auto t1_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
-        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, dof[t], z, 0, 0, 0);
-        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, dof[t], z, 0, 0, 0);
-        float ds[8];
+        f32x4 s0[2], s1[2], d0[2], d1[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int kj = k0 + slot32(g, e);
-          float pr = fexp2((e < 4 ? s0[e] : s1[e - 4]) * sc2 - lse2[t]);
-          if (cls[t] == TILE_MIXED && !(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) pr = 0.f;
-          float dp = (e < 4 ? d0[e] : d1[e - 4]);
-          if (p.drop_thr) dp *= drop_mult2(p, drow[t], kj);
-          ds[e] = pr * (dp - dl[t]) * p.scale;
+        for (int t = T0; t < T1; ++t) {
+          s0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
+          s1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
+          d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, dof[t], z, 0, 0, 0);
+          d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, dof[t], z, 0, 0, 0);
         }
-        const bf16x8 dsf = pack8(ds);
-        dqt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsf, dqt[t][0], 0, 0, 0);
-        dqt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsf, dqt[t][1], 0, 0, 0);
+        float ds[2][8];
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+          float pr[8], dp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pr[e] = fexp2(fmaf(e < 4 ? s0[t][e] : s1[t][e - 4], sc2, -lse2[t]));
+            dp[e] = e < 4 ? d0[t][e] : d1[t][e - 4];
+          }
+          if (MASKED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int kj = k0 + slot32(g, e);
+              if (!(kj < p.L && visible(qi[t], kj, p.x_len, xl, yl))) pr[e] = 0.f;
+            }
+          }
+          if (thr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned hh = drop_pair(rowc[t][e] + k0c);
+              dp[e] = keep_lo(hh, thr) ? dp[e] : 0.f;
+              dp[e + 4] = keep_hi(hh, thr) ? dp[e + 4] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ds[t][e] = pr[e] * (dp[e] - dlk[t]);
+        }
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+          const bf16x8 dsf = pack8(ds[t]);
+          dqt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsf, dqt[t][0], 0, 0, 0);
+          dqt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsf, dqt[t][1], 0, 0, 0);
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (JOINT) {
+        if (cls[0] == TILE_FULL && cls[1] == TILE_FULL) body(std::false_type{}, I0{}, I2{});
+        else body(std::true_type{}, I0{}, I2{});
+      } else {
+        if (cls[0] == TILE_FULL) body(std::false_type{}, I0{}, I1{});
+        else if (cls[0] == TILE_MIXED) body(std::true_type{}, I0{}, I1{});
+        if (cls[1] == TILE_FULL) body(std::false_type{}, I1{}, I2{});
+        else if (cls[1] == TILE_MIXED) body(std::true_type{}, I1{}, I2{});
       }
     }
+    if (more) EVT_TILE_STORE(Ks[buf ^ 1], Vs[buf ^ 1]);
+    __syncthreads();
   }
   bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dq) + b * p.sb + h * p.sh;
+  const float fin = p.scale * p.keep_scale;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (qi[t] >= p.L) continue;
@@ -334,29 +470,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(AP p) {
     for (int mt = 0; mt < 2; ++mt) {
       bf16_t o4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = f2bf(dqt[t][mt][r]);
+      for (int r = 0; r < 4; ++r) o4[r] = f2bf(dqt[t][mt][r] * fin);
       *reinterpret_cast<uint2*>(dQ + qi[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dK/dV (bf16): block = 4 waves x 2 key tiles (128 keys); query blocks of 64 through LDS
+// dK/dV (bf16): block = 4 waves x 2 key tiles (128 keys); query blocks of 64 through LDS.  A lane's two key tiles are
+// the keys kp and kp + 16 of one dropout hash; the per-query hash part comes from an LDS table filled per query block.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Os[64 * PITCH];
-  __shared__ float lse_s[64], dl_s[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <bool JOINT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16(AP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t Os[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][64];
+  __shared__ __attribute__((aligned(16))) float dl_s[2][64];
+  __shared__ __attribute__((aligned(16))) unsigned row_s[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-  const int kblk = blockIdx.x * 128;
+  // 1-D grid, longest blocks first: key block 0 (seen by every query) of all (b, h), then 1, ...
+  const int BH = p.B * p.H;
+  const int bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int kblk = (blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
   const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
   const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
   const float sc2 = p.scale * LOG2E;
+  const unsigned thr = p.drop_thr;
+  const float inv_ks = 1.f / p.keep_scale;
   bf16x8 kf[2], vf[2];
   f32x4 dkt[2][2], dvt[2][2];
   int kj[2], kt0[2];
@@ -369,21 +514,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
     vf[t] = ld8(V + kc * p.sl + g * 8);
     dkt[t][0] = dkt[t][1] = dvt[t][0] = dvt[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const unsigned kpc = __umul24((unsigned)kj[0], DROP_KC);        // kj[0] has bit 4 clear: it is the pair's kp
   const int q_begin = (kblk >= p.x_len) ? (kblk / 64) * 64 : 0;
-  for (int qb = q_begin; qb < p.L; qb += 64) {
-    __syncthreads();
-    {
-      const int r = tid >> 2, c8 = tid & 3;
-      const int qq = min(qb + r, p.L - 1);
-      *reinterpret_cast<uint4*>(Qs + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(Q + qq * p.sl + c8 * 8);
-      *reinterpret_cast<uint4*>(Os + r * PITCH + c8 * 8) = *reinterpret_cast<const uint4*>(dO + qq * p.ol + c8 * 8);
-      if (tid < 64) {
-        const int q2 = min(qb + tid, p.L - 1);
-        lse_s[tid] = p.lse[((long)b * p.H + h) * p.L + q2] * LOG2E;
-        dl_s[tid] = p.delta[((long)b * p.H + h) * p.L + q2];
-      }
+  EVT_TILE_REGS;
+  float lse_r = 0.f, dl_r = 0.f;
+  unsigned row_r = 0u;
+  auto load_rows = [&](int qb) {
+    if (tid < 64) {
+      const int q2 = min(qb + tid, p.L - 1);
+      lse_r = p.lse[((long)b * p.H + h) * p.L + q2] * LOG2E;
+      dl_r = p.delta[((long)b * p.H + h) * p.L + q2] * inv_ks;
+      row_r = thr ? drop_row(p, (unsigned)bh, qb + tid) : 0u;
     }
-    __syncthreads();
+  };
+  auto store_rows = [&](int bi) {
+    if (tid < 64) { lse_s[bi][tid] = lse_r; dl_s[bi][tid] = dl_r; row_s[bi][tid] = row_r; }
+  };
+  EVT_TILE_LOAD(Q, p.sl, dO, p.ol, q_begin);
+  load_rows(q_begin);
+  EVT_TILE_STORE(Qs[0], Os[0]);
+  store_rows(0);
+  __syncthreads();
+  int buf = 0;
+  for (int qb = q_begin; qb < p.L; qb += 64, buf ^= 1) {
+    const bool more = qb + 64 < p.L;
+    if (more) { EVT_TILE_LOAD(Q, p.sl, dO, p.ol, qb + 64); load_rows(qb + 64); }
+    const bf16_t* Qc = Qs[buf];
+    const bf16_t* Oc = Os[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int q0 = qb + sb * 32;
@@ -391,51 +548,92 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(q0, q0 + 31, kt0[t], kt0[t] + 15, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 qa0 = ld8(Qs + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 qa1 = ld8(Qs + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16x8 oa0 = ld8(Os + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 oa1 = ld8(Os + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* qrow = Qs + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-      const bf16_t* orow = Os + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const bf16x8 qa0 = ld8(Qc + (sb * 32 + n) * PITCH + g * 8);
+      const bf16x8 qa1 = ld8(Qc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const bf16x8 oa0 = ld8(Oc + (sb * 32 + n) * PITCH + g * 8);
+      const bf16x8 oa1 = ld8(Oc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const bf16_t* qrow = Qc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const bf16_t* orow = Oc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
       const bf16x8 qt0 = tr2(qrow, qrow + 16 * PITCH), qt1 = tr2(qrow + 16, qrow + 16 * PITCH + 16);
       const bf16x8 dt0 = tr2(orow, orow + 16 * PITCH), dt1 = tr2(orow + 16, orow + 16 * PITCH + 16);
       float lq[8], dq8[8];
-      unsigned drw[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        lq[e] = lse_s[sb * 32 + slot32(g, e)];
-        dq8[e] = dl_s[sb * 32 + slot32(g, e)];
-        drw[e] = p.drop_thr ? drop_row(p, blockIdx.y, q0 + slot32(g, e)) : 0u;
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (cls[t] == TILE_EMPTY) continue;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[t], z, 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[t], z, 0, 0, 0);
-        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa0, vf[t], z, 0, 0, 0);
-        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa1, vf[t], z, 0, 0, 0);
-        float pr[8], ds[8];
+      unsigned hh[8];
+      {
+        const f32x4 la = *reinterpret_cast<const f32x4*>(&lse_s[buf][sb * 32 + g * 4]);
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(&lse_s[buf][sb * 32 + 16 + g * 4]);
+        const f32x4 da = *reinterpret_cast<const f32x4*>(&dl_s[buf][sb * 32 + g * 4]);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(&dl_s[buf][sb * 32 + 16 + g * 4]);
+        const uint4 ra = *reinterpret_cast<const uint4*>(&row_s[buf][sb * 32 + g * 4]);
+        const uint4 rb = *reinterpret_cast<const uint4*>(&row_s[buf][sb * 32 + 16 + g * 4]);
+        const unsigned rr[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int qi = q0 + slot32(g, e);
-          float pe = fexp2((e < 4 ? s0[e] : s1[e - 4]) * sc2 - lq[e]);
-          if (cls[t] == TILE_MIXED && !(qi < p.L && kj[t] < p.L && visible(qi, kj[t], p.x_len, xl, yl))) pe = 0.f;
-          const float dm = p.drop_thr ? drop_mult2(p, drw[e], kj[t]) : 1.f;
-          const float dp = (e < 4 ? d0[e] : d1[e - 4]);
-          ds[e] = pe * (dp * dm - dq8[e]) * p.scale;
-          pr[e] = pe * dm;
+          lq[e] = e < 4 ? la[e] : lb[e - 4];
+          dq8[e] = e < 4 ? da[e] : db[e - 4];
+          hh[e] = thr ? drop_pair(rr[e] + kpc) : 0u;
         }
-        const bf16x8 pf = pack8(pr), dsf = pack8(ds);
-        dvt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pf, dvt[t][0], 0, 0, 0);
-        dvt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt1, pf, dvt[t][1], 0, 0, 0);
-        dkt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsf, dkt[t][0], 0, 0, 0);
-        dkt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt1, dsf, dkt[t][1], 0, 0, 0);
+      }
+      auto body = [&](auto masked_tag, auto t0_tag, auto t1_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s0[2], s1[2], d0[2], d1[2];
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+          s0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[t], z, 0, 0, 0);
+          s1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[t], z, 0, 0, 0);
+          d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa0, vf[t], z, 0, 0, 0);
+          d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa1, vf[t], z, 0, 0, 0);
+        }
+        float pr[2][8], ds[2][8];
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float pe = fexp2(fmaf(e < 4 ? s0[t][e] : s1[t][e - 4], sc2, -lq[e]));
+            if (MASKED) {
+              const int qi = q0 + slot32(g, e);
+              if (!(qi < p.L && kj[t] < p.L && visible(qi, kj[t], p.x_len, xl, yl))) pe = 0.f;
+            }
+            float dp = e < 4 ? d0[t][e] : d1[t][e - 4];
+            float pk = pe;
+            if (thr) {
+              const bool keep = t == 0 ? keep_lo(hh[e], thr) : keep_hi(hh[e], thr);
+              dp = keep ? dp : 0.f;
+              pk = keep ? pe : 0.f;
+            }
+            ds[t][e] = pe * (dp - dq8[e]);
+            pr[t][e] = pk;
+          }
+        }
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+          const bf16x8 pf = pack8(pr[t]), dsf = pack8(ds[t]);
+          dvt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pf, dvt[t][0], 0, 0, 0);
+          dvt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt1, pf, dvt[t][1], 0, 0, 0);
+          dkt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsf, dkt[t][0], 0, 0, 0);
+          dkt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt1, dsf, dkt[t][1], 0, 0, 0);
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (JOINT) {
+        if (cls[0] == TILE_FULL && cls[1] == TILE_FULL) body(std::false_type{}, I0{}, I2{});
+        else body(std::true_type{}, I0{}, I2{});
+      } else {
+        if (cls[0] == TILE_FULL) body(std::false_type{}, I0{}, I1{});
+        else if (cls[0] == TILE_MIXED) body(std::true_type{}, I0{}, I1{});
+        if (cls[1] == TILE_FULL) body(std::false_type{}, I1{}, I2{});
+        else if (cls[1] == TILE_MIXED) body(std::true_type{}, I1{}, I2{});
       }
     }
+    if (more) { EVT_TILE_STORE(Qs[buf ^ 1], Os[buf ^ 1]); store_rows(buf ^ 1); }
+    __syncthreads();
   }
   bf16_t* dK = reinterpret_cast<bf16_t*>(p.dk) + b * p.sb + h * p.sh;
   bf16_t* dV = reinterpret_cast<bf16_t*>(p.dv) + b * p.sb + h * p.sh;
+  const float fk = p.scale * p.keep_scale, fv = p.keep_scale;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (kj[t] >= p.L) continue;
@@ -443,7 +641,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(AP p) {
     for (int mt = 0; mt < 2; ++mt) {
       bf16_t a4[4], b4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a4[r] = f2bf(dkt[t][mt][r]); b4[r] = f2bf(dvt[t][mt][r]); }
+      for (int r = 0; r < 4; ++r) { a4[r] = f2bf(dkt[t][mt][r] * fk); b4[r] = f2bf(dvt[t][mt][r] * fv); }
       *reinterpret_cast<uint2*>(dK + kj[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(a4);
       *reinterpret_cast<uint2*>(dV + kj[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(b4);
     }
@@ -594,6 +792,9 @@ __global__ void attn_bwd_dkv_f32(AP p) {
   for (int d = 0; d < DH; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
 }
 
+// two-tile bodies (more instruction-level parallelism, more registers) or one tile at a time: measurement switch
+int g_attn_joint = getenv("EVT_ATTN_JOINT") ? atoi(getenv("EVT_ATTN_JOINT")) : 0;   // measured: one tile at a time is 4-9 % faster
+
 int check(const evt_attn_params* a) {
   if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return EVT_EINVAL;
   if (a->dtype == EVT_DT_BF16) {
@@ -616,9 +817,11 @@ AP make_ap(const evt_attn_params* a) {
   p.ob = a->o_stride_b; p.ol = a->o_stride_l; p.oh = a->o_stride_h;
   p.scale = 1.0f / sqrtf((float)a->D);
   if (a->dropout_p > 0.f) {
-    const double thr = (double)a->dropout_p * 4294967296.0;
-    p.drop_thr = thr >= 4294967295.0 ? 4294967295u : (unsigned)thr;
-    p.keep_scale = 1.0f / (1.0f - a->dropout_p);
+    unsigned thr16 = (unsigned)((double)a->dropout_p * 65536.0 + 0.5);
+    if (thr16 < 1u) thr16 = 1u;
+    if (thr16 > 65535u) thr16 = 65535u;
+    p.drop_thr = thr16 << 16;
+    p.keep_scale = 65536.0f / (float)(65536u - thr16);
   } else { p.drop_thr = 0u; p.keep_scale = 1.f; }
   p.seed = a->seed;
   return p;
@@ -627,6 +830,8 @@ AP make_ap(const evt_attn_params* a) {
 }  // namespace
 
 extern "C" {
+
+void evt_debug_attn_variant(int joint) { g_attn_joint = joint; }
 
 int evt_attn_prefixlm_fwd(const evt_attn_params* a, const void* q, const void* k, const void* v, const int32_t* x_lens,
                           const int32_t* y_lens, void* o, float* lse, void* stream) {
@@ -637,7 +842,8 @@ int evt_attn_prefixlm_fwd(const evt_attn_params* a, const void* q, const void* k
   p.q = q; p.k = k; p.v = v; p.out = o; p.lse = lse; p.x_lens = x_lens; p.y_lens = y_lens;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == EVT_DT_BF16) {
-    hipLaunchKernelGGL(attn_fwd_bf16, dim3((a->L + 127) / 128, a->B * a->H), dim3(256), 0, st, p);
+    if (g_attn_joint) hipLaunchKernelGGL(attn_fwd_bf16<true>, dim3(((a->L + 127) / 128) * a->B * a->H), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_bf16<false>, dim3(((a->L + 127) / 128) * a->B * a->H), dim3(256), 0, st, p);
   } else {
     const long total = (long)a->B * a->H * a->L;
     const int blocks = (int)((total + 63) / 64);
@@ -662,8 +868,14 @@ int evt_attn_prefixlm_bwd(const evt_attn_params* a, const void* q, const void* k
   const int dblocks = (int)((total * lpr + 255) / 256);
   if (a->dtype == EVT_DT_BF16) {
     hipLaunchKernelGGL(attn_delta<bf16_t>, dim3(dblocks), dim3(256), 0, st, p, a->D);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16, dim3((a->L + 127) / 128, a->B * a->H), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16, dim3((a->L + 127) / 128, a->B * a->H), dim3(256), 0, st, p);
+    const dim3 grid(((a->L + 127) / 128) * a->B * a->H);
+    if (g_attn_joint) {
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16<true>, grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, grid, dim3(256), 0, st, p);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dkv_bf16<false>, grid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_bwd_dq_bf16<false>, grid, dim3(256), 0, st, p);
+    }
   } else {
     hipLaunchKernelGGL(attn_delta<float>, dim3(dblocks), dim3(256), 0, st, p, a->D);
     const int blocks = (int)((total + 63) / 64);

@@ -41,6 +41,9 @@ const char* evt_version(void);
  * product path) nothing is recorded and the library keeps no mutable state. */
 void evt_debug_kernel_tags(int32_t enable);
 const char* evt_last_kernel_tag(void);
+/* measurement switch of the bf16 attention kernels: 1 = both query/key tiles of a wave in one instruction stream
+ * , 0 = one tile at a time (fewer registers, more waves per SIMD; default).  Same results either way. */
+void evt_debug_attn_variant(int32_t joint);
 
 /* Scratch memory the caller must provide, in bytes, for the ops that take a workspace pointer; -1 for an unknown op or
  * a wrong dims count.  The library never allocates.

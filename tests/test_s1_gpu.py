@@ -31,19 +31,24 @@ ATTN_CASES = [  # B, H, x_len, y_len, x_lens, y_lens
 ]
 
 
-def _hash_keep(seed, bh, L_, thr):
-    """python mirror of drop_row / drop_mult2 in csrc/attention.hip (24-bit multiplies, xor-shifts, mod 2^32)"""
+def _hash_keep(seed, bh, L_, thr16):
+    """python mirror of drop_row / drop_pair / keep_lo / keep_hi in csrc/attention.hip (mod 2^32): one hash decides the
+    keys kp = k & ~16 (low 16 bits) and kp + 16 (high 16 bits) of a query"""
     M, M24 = 0xFFFFFFFF, 0xFFFFFF
     q = torch.arange(L_, dtype=torch.int64)[:, None]
     k = torch.arange(L_, dtype=torch.int64)[None, :]
-    a = ((bh << 11) & M) ^ q
-    row = (((a & M24) * 0x9E3779) & M) ^ seed ^ (a >> 7)
-    x = (row + ((k & M24) * 0x85EBCB & M)) & M
+    a = ((((bh << 11) & M) ^ q) + ((seed * 0x9E3779B1) & M)) & M
+    a = a ^ (a >> 16)
+    a = (a * 0x85EBCA6B) & M          # int64 wrap-around keeps the low 32 bits exact
+    a = a ^ (a >> 13)
+    a = (a * 0xC2B2AE35) & M
+    a = a ^ (a >> 16)
+    kp = k & ~16
+    x = (a + (((kp & M24) * 0x85EBCB) & M)) & M
     x = x ^ (x >> 15)
     x = ((((x & M24) * 0x2C1B3D) & M) ^ (x >> 9)) & M
-    x = (x ^ (x << 13)) & M
-    x = x ^ (x >> 17)
-    return x >= thr
+    f = torch.where((k & 16) != 0, x >> 16, x & 0xFFFF)
+    return f >= thr16
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -70,9 +75,9 @@ def test_attention_parity(gpu, case, dtype, dropout):
     s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(D)
     p = F.softmax(s.masked_fill(mask[:, None], float("-inf")), dim=-1)
     if dropout > 0:
-        thr = int(dropout * 4294967296.0)
-        keep = torch.stack([torch.stack([_hash_keep(seed, b * H + h, L_, thr) for h in range(H)]) for b in range(B)])
-        p = p * keep / (1 - dropout)
+        thr16 = int(dropout * 65536.0 + 0.5)
+        keep = torch.stack([torch.stack([_hash_keep(seed, b * H + h, L_, thr16) for h in range(H)]) for b in range(B)])
+        p = p * keep / (1 - thr16 / 65536.0)
     oo = torch.matmul(p, v).transpose(1, 2).reshape(B, L_, E)
     oo.backward(d_o)
     # HIP
