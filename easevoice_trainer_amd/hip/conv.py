@@ -231,13 +231,16 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
     TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape, m))
 
 
-def _fwd(slot, x, res, in_slope, out_act, out_slope):
+def _fwd(slot, x, res, in_slope, out_act, out_slope, out=None):
+    """`out`: optional preallocated contiguous [nseq, Lout, Cout] destination (e.g. one plane of a q|k|v buffer)"""
     m = slot.module
     if x.dim() != 3 or x.size(2) != m.cin or x.dtype != slot.bank.dtype or not x.is_contiguous():
         raise L.EvtError(f"conv input must be contiguous [nseq, L, {m.cin}] {slot.bank.dtype}, got "
                          f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
     nseq, lin = x.size(0), x.size(1)
-    y = torch.empty((nseq, m.lout(lin), m.cout), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((nseq, m.lout(lin), m.cout), dtype=x.dtype, device=x.device)
+    if y.shape != (nseq, m.lout(lin), m.cout) or y.dtype != x.dtype or not y.is_contiguous():
+        raise L.EvtError("conv output buffer must be contiguous [nseq, Lout, Cout] in the compute dtype")
     if res is not None and (res.shape != y.shape or not res.is_contiguous() or res.dtype != x.dtype):
         raise L.EvtError("residual must match the output")
     p = slot.params(nseq, lin, in_slope, out_act, out_slope)

@@ -33,6 +33,16 @@ def bump_rng(device):
     L.check(L.lib().evt_counter_inc(L.ptr(t), C.c_uint32(1), L.stream_ptr()), "evt_counter_inc")
 
 
+def grad_sink(p):
+    """fp32 arena gradient view of a runtime-managed parameter (runtime.ModelRuntime): a fused backward kernel adds its
+    parameter gradient there and returns None to autograd.  None for a parameter outside a runtime (stand-alone tests):
+    the caller then allocates a zeroed tensor and returns it the ordinary way."""
+    v = getattr(p, "_evt_grad_view", None)
+    if v is not None and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == p.numel() and v.device == p.device:
+        return v
+    return None
+
+
 def new_site() -> int:
     """a distinct dropout stream id per call site (module instance)"""
     return next(_SITES)
@@ -59,6 +69,7 @@ class ResDropLNFn(torch.autograd.Function):
                 "evt_res_dropout_ln_fwd")
         ctx.save_for_backward(x, y, gamma, mean, rstd, lens)
         ctx.cfg = (p, site, rps, rows, Cc)
+        ctx.sinks = (grad_sink(gamma), grad_sink(beta))
         return out
 
     @staticmethod
@@ -68,13 +79,19 @@ class ResDropLNFn(torch.autograd.Function):
         dout = dout.contiguous()
         dx = torch.empty_like(x)
         dy = torch.empty_like(x) if p > 0.0 else None
-        dgb = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)     # one fill for both accumulators
-        dgamma, dbeta = dgb[0], dgb[1]
+        sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
+        if sunk:
+            dgamma, dbeta = ctx.sinks
+        else:
+            dgb = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)     # one fill for both accumulators
+            dgamma, dbeta = dgb[0], dgb[1]
         seed = rng_counter(x.device)
         L.check(L.lib().evt_res_dropout_ln_bwd(L.dt_of(x), L.ptr(x), L.ptr(y), L.ptr(gamma), L.ptr(dout), L.ptr(mean),
                                                L.ptr(rstd), L.ptr(lens), rps, C.c_float(p), L.ptr(seed),
                                                C.c_uint32(site), L.ptr(dx), L.ptr(dy), L.ptr(dgamma), L.ptr(dbeta),
                                                C.c_int64(rows), Cc, L.stream_ptr()), "evt_res_dropout_ln_bwd")
+        if sunk:
+            dgamma = dbeta = None
         return dx, (dy if dy is not None else dx), dgamma, dbeta, None, None, None, None
 
 
@@ -129,6 +146,77 @@ class RelAttnFn(torch.autograd.Function):
 
 def rel_attention(qkv, emb_k, emb_v, lens, n_heads, window, p, site):
     return RelAttnFn.apply(qkv, emb_k, emb_v, lens, int(n_heads), int(window), float(p), int(site))
+
+
+class RelSelfAttnFn(torch.autograd.Function):
+    """The q / k / v projections (three 1x1 convs of the fused conv family, attentions.py:196-205 of the reference) AND the
+    fused relative-position attention core as ONE autograd node: x [B, T, C] bf16 -> [B, T, C].
+    Forward: three k = 1 conv launches write the planes of one [3, B, T, C] buffer, evt_relattn_fwd reads them through its
+    three row pointers (row stride C).  Backward: evt_relattn_bwd, three weight-gradient launches (each also produces the
+    bias gradient), three backward-data launches chained through their add-epilogue -- so the sum over the three
+    branches needs no element-wise launch.  (Through F.linear this was: two weight concatenations, a cast of the packed
+    weight, a vendor GEMM, two more GEMMs, a column-sum launch and the concatenation's backward per layer and step.)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, emb_k, emb_v, lens, slots, n_heads, window, p, site):
+        from . import conv as HC
+
+        B, T, Cc = x.shape
+        if x.dtype != torch.bfloat16 or not x.is_contiguous() or Cc % n_heads:
+            raise L.EvtError(f"relattn: contiguous bf16 [B, T, C] expected, got {tuple(x.shape)} {x.dtype}")
+        D = Cc // n_heads
+        ek, ev = emb_k.contiguous(), emb_v.contiguous()
+        qkv = torch.empty((3, B, T, Cc), dtype=x.dtype, device=x.device)
+        for i, s in enumerate(slots):
+            HC._fwd(s, x, None, 1.0, L.ACT_NONE, 1.0, out=qkv[i])
+        out = torch.empty((B, T, Cc), dtype=x.dtype, device=x.device)
+        lse = torch.empty((B * n_heads, T), dtype=torch.float32, device=x.device)
+        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), Cc, Cc, p, site, rng_counter(x.device).data_ptr())
+        L.check(L.lib().evt_relattn_fwd(C.byref(prm), L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(ek), L.ptr(ev),
+                                        L.ptr(lens), L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_relattn_fwd")
+        ctx.save_for_backward(x, qkv, out, lse, ek, ev, lens)
+        ctx.cfg = (slots, n_heads, window, p, site)
+        ctx.sinks = (grad_sink(emb_k), grad_sink(emb_v))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_o):
+        from . import conv as HC
+
+        x, qkv, out, lse, ek, ev, lens = ctx.saved_tensors
+        slots, n_heads, window, p, site = ctx.cfg
+        _, B, T, Cc = qkv.shape
+        d_o = d_o.contiguous()
+        dqkv = torch.empty_like(qkv)
+        sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
+        if sunk:
+            demb = ctx.sinks
+        else:
+            demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=x.device)   # one fill for both
+        delta = torch.empty_like(lse)
+        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), Cc, Cc, p, site,
+                              rng_counter(x.device).data_ptr())
+        L.check(L.lib().evt_relattn_bwd(C.byref(prm), L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(out), L.ptr(d_o),
+                                        L.ptr(lse), L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(dqkv[0]), L.ptr(dqkv[1]),
+                                        L.ptr(dqkv[2]), L.ptr(demb[0]), L.ptr(demb[1]), L.ptr(delta), L.stream_ptr()),
+                "evt_relattn_bwd")
+        dx = None
+        for i, s in enumerate(slots):
+            if s.bank.weight_grads:
+                HC._bwd_weight(s, x, dqkv[i], None, B, T, 1.0, L.ACT_NONE, 1.0)
+            if ctx.needs_input_grad[0]:
+                dx = HC._bwd_data(s, dqkv[i], None, x, dx, B, T, 1.0, L.ACT_NONE, 1.0)
+        if sunk:
+            return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, demb[0], demb[1], None, None, None, None, None, None
+
+
+def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site):
+    slots = (conv_q._slot, conv_k._slot, conv_v._slot)
+    if any(s is None for s in slots):
+        raise L.EvtError("rel_self_attention before WeightBank.attach(); there is no eager fallback")
+    return RelSelfAttnFn.apply(x, slots[0].bank.anchor, emb_k, emb_v, lens, slots, int(n_heads), int(window), float(p),
+                               int(site))
 
 
 class WNResidualFn(torch.autograd.Function):

@@ -15,7 +15,7 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import EvtConv1d
-from ..hip.enc import new_site, rel_attention, relu_dropout, res_drop_ln
+from ..hip.enc import new_site, rel_self_attention, relu_dropout, res_drop_ln
 
 
 class LayerNorm(nn.Module):
@@ -72,9 +72,9 @@ class MultiHeadAttention(nn.Module):
         self.channels, self.out_channels, self.n_heads = channels, out_channels, n_heads
         self.p_dropout, self.window_size = p_dropout, window_size
         self.k_channels = channels // n_heads
-        self.conv_q = PointwiseConv(channels, channels)
-        self.conv_k = PointwiseConv(channels, channels)
-        self.conv_v = PointwiseConv(channels, channels)
+        self.conv_q = pointwise(channels, channels)
+        self.conv_k = pointwise(channels, channels)
+        self.conv_v = pointwise(channels, channels)
         self.conv_o = pointwise(channels, out_channels)
         self.drop = nn.Dropout(p_dropout)
         if window_size is not None:
@@ -122,19 +122,18 @@ class MultiHeadAttention(nn.Module):
     def fused_ok(self, x, c):
         """self-attention with relative window in bf16 on the GPU -> csrc/relattn.hip"""
         return (x is c and self.window_size is not None and x.is_cuda and x.dtype == torch.bfloat16
+                and x.is_contiguous() and isinstance(self.conv_q, PointwiseEvtConv)
                 and self.k_channels % 32 == 0 and self.k_channels <= 128 and 2 * self.window_size + 1 <= 16)
 
     def forward(self, x, c, attn_mask=None, lens=None):
         """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend).
         With `lens` [B] int32 (live frames, the mask being lens x lens) and bf16 self-attention, the whole core --
-        scores, relative logits, mask, softmax, dropout, values, relative values -- is one fused launch on a packed
-        q|k|v projection (one GEMM instead of three)."""
+        scores, relative logits, mask, softmax, dropout, values, relative values -- is one fused launch behind the three
+        1x1 projections, all of it one autograd node (hip/enc.py::RelSelfAttnFn)."""
         if lens is not None and self.fused_ok(x, c):
-            w = torch.cat([self.conv_q.weight, self.conv_k.weight, self.conv_v.weight], dim=0).squeeze(-1)
-            bias = torch.cat([self.conv_q.bias, self.conv_k.bias, self.conv_v.bias], dim=0)
-            qkv = F.linear(x, w, bias).to(torch.bfloat16).contiguous()
             p = self.drop.p if self.training else 0.0
-            out = rel_attention(qkv, self.emb_rel_k, self.emb_rel_v, lens, self.n_heads, self.window_size, p, self._site)
+            out = rel_self_attention(x, self.conv_q, self.conv_k, self.conv_v, self.emb_rel_k, self.emb_rel_v, lens,
+                                     self.n_heads, self.window_size, p, self._site)
             return self.conv_o(out)
         b, t_t, _ = x.shape
         t_s = c.size(1)

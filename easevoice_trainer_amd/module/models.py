@@ -21,6 +21,7 @@ from torch.nn import functional as F
 from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
 from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
+from ..hip.wn import wn_stack
 from . import commons
 from .attentions import Encoder, MultiHeadAttention, PointwiseConv, pointwise
 
@@ -83,12 +84,18 @@ class WN(nn.Module, _ComputeDtype):
         H = self.hidden_channels
         if lens is None:
             lens = x_mask.sum(dim=(1, 2)).to(torch.int32)
+        x = x.contiguous()
+        if x.is_cuda and not (self.training and self.drop.p > 0):
+            # the whole stack as one autograd node (hip/wn.py): same launches, no torch glue between them
+            g_lbh = None
+            if g is not None:
+                g_lbh = self.cond_layer(g).to(x.dtype).view(g.size(0), self.n_layers, 2 * H).transpose(0, 1).contiguous()
+            return wn_stack(x, g_lbh, lens, self.in_layers, self.res_skip_layers, H)
         gs = None
         if g is not None:
             g = self.cond_layer(g).to(x.dtype)     # [B, 2*H*n_layers]
             gs = unbind_rows(g.view(g.size(0), self.n_layers, 2 * H).transpose(0, 1).contiguous())
         output = None
-        x = x.contiguous()
         for i in range(self.n_layers):
             x_in = self.in_layers[i](x)
             acts = self.drop(GatedActFn.apply(x_in, gs[i] if gs is not None else None))

@@ -186,6 +186,11 @@ class ModelRuntime:
             if hasattr(m, "_slot"):
                 conv_owned.update(id(p) for p in m.parameters(recurse=False))
         self._free = [(p, p.grad) for p in model.parameters() if id(p) not in conv_owned]
+        # Kernels that produce such a parameter's gradient themselves (LayerNorm gamma / beta, relative-position
+        # embeddings: fp32 atomics) accumulate straight into the arena view and hand autograd no tensor at all
+        # (hip/enc.py::grad_sink) -- no zero-filled scratch, no clone in AccumulateGrad, nothing to gather afterwards.
+        for p, view in self._free:
+            p._evt_grad_view = view
 
     def zero_grad(self):
         self.arena.zero_grad()

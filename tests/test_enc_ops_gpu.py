@@ -129,3 +129,54 @@ def test_relu_dropout(gpu):
     # the gradient is non-zero exactly where the output is: same mask both ways
     assert torch.equal(xr.grad != 0, y != 0)
     assert torch.allclose(xr.grad[y != 0].float(), torch.full_like(xr.grad[y != 0].float(), 1 / (1 - p)), rtol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_wn_stack_node(gpu, dtype):
+    """the WN stack as one autograd node (hip/wn.py::WNStackFn: in_layer conv, gate, res_skip conv, residual / skip
+    bookkeeping per layer; chained gradient adds; one conditioning-gradient buffer) against oracle/s2_step.py::wn
+    (modules.py:187-212 of the reference): output, dx, dg and every parameter gradient, ragged lengths."""
+    from easevoice_trainer_amd.hip import conv as HC
+    from easevoice_trainer_amd.module.models import WN
+    from oracle.s2_step import SD, wn
+
+    torch.manual_seed(11)
+    B, T, H, NL, GIN = 3, 77, 192, 4, 512
+    m = WN(H, 5, 1, NL, gin_channels=GIN).to(gpu)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.normal_(0, 0.05)
+    bank = HC.WeightBank(m, dtype, gpu)
+    bank.build_tables()
+    bank.fold()
+    lens = torch.tensor([T, 40, 5], device=gpu, dtype=torch.int32)
+    live = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    x = (torch.randn(B, T, H, device=gpu) * live)
+    g = torch.randn(B, GIN, device=gpu)
+    wgt = torch.randn(B, T, H, device=gpu)
+    if dtype == torch.bfloat16:
+        x, g = x.bfloat16().float(), g.bfloat16().float()
+    x, g = x.detach(), g.detach()
+    xg, gg = x.to(dtype).clone().requires_grad_(True), g.clone().requires_grad_(True)
+    out = m(xg, live.to(dtype), g=gg, lens=lens)
+    (out.float() * wgt).sum().backward()
+    bank.grads()
+    torch.cuda.synchronize()
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict(keep_vars=True).items()}
+    xr, gr = x.cpu().clone().requires_grad_(True), g.cpu().clone().requires_grad_(True)
+    ref = wn(SD(sd), xr.transpose(1, 2), live.cpu().transpose(1, 2), gr.unsqueeze(-1), NL, hidden=H).transpose(1, 2)
+    (ref * wgt.cpu()).sum().backward()
+    tol = 2e-3 if dtype == torch.float32 else 6e-2
+
+    def close(a, b, name):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-6)
+        assert err < tol, f"{name}: rel err {err:.3e} (tol {tol})"
+
+    close(out, ref, "out")
+    close(xg.grad.float() * live, xr.grad * live.cpu(), "dx")
+    close(gg.grad, gr.grad, "dg")
+    for k, p_ in m.named_parameters():
+        close(p_.grad, sd[k].grad, k)

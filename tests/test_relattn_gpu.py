@@ -96,3 +96,62 @@ def test_relattn_dropout_consistency(gpu):
         out0 = E.rel_attention(qkv.detach(), ek.detach(), ev.detach(), lens, H, w, 0.0, 5)
     assert not torch.equal(out0, out)
     assert abs(out.float().mean().item() - out0.float().mean().item()) < 0.05
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 2, 96), (3, 200, 2, 96)])
+def test_self_attention_block_parity(gpu, shape):
+    """MultiHeadAttention (q / k / v / o projections + relative attention core, attentions.py:179-292) through the fused
+    node hip/enc.py::RelSelfAttnFn (three 1x1 conv launches + evt_relattn_*; chained backward-data launches, fused bias
+    gradients) against oracle/s2_step.py::mha on the same bf16-rounded weights and inputs: output, dx and every
+    parameter gradient."""
+    from easevoice_trainer_amd.hip import conv as HC
+    from easevoice_trainer_amd.module.attentions import MultiHeadAttention
+    from oracle.s2_step import SD, mha
+
+    B, T, H, D = shape
+    w, C = 4, H * D
+    torch.manual_seed(T)
+    m = MultiHeadAttention(C, C, H, p_dropout=0.0, window_size=w).to(gpu)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if "conv" in n_:
+                p_.copy_(p_.bfloat16().float())          # the kernels see bf16 weights: give the oracle the same values
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.1)
+                p_.copy_(p_.bfloat16().float())
+    bank = HC.WeightBank(m, torch.bfloat16, gpu)
+    bank.build_tables()
+    bank.fold()
+    x = (torch.randn(B, T, C, device=gpu) * 1.2).bfloat16()
+    lens = torch.tensor([T, max(3, T // 2), 1][:B], device=gpu, dtype=torch.int32)
+    live = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)     # [B, T, 1]
+    x = (x.float() * live).bfloat16()
+    wgt = torch.randn(B, T, C, device=gpu)
+
+    xg = x.clone().requires_grad_(True)
+    out = m(xg, xg, None, lens=lens)
+    ((out.float() * live) * wgt).sum().backward()
+    bank.grads()
+    torch.cuda.synchronize()
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict(keep_vars=True).items()}
+    xr = x.float().cpu().requires_grad_(True)
+    lv = live.cpu().squeeze(-1)
+    mask = lv[:, None, :, None] * lv[:, None, None, :]
+    ref = mha(SD(sd), xr.transpose(1, 2), xr.transpose(1, 2), mask, H, window=w).transpose(1, 2)
+    ((ref * live.cpu()) * wgt.cpu()).sum().backward()
+
+    def close(a, b, name, tol=3e-2):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-6)
+        assert err < tol, f"{name}: rel err {err:.3e} shape={shape}"
+
+    close(out.float() * live, ref * live.cpu(), "out")
+    close(xg.grad.float() * live, xr.grad * live.cpu(), "dx")
+    for k, p_ in m.named_parameters():
+        if k == "conv_k.bias":
+            # a constant added to every key shifts all scores of a query alike: the softmax does not see it, the exact
+            # gradient is 0 and both sides hold rounding noise -- compare it with the size of the value-bias gradient
+            assert p_.grad.abs().max().item() < 2e-2 * sd["conv_v.bias"].grad.abs().max().item(), k
+            continue
+        close(p_.grad, sd[k].grad, k)
