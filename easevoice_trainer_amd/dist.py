@@ -4,10 +4,18 @@ What the reference does (src/train/sovits.py:321-322, Lightning DDP in src/train
 default 25 MiB buckets over several hundred gradient tensors; the discriminator's reducer fires a second, discarded
 time during the generator backward; s1 all-reduces on each of the 4 accumulation micro-batches.
 
-MI355X-first: gradients of a model are ONE contiguous fp32 buffer, so the exchange is a handful of large collectives
-issued on a side HIP stream as soon as the backward that produced them is done:
-  * D gradients are reduced while the generator's forward/backward through D runs, G gradients while the optimiser
-    of D and the loss bookkeeping run (GradReducer.all_reduce(async_op=True) + wait()); nothing is reduced twice;
+MI355X-first: gradients of a model are ONE contiguous fp32 buffer whose sub-models are contiguous ranges, so the
+exchange is a handful of large collectives issued on a side HIP stream as soon as the backward that produced a range
+is done (train/s2_engine.py::_program drives this; the results equal the plain two-reduction step, tested on the GPU
+over gloo and on the CPU):
+  * s2 discriminators: in the D step the six sub-discriminators are differentiated one after the other (their graphs
+    are disjoint there); the ~31 MB range of sub-discriminator i is reduced while sub-discriminator i-1 runs its
+    backward; the D optimiser waits for the side stream;
+  * s2 generator: the autograd graph is cut at the vocoder's inputs; the backward through D and `dec` runs first, the
+    vocoder's 58 MB range is reduced under the flow / encoder backward, the remaining ~146 MB after it; nothing is
+    reduced twice (the reference's DDP reduces D a second, discarded time during the generator backward);
+  * s1: ONE reduction of the 310 MB arena per optimiser step, i.e. per four micro-batches (~0.2 s of compute);
+  * with HIP-graph replay the pieces are separate graphs and the collectives are issued between the replays;
   * bucket size defaults to 64 MiB: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so per-collective latency
     dominates small buckets; reduce-scatter + all-gather of a large bucket uses every link at once;
   * averaging (1/world) is folded into the AdamW launch (grad_scale), not a separate pass over the buffer.

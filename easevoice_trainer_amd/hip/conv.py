@@ -137,8 +137,10 @@ class WeightBank:
         """(Re)build the device descriptor tables.  Must be called after parameters (and their .grad
         buffers) have reached their final storage (ParamArena.flatten)."""
         items, rows = [], []
+        self._slot_rows = []
         for i, s in enumerate(self.slots):
             m = s.module
+            self._slot_rows.append((len(rows), len(rows) + s.layout.d0))
             v = m.v
             if v.grad is None:
                 v.grad = torch.zeros_like(v)
@@ -179,11 +181,27 @@ class WeightBank:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._held.clear()
 
-    def grads(self):
-        """dW images -> weight_v.grad / weight_g.grad (or weight.grad): ONE launch."""
+    def rows_of(self, modules):
+        """[lo, hi) of the row table covered by `modules` (EvtConv1d instances of this bank, contiguous in slot order):
+        lets a data-parallel step finish -- and start reducing -- the gradients of one sub-model while the backward of
+        the next is still running"""
+        idx = sorted(i for i, s in enumerate(self.slots) if any(s.module is m for m in modules))
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise L.EvtError("rows_of: the modules must be a contiguous, non-empty run of this bank's convolutions")
+        if self._items is None:
+            self.build_tables()
+        return self._slot_rows[idx[0]][0], self._slot_rows[idx[-1]][1]
+
+    def grads(self, lo=None, hi=None):
+        """dW images -> weight_v.grad / weight_g.grad (or weight.grad), ACCUMULATED (+=): one launch over the whole
+        model, or over the row range [lo, hi) of rows_of() -- every row must be visited exactly once per backward."""
         self.join_side()
-        L.check(L.lib().evt_wn_grad_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
-                "evt_wn_grad_multi")
+        lo = 0 if lo is None else lo
+        hi = self._nrows if hi is None else hi
+        if hi <= lo:
+            return
+        rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
+        L.check(L.lib().evt_wn_grad_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_grad_multi")
 
 
 TRACE = None   # profiling only (set_trace): (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch

@@ -630,6 +630,8 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             self.ssl_proj = nn.Conv1d(ssl_dim, ssl_dim, 1, stride=1)
         self.quantizer = ResidualVectorQuantizer(dimension=ssl_dim, n_q=1, bins=1024)
         self.freeze_quantizer = freeze_quantizer
+        self.split_backward = False      # set by a data-parallel S2Engine (see forward)
+        self._cut = None
 
     def _quantize(self, ssl_cl):
         """ssl_proj (fp32, no grad reaches it: models.py:912-921) + code look-up + x2 nearest upsample"""
@@ -717,7 +719,15 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
                 z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
             else:
                 z_slice = commons.slice_segments(z, ids_slice, self.segment_size)
-            o = self.dec(z_slice, g=ge)                                                        # [B, seg*hop, 1]
+            if self.split_backward and torch.is_grad_enabled():
+                # data-parallel step: the autograd graph is cut at the vocoder's inputs, so that the engine can run the
+                # backward of `dec` (and of the discriminators above it) first, start reducing those gradients, and
+                # continue into flow / encoders from the saved cut gradients (train/s2_engine.py)
+                z_cut, ge_cut = z_slice.detach().requires_grad_(True), ge.detach().requires_grad_(True)
+                self._cut = ((z_slice, z_cut), (ge, ge_cut))
+                o = self.dec(z_cut, g=ge_cut)
+            else:
+                o = self.dec(z_slice, g=ge)                                                    # [B, seg*hop, 1]
         commit_loss = torch.zeros((), device=dev)   # quantizer in eval mode: core_vq.py:311-316 adds nothing
         tr = lambda t: t.transpose(1, 2)
         y_mask_ncl = y_mask.transpose(1, 2)

@@ -50,6 +50,23 @@ class ParamArena:
         o = self.offsets[name]
         return o, o + numel
 
+    def range_of_prefix(self, prefix, stop_before=None):
+        """[lo, hi) floats of all parameters whose name starts with `prefix` (registration order keeps a sub-module's
+        parameters adjacent), optionally ending before the first parameter that starts with `stop_before`; hi is
+        aligned up like every parameter start.  Used to reduce one sub-model's gradients on their own."""
+        names = [n for n in self.names if n.startswith(prefix)]
+        if stop_before is not None:
+            cut = [i for i, n in enumerate(names) if n.startswith(stop_before)]
+            if cut:
+                names = names[:cut[0]]
+        if not names:
+            raise KeyError(prefix)
+        i0, i1 = self.names.index(names[0]), self.names.index(names[-1])
+        if self.names[i0:i1 + 1] != names:
+            raise ValueError(f"parameters of {prefix!r} are not adjacent in the arena")
+        hi = self.offsets[self.names[i1 + 1]] if i1 + 1 < len(self.names) else self.numel
+        return self.offsets[names[0]], hi
+
     def zero_grad(self):
         self.grad.zero_()
 
@@ -211,8 +228,23 @@ class ModelRuntime:
             self.bank.fold()
             self._fold_stamp = stamp
 
-    def finish_grads(self):
-        self.bank.grads()
+    def finish_conv_grads(self, modules):
+        """the convolution weight gradients of `modules` only (a contiguous run of the bank), e.g. one sub-discriminator
+        right after its backward; the final finish_grads(done=[...]) must then be told which row ranges are done"""
+        lo, hi = self.bank.rows_of(modules)
+        self.bank.grads(lo, hi)
+        return lo, hi
+
+    def finish_grads(self, done=()):
+        """`done`: row ranges already finished by finish_conv_grads() in this backward (each row exactly once)"""
+        if not done:
+            self.bank.grads()
+        else:
+            at = 0
+            for lo, hi in sorted(done):
+                self.bank.grads(at, lo)
+                at = hi
+            self.bank.grads(at, None)
         dst, src = [], []
         for p, view in self._free:
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():

@@ -9,6 +9,7 @@ Differences from the reference that do not change the arithmetic of the losses /
     are single launches over it; no `.item()` host syncs inside the step;
   * bf16 compute needs no GradScaler (the reference's fp16 autocast + GradScaler is SURVEY §8(f) N4).
 """
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Optional
@@ -52,6 +53,18 @@ class S2Engine:
         self.reducer = reducer  # dist.GradReducer or None
         self.optim_g = self.optim_d = None
         self.graphs_enabled = False
+        # data parallelism: gradients are reduced sub-model by sub-model on a side stream while the backward of the next
+        # sub-model runs (EVT_DP_OVERLAP=0: the two whole-arena reductions between the phases, nothing overlapped)
+        self.overlap = (reducer is not None and reducer.world > 1 and os.environ.get("EVT_DP_OVERLAP", "1") != "0")
+        if self.overlap:
+            self.net_g.split_backward = True
+            nd = len(self.net_d.discriminators)
+            self._d_ranges = [self.rt_d.arena.range_of_prefix(f"discriminators.{i}.") for i in range(nd)]
+            self._d_convs = [[m for m in d.modules() if hasattr(m, "_slot")] for d in self.net_d.discriminators]
+            # the vocoder's convolutions (conv_pre .. conv_post; its 1x1 conditioning layer is an autograd parameter and
+            # goes with the rest): ~58 MB of the generator's 205 MB, reduced under the flow / encoder backward
+            self._dec_convs = [m for n, m in self.net_g.dec.named_modules() if hasattr(m, "_slot")]
+            self._dec_range = self.rt_g.arena.range_of_prefix("dec.", stop_before="dec.cond.")
 
     # -- optimisers: 4 groups for G exactly as sovits.py:286-319 (text_embedding / encoder_text / mrte at a
     #    lower lr), everything that receives no gradient (ssl_proj) left out
@@ -87,7 +100,7 @@ class S2Engine:
     # Each phase has no host synchronisation and no per-step host argument, so with fixed batch shapes it is captured
     # once into a HIP graph and replayed (enable_graphs): ~4600 launches per step become three graph launches.
     # ------------------------------------------------------------------------------------------------------------
-    def _phase_a(self, st):
+    def _phase_a(self, st, backward=True):
         d, t = self.hps["data"], self.hps["train"]
         hop, seg = d["hop_length"], t["segment_size"]
         net_g, net_d, rt_g, rt_d = self.net_g, self.net_d, self.rt_g, self.rt_d
@@ -107,11 +120,16 @@ class S2Engine:
         # ---- discriminator step (sovits.py:497-507) ----
         rt_d.bank.weight_grads = True
         y_d_hat_r, y_d_hat_g, _, _ = net_d(st.y_seg, st.y_hat.detach())
+        if not backward:
+            st.d_losses = [discriminator_loss([r], [g]) for r, g in zip(y_d_hat_r, y_d_hat_g)]
+            st.d_done = []
+            st.loss_disc = torch.stack([l.detach() for l in st.d_losses]).sum()
+            return
         st.loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
         st.loss_disc.backward()
         rt_d.finish_grads()
 
-    def _phase_b(self, st):
+    def _phase_b(self, st, backward=True):
         t = self.hps["train"]
         net_d, rt_g, rt_d = self.net_d, self.rt_g, self.rt_d
         st.gss_d = rt_d.grad_sumsq() * (st.inv_world * st.inv_world)   # norm of the AVERAGED gradient, as DDP logs it
@@ -131,6 +149,8 @@ class S2Engine:
         st.loss_fm = feature_loss(fmap_r, fmap_g)
         st.loss_gen = generator_loss(st.y_d_hat_g)
         st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
+        if not backward:
+            return
         st.loss_gen_all.backward()
         rt_d.bank.weight_grads = True
         rt_g.finish_grads()
@@ -154,6 +174,70 @@ class S2Engine:
         if self.reducer is not None:
             self.reducer.all_reduce(arena.grad)
 
+    # ---- data-parallel variant of the phases: the same arithmetic cut into pieces at the points where a sub-model's
+    #      gradients are complete; `_program` pairs every piece with the reductions to start right after it ----
+    def _phase_a0(self, st):
+        """phase A up to the discriminator losses, one loss per sub-discriminator (their graphs are disjoint in the D
+        step: the inputs are detached), so that each can be differentiated -- and its gradients reduced -- on its own"""
+        self._phase_a(st, backward=False)
+
+    def _phase_a_bwd(self, st, i):
+        st.d_losses[i].backward()
+        st.d_done.append(self.rt_d.finish_conv_grads(self._d_convs[i]))
+        if len(st.d_done) == len(self._d_convs):
+            self.rt_d.finish_grads(done=st.d_done)
+
+    def _phase_b0(self, st):
+        """D optimiser, the generator's losses, and the backward through D and the vocoder (down to the cut)"""
+        self._phase_b(st, backward=False)
+        (st.loss_gen + st.loss_fm + st.loss_mel).backward()
+        self.rt_d.bank.weight_grads = True
+        st.g_done = [self.rt_g.finish_conv_grads(self._dec_convs)]
+
+    def _phase_b1(self, st):
+        """the rest of the generator's backward: KL term + the gradients saved at the cut -> flow, encoders"""
+        roots, grads = [st.loss_kl + st.kl_ssl * 1], [None]
+        for full, cut in self.net_g._cut:
+            if cut.grad is not None:
+                roots.append(full)
+                grads.append(cut.grad)
+        torch.autograd.backward(roots, grads)
+        self.net_g._cut = None
+        self.rt_g.finish_grads(done=st.g_done)
+
+    def _reduce_async(self, flat, lo, hi):
+        self.reducer.all_reduce(flat[lo:hi], async_op=True)
+
+    def _program(self):
+        """[(phase, host action after it)]: the phases are what a HIP graph captures, the actions run between them"""
+        if not self.overlap:
+            return [(self._phase_a, lambda: self._reduce(self.rt_d.arena)),
+                    (self._phase_b, lambda: self._reduce(self.rt_g.arena)), (self._phase_c, None)]
+        gd, gg, red = self.rt_d.arena.grad, self.rt_g.arena.grad, self.reducer
+        prog = [(self._phase_a0, None)]
+        order = list(reversed(range(len(self._d_convs))))          # the reference's engine would also end with d0
+        for n, i in enumerate(order):
+            lo, hi = self._d_ranges[i]
+            last = n == len(order) - 1
+
+            def after(lo=lo, hi=hi, last=last):
+                self._reduce_async(gd, lo, hi)
+                if last:
+                    red.wait()                                      # optim_d reads the reduced gradients
+            prog.append((lambda st, i=i: self._phase_a_bwd(st, i), after))
+        dlo, dhi = self._dec_range
+        prog.append((self._phase_b0, lambda: self._reduce_async(gg, dlo, dhi)))
+
+        def after_b1():
+            if dlo > 0:
+                self._reduce_async(gg, 0, dlo)
+            if dhi < gg.numel():
+                self._reduce_async(gg, dhi, gg.numel())
+            red.wait()
+        prog.append((self._phase_b1, after_b1))
+        prog.append((self._phase_c, None))
+        return prog
+
     def step(self, ssl, spec, spec_lengths, y, text, text_lengths, eps=None, ids_slice=None, do_opt=True,
              hook_after_d=None) -> S2Losses:
         """One GAN step.  Layouts as in the reference: ssl [B,768,T], spec [B,1025,T], y [B,1,T*hop], text [B,Tt]."""
@@ -162,11 +246,10 @@ class S2Engine:
         st = SimpleNamespace(ssl=ssl, spec=spec, spec_lengths=spec_lengths, y=y, text=text, text_lengths=text_lengths,
                              eps=eps, ids_slice_in=ids_slice, do_opt=do_opt, hook_after_d=hook_after_d,
                              inv_world=1.0 / self.reducer.world if self.reducer is not None else 1.0)
-        self._phase_a(st)
-        self._reduce(self.rt_d.arena)
-        self._phase_b(st)
-        self._reduce(self.rt_g.arena)
-        self._phase_c(st)
+        for phase, after in self._program():
+            phase(st)
+            if after is not None:
+                after()
         return self._result(st)
 
     # ---- HIP-graph replay of the step for repeated batch shapes ----
@@ -214,14 +297,12 @@ class S2Engine:
         for dst, src in zip(ent["static"], inputs):
             if dst is not None:
                 dst.copy_(src, non_blocking=True)
-        ga, gb, gc = ent["graphs"]
         self.optim_d._segments()    # scheduler changes reach the device tables (in place) before the replay
         self.optim_g._segments()
-        ga.replay()
-        self._reduce(self.rt_d.arena)
-        gb.replay()
-        self._reduce(self.rt_g.arena)
-        gc.replay()
+        for g, after in zip(ent["graphs"], ent["after"]):
+            g.replay()
+            if after is not None:
+                after()
         self.optim_d.note_replayed_step()
         self.optim_g.note_replayed_step()
         return ent["result"]
@@ -236,16 +317,17 @@ class S2Engine:
         self.optim_g._segments()
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
-        graphs = []
-        for phase in (self._phase_a, self._phase_b, self._phase_c):
+        graphs, afters = [], []
+        for phase, after in self._program():
             g = torch.cuda.CUDAGraph()
             # "relaxed": pinned staging buffers of the loss tables may be allocated while capturing
             with torch.cuda.graph(g, pool=pool, capture_error_mode="relaxed"):
                 phase(st)
             graphs.append(g)
+            afters.append(after)
         # capture records the optimiser launches without running them: undo the python-side counters it bumped
         self.optim_d.step_count -= 1
         self.optim_g.step_count -= 1
         # only detached results are kept: a live autograd graph would pin its AccumulateGrad nodes (created on the capture
         # stream) and later eager steps of other shapes would run their gradient accumulation on that stream
-        ent.update(graphs=tuple(graphs), static=static, result=self._result(st))
+        ent.update(graphs=tuple(graphs), after=tuple(afters), static=static, result=self._result(st))
