@@ -1,0 +1,122 @@
+"""The discriminators' part of the GENERATOR step (src/train/sovits.py:509-516: net_d(y, y_hat) -> feature_loss +
+generator_loss) as ONE autograd node over all sub-discriminators.
+
+The reference runs D on the real and on the generated audio and differentiates the two losses through the generated
+half only (the real feature maps are detached, losses.py:11).  Here, per sub-discriminator:
+  * forward: real and generated sequences go through every convolution as ONE batch [real ; fake] -- the wide
+    1024-channel layers run at the efficiency of the D step's batched pass (a fake-only launch fills half the chip);
+  * losses: one launch for all 37 feature-map L1 terms (pointers to the two halves of each map), one for the six LSGAN
+    terms;
+  * backward: backward-data launches over the FAKE half only (the halves are contiguous), each adding the feature-loss
+    gradient of its input map through the add-epilogue; no weight gradients (the reference computes and discards them),
+    no zero-padded slice gradients, no element-wise sums, ~45 autograd nodes less per sub-discriminator.
+"""
+import ctypes as C
+
+import torch
+
+from . import conv as HC
+from . import lib as L
+
+
+def _seg_table(a, b, da, scales, device):
+    segs = [L.Seg(x.data_ptr(), y.data_ptr() if y is not None else None, g.data_ptr() if g is not None else None,
+                  x.numel(), sc, 0) for x, y, g, sc in zip(a, b, da, scales)]
+    return L.struct_to_device(segs, device)
+
+
+class MPDGenLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, plan, n_items, *xs):
+        """plan: per sub-discriminator (conv slots, (act, slope) per conv); xs: the prepared generated inputs
+        [n_i, L_i, 1] (differentiable) followed by the prepared real inputs (same shapes).
+        Returns (loss_gen, loss_fm, *generated logits [n_items, -1])."""
+        nd = len(plan)
+        fakes, reals = xs[:nd], xs[nd:]
+        dev = fakes[0].device
+        dt = L.dt_of(fakes[0])
+        maps, saved = [], []           # per sub-D: list of batched outputs
+        for (slots, acts), xf, xr in zip(plan, fakes, reals):
+            x = torch.cat([xr, xf], dim=0)
+            ys = []
+            for s, (act, slope) in zip(slots, acts):
+                x = HC._fwd(s, x, None, 1.0, act, slope)
+                ys.append(x)
+            maps.append(ys)
+        fa, fb, fs, la, ls = [], [], [], [], []
+        for ys in maps:
+            for y in ys:
+                h = y.size(0) // 2
+                fa.append(y[h:])
+                fb.append(y[:h])
+                fs.append(2.0 / y[h:].numel())           # losses.py:7-15: 2 * mean|r - g| per map
+            lg = ys[-1][ys[-1].size(0) // 2:]
+            la.append(lg)
+            ls.append(1.0 / lg.numel())                   # losses.py:35-43: mean((1 - dg)^2)
+        out = torch.zeros(2, dtype=torch.float32, device=dev)
+        L.check(L.lib().evt_l1_multi_fwd(dt, L.ptr(_seg_table(fa, fb, [None] * len(fa), fs, dev)), len(fa),
+                                         L.ptr(out[1:]), L.stream_ptr()), "evt_l1_multi_fwd")
+        L.check(L.lib().evt_lsgan_multi_fwd(dt, L.ptr(_seg_table(la, [None] * nd, [None] * nd, ls, dev)), nd,
+                                            C.c_float(1.0), L.ptr(out[:1]), L.stream_ptr()), "evt_lsgan_multi_fwd")
+        ctx.plan, ctx.dt = plan, dt
+        ctx.counts = [len(ys) for ys in maps]
+        ctx.in_shapes = [tuple(x.shape) for x in fakes]
+        ctx.save_for_backward(*[y for ys in maps for y in ys])
+        logits = [lg.reshape(n_items, -1).detach() for lg in la]
+        ctx.mark_non_differentiable(*logits)
+        return (out[0], out[1], *logits)
+
+    @staticmethod
+    def backward(ctx, dgen, dfm, *_unused):
+        plan, dt = ctx.plan, ctx.dt
+        flat = list(ctx.saved_tensors)
+        maps, at = [], 0
+        for c in ctx.counts:
+            maps.append(flat[at: at + c])
+            at += c
+        dev = flat[0].device
+        nd = len(plan)
+        # feature-loss gradients of every generated map, LSGAN gradients of the generated logits: two launches
+        fa, fb, fs, fg, la, ls, lgr = [], [], [], [], [], [], []
+        for ys in maps:
+            for y in ys:
+                h = y.size(0) // 2
+                fa.append(y[h:])
+                fb.append(y[:h])
+                fs.append(2.0 / y[h:].numel())
+                fg.append(torch.empty_like(y[h:]))
+            lg = ys[-1][ys[-1].size(0) // 2:]
+            la.append(lg)
+            ls.append(1.0 / lg.numel())
+            lgr.append(torch.empty_like(lg))
+        dl = torch.stack([dgen.reshape(()).float(), dfm.reshape(()).float()]).contiguous()
+        L.check(L.lib().evt_l1_multi_bwd(dt, L.ptr(_seg_table(fa, fb, fg, fs, dev)), len(fa), L.ptr(dl[1:]),
+                                         L.stream_ptr()), "evt_l1_multi_bwd")
+        L.check(L.lib().evt_lsgan_multi_bwd(dt, L.ptr(_seg_table(la, [None] * nd, lgr, ls, dev)), nd, C.c_float(1.0),
+                                            L.ptr(dl[:1]), L.stream_ptr()), "evt_lsgan_multi_bwd")
+        grads, gi = [], 0
+        for (slots, acts), ys, lg_grad, in_shape in zip(plan, maps, lgr, ctx.in_shapes):
+            nl = len(slots)
+            mg = fg[gi: gi + nl]
+            gi += nl
+            dy = mg[-1] + lg_grad                                    # the last map is also the logits (a few K values)
+            for l in reversed(range(nl)):
+                s, (act, slope) = slots[l], acts[l]
+                y_act = ys[l][ys[l].size(0) // 2:]
+                half = y_act.size(0)
+                lin = ys[l - 1].size(1) if l > 0 else in_shape[1]
+                add = mg[l - 1] if l > 0 else None
+                a_kind, a_slope, y_arg = act, slope, (y_act if act != L.ACT_NONE else None)
+                if act != L.ACT_NONE and L.lib().evt_conv1d_wants_plain_dy(C.byref(s.params(half, lin, 1.0, act, slope))):
+                    dy_eff = torch.empty_like(dy)
+                    L.check(L.lib().evt_dact_mul(dt, L.ptr(dy), L.ptr(y_act), int(act), C.c_float(slope), L.ptr(dy_eff),
+                                                 C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
+                    dy, y_arg, a_kind, a_slope = dy_eff, None, L.ACT_NONE, 1.0
+                if add is not None and s.module.groups > 1:
+                    # the grouped kernels take no add operand (the dispatcher would fall back to the generic path)
+                    dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, None, half, lin, 1.0, a_kind, a_slope)
+                    dy.add_(add)
+                else:
+                    dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, add, half, lin, 1.0, a_kind, a_slope)
+            grads.append(dy)
+        return (None, None, None, *grads, *([None] * nd))

@@ -522,14 +522,25 @@ class DiscriminatorP(nn.Module, _ComputeDtype):
                       padding=get_padding(kernel_size, 1), weight_norm=True, kdims=2) for i in range(5)])
         self.conv_post = EvtConv1d(1024, 1, 3, padding=1, weight_norm=True, kdims=2)
 
-    def forward(self, x):
-        """x [N, T] fp32 waveform -> (logits [N, p*H'] , fmaps list of [N*p, H_i, C_i])"""
+    def prepare(self, x):
+        """x [N, T] fp32 waveform -> the p interleaved sequences [N*p, T'/p, 1] in the compute dtype"""
         n, t = x.shape
         p = self.period
         if t % p != 0:
             x = F.pad(x.unsqueeze(1), (0, p - (t % p)), "reflect").squeeze(1)
             t = x.size(1)
-        x = x.view(n, t // p, p).transpose(1, 2).reshape(n * p, t // p, 1).to(self.cd).contiguous()
+        return x.view(n, t // p, p).transpose(1, 2).reshape(n * p, t // p, 1).to(self.cd).contiguous()
+
+    def plan(self):
+        """(conv slots, (output activation, slope) per conv) in forward order -- what hip/disc.py runs"""
+        convs = list(self.convs) + [self.conv_post]
+        return (tuple(c._slot for c in convs),
+                tuple([(L.ACT_LRELU, LRELU_SLOPE)] * len(self.convs) + [(L.ACT_NONE, 1.0)]))
+
+    def forward(self, x):
+        """x [N, T] fp32 waveform -> (logits [N, p*H'] , fmaps list of [N*p, H_i, C_i])"""
+        x = self.prepare(x)
+        n = x.size(0) // self.period
         fmap = []
         for l in self.convs:
             x = l(x, out_act=L.ACT_LRELU, out_slope=LRELU_SLOPE)
@@ -552,8 +563,16 @@ class DiscriminatorS(nn.Module, _ComputeDtype):
                                     for ci, co, k, s, g, p in spec])
         self.conv_post = EvtConv1d(1024, 1, 3, padding=1, weight_norm=True)
 
+    def prepare(self, x):
+        return x.unsqueeze(-1).to(self.cd).contiguous()
+
+    def plan(self):
+        convs = list(self.convs) + [self.conv_post]
+        return (tuple(c._slot for c in convs),
+                tuple([(L.ACT_LRELU, LRELU_SLOPE)] * len(self.convs) + [(L.ACT_NONE, 1.0)]))
+
     def forward(self, x):
-        x = x.unsqueeze(-1).to(self.cd).contiguous()
+        x = self.prepare(x)
         fmap = []
         for l in self.convs:
             x = l(x, out_act=L.ACT_LRELU, out_slope=LRELU_SLOPE)
@@ -583,6 +602,24 @@ class MultiPeriodDiscriminator(nn.Module):
             outs.append(o)
             fmaps.append(f)
         return outs, fmaps
+
+    def generator_losses(self, y, y_hat):
+        """The discriminators' part of the generator step (sovits.py:509-516): (generator_loss, feature_loss, generated
+        logits per sub-discriminator) with gradients towards y_hat only -- one autograd node, real and generated audio
+        batched through every convolution (hip/disc.py)."""
+        from ..hip.disc import MPDGenLossFn
+
+        n = y.size(0)
+        yr, yg = y.reshape(n, -1).float(), y_hat.reshape(n, -1).float()
+        with torch.no_grad():
+            reals = [d.prepare(yr) for d in self.discriminators]
+        fakes = [d.prepare(yg) for d in self.discriminators]
+        plan = tuple(d.plan() for d in self.discriminators)
+        if any(s is None for slots, _ in plan for s in slots):
+            raise L.EvtError("MultiPeriodDiscriminator used before WeightBank.attach(); there is no eager fallback")
+        anchor = plan[0][0][0].bank.anchor
+        out = MPDGenLossFn.apply(anchor, plan, n, *fakes, *reals)
+        return out[0], out[1], list(out[2:])
 
     def forward(self, y, y_hat):
         n = y.size(0)

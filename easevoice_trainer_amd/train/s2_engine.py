@@ -140,14 +140,11 @@ class S2Engine:
             rt_d.prepare()   # D weights changed: refold before the generator's pass through D
         # ---- generator step (sovits.py:509-525) ----
         rt_d.bank.weight_grads = False
-        with torch.no_grad():
-            _, fmap_r = net_d.forward_single(st.y_seg)
-        st.y_d_hat_g, fmap_g = net_d.forward_single(st.y_hat)
+        # D on real + generated audio, feature / generator losses, gradients towards y_hat: one autograd node
+        st.loss_gen, st.loss_fm, st.y_d_hat_g = net_d.generator_losses(st.y_seg, st.y_hat)
         z, z_p, m_p, logs_p, m_q, logs_q = st.lat
         st.loss_mel = F.l1_loss(st.y_mel, st.y_hat_mel) * t["c_mel"]
         st.loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, st.z_mask, lens=st.spec_lengths) * t["c_kl"]
-        st.loss_fm = feature_loss(fmap_r, fmap_g)
-        st.loss_gen = generator_loss(st.y_d_hat_g)
         st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
         if not backward:
             return
