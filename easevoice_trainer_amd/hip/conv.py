@@ -49,7 +49,8 @@ def conv_layout(dt, cin, cout, k, stride, pad, dil, groups, transposed) -> L.WLa
 class EvtConv1d(nn.Module):
     """Conv1d / ConvTranspose1d parameter holder.  Keys: `weight` (+`bias`) or `weight_g`/`weight_v`
     (+`bias`) exactly as torch's (old-style weight-normed) modules expose them; `kdims=2` appends the
-    trailing size-1 kernel dim of DiscriminatorP's Conv2d((k,1)) weights."""
+    trailing size-1 kernel dim of DiscriminatorP's Conv2d((k,1)) weights; `kdims=0` (k = 1 only) drops the kernel dim:
+    the `weight` [cout, cin] / `bias` of an nn.Linear, run as a 1x1 convolution over the rows."""
 
     def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, bias=True, transposed=False,
                  weight_norm=False, kdims=1):
@@ -58,7 +59,9 @@ class EvtConv1d(nn.Module):
         self.groups, self.transposed, self.weight_norm, self.kdims = groups, transposed, weight_norm, kdims
         d0 = cin if transposed else cout
         d1 = cout if transposed else cin // groups
-        wshape = (d0, d1, k) + ((1,) if kdims == 2 else ())
+        if kdims == 0 and (k != 1 or transposed or groups != 1):
+            raise L.EvtError("kdims=0 is the nn.Linear layout: k = 1, dense, not transposed")
+        wshape = (d0, d1) if kdims == 0 else (d0, d1, k) + ((1,) if kdims == 2 else ())
         w = torch.empty(wshape)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         fan_in = d1 * k if not transposed else d0 * k  # torch: fan_in is computed from weight.size(1)*k

@@ -49,20 +49,30 @@ class PointwiseEvtConv(EvtConv1d):
     3200-row x 192..768-column GEMM is launch/latency-bound, the ring-pipelined k = 1 conv does it in ~10 us and its
     weight-gradient launch also produces the bias gradient (F.linear needs dgrad + wgrad + a column-sum launch)."""
 
-    def __init__(self, cin, cout):
-        super().__init__(cin, cout, 1)
+    def __init__(self, cin, cout, kdims=1, weight_norm=False):
+        super().__init__(cin, cout, 1, kdims=kdims, weight_norm=weight_norm)
 
     def forward(self, x):
+        """x [..., cin] -> [..., cout]: any leading shape (a [B, cin] vector is one sequence of B rows)"""
         if self._slot is not None:
             cd = self._slot.bank.dtype
             if x.dtype != cd or not x.is_contiguous():
                 x = x.to(cd).contiguous()
-        return super().forward(x)
+        if x.dim() == 3:
+            return super().forward(x)
+        lead = x.shape[:-1]
+        return super().forward(x.reshape(1, -1, x.size(-1))).reshape(*lead, self.cout)
 
 
 def pointwise(cin, cout):
-    """1x1 conv on [B, T, C]: HIP conv when both widths are multiples of 64, a library GEMM otherwise"""
-    return PointwiseEvtConv(cin, cout) if cin % 64 == 0 and cout % 64 == 0 else PointwiseConv(cin, cout)
+    """1x1 conv on [B, T, C]: the library's conv kernels whenever the rows are 16-byte aligned (both widths multiples
+    of 8); only the 1025-bin spectrogram projection of the posterior encoder stays on a vendor GEMM"""
+    return PointwiseEvtConv(cin, cout) if cin % 8 == 0 and cout % 8 == 0 else PointwiseConv(cin, cout)
+
+
+def linear_rows(cin, cout):
+    """an nn.Linear (state_dict keys `weight` [cout, cin], `bias`) on the same kernels"""
+    return PointwiseEvtConv(cin, cout, kdims=0) if cin % 8 == 0 and cout % 8 == 0 else nn.Linear(cin, cout)
 
 
 class MultiHeadAttention(nn.Module):

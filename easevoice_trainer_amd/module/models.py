@@ -23,7 +23,7 @@ from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
 from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
 from ..hip.wn import wn_stack
 from . import commons
-from .attentions import Encoder, MultiHeadAttention, PointwiseConv, pointwise
+from .attentions import Encoder, MultiHeadAttention, PointwiseConv, PointwiseEvtConv, linear_rows, pointwise
 
 LRELU_SLOPE = 0.1
 N_SYMBOLS = 732  # len(SYMBOLS), src/easevoice/text/symbols.py:410-412 (pinned by tests/easevoice/text_test.py)
@@ -41,20 +41,14 @@ class _ComputeDtype:
 # --------------------------------------------------------------------------------------------------
 # WN / posterior encoder / flow
 # --------------------------------------------------------------------------------------------------
-class WeightNormPointwise(nn.Module):
-    """weight-normed nn.Conv1d(cin, cout, 1) applied to a [B, C] vector (the WN cond_layer on ge)."""
+class WeightNormPointwise(PointwiseEvtConv):
+    """weight-normed nn.Conv1d(cin, cout, 1) applied to a [B, C] vector (the WN cond_layer on ge): keys bias, weight_g,
+    weight_v like the reference; the weight-norm fold and its gradient are the bank's multi-tensor launches, the product
+    a 1x1 conv over the B rows (through torch this was a norm / divide / multiply chain, a vendor GEMM and their
+    backward per call)."""
 
     def __init__(self, cin, cout):
-        super().__init__()
-        c = nn.Conv1d(cin, cout, 1)
-        self.bias = c.bias
-        self.weight_g = nn.Parameter(c.weight.detach().reshape(cout, -1).norm(dim=1).reshape(cout, 1, 1))
-        self.weight_v = nn.Parameter(c.weight.detach().clone())
-
-    def forward(self, g):
-        v = self.weight_v.squeeze(-1)
-        w = v * (self.weight_g.view(-1, 1) / v.norm(dim=1, keepdim=True))
-        return F.linear(g, w, self.bias)
+        super().__init__(cin, cout, weight_norm=True)
 
 
 class WN(nn.Module, _ComputeDtype):
@@ -114,9 +108,9 @@ class PosteriorEncoder(nn.Module, _ComputeDtype):
                  gin_channels=0):
         super().__init__()
         self.out_channels = out_channels
-        self.pre = PointwiseConv(in_channels, hidden_channels)
+        self.pre = pointwise(in_channels, hidden_channels)
         self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
-        self.proj = PointwiseConv(hidden_channels, out_channels * 2)
+        self.proj = pointwise(hidden_channels, out_channels * 2)
 
     def forward(self, x, x_mask, g=None, eps=None, lens=None):
         """x [B, T, spec] -> z, m, logs [B, T, out]; eps (the randn_like draw of models.py:358) may be injected"""
@@ -140,10 +134,10 @@ class ResidualCouplingLayer(nn.Module, _ComputeDtype):
         super().__init__()
         assert channels % 2 == 0
         self.half_channels, self.mean_only = channels // 2, mean_only
-        self.pre = PointwiseConv(self.half_channels, hidden_channels)
+        self.pre = pointwise(self.half_channels, hidden_channels)
         self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=p_dropout,
                       gin_channels=gin_channels)
-        self.post = PointwiseConv(hidden_channels, self.half_channels * (2 - mean_only))
+        self.post = pointwise(hidden_channels, self.half_channels * (2 - mean_only))
         self.post.weight.data.zero_()
         self.post.bias.data.zero_()
 
@@ -250,7 +244,7 @@ class TextEncoder(nn.Module, _ComputeDtype):
 class LinearNorm(nn.Module):
     def __init__(self, cin, cout, bias=True):
         super().__init__()
-        self.fc = nn.Linear(cin, cout, bias)
+        self.fc = linear_rows(cin, cout) if bias else nn.Linear(cin, cout, bias)
 
     def forward(self, x):
         return self.fc(x)
@@ -292,11 +286,11 @@ class StyleAttention(nn.Module):
     def __init__(self, n_head, d_model, d_k, d_v, dropout=0.0):
         super().__init__()
         self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
-        self.w_qs = nn.Linear(d_model, n_head * d_k)
-        self.w_ks = nn.Linear(d_model, n_head * d_k)
-        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        self.w_qs = linear_rows(d_model, n_head * d_k)
+        self.w_ks = linear_rows(d_model, n_head * d_k)
+        self.w_vs = linear_rows(d_model, n_head * d_v)
         self.temperature = float(d_model) ** 0.5
-        self.fc = nn.Linear(n_head * d_v, d_model)
+        self.fc = linear_rows(n_head * d_v, d_model)
         self.dropout = nn.Dropout(dropout)
         self.attn_dropout = nn.Dropout(dropout)
 
@@ -487,7 +481,7 @@ class Generator(nn.Module, _ComputeDtype):
                 self.resblocks.append(ResBlock1(ch, k, tuple(d)))
         self.conv_post = EvtConv1d(ch, 1, 7, padding=3, bias=False)
         if gin_channels != 0:
-            self.cond = PointwiseConv(gin_channels, upsample_initial_channel)
+            self.cond = pointwise(gin_channels, upsample_initial_channel)
 
     def forward(self, x, g=None):
         """x [B, T, inter] -> waveform [B, T*prod(up), 1]"""

@@ -14,6 +14,8 @@ def _w(m):
         v = m.weight_v.squeeze(-1) if m.kdims == 2 else m.weight_v
         g = m.weight_g.squeeze(-1) if m.kdims == 2 else m.weight_g
         return O.weight_norm_fold(v, g)
+    if m.kdims == 0:
+        return m.weight.unsqueeze(-1)             # nn.Linear layout [cout, cin]
     return m.weight.squeeze(-1) if m.kdims == 2 else m.weight
 
 

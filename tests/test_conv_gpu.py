@@ -26,6 +26,13 @@ CASES = [
     (192, 768, 3, 1, 1, 1, 1, False, False, 37, 2),
     (192, 384, 1, 1, 0, 1, 1, False, True, 45, 2),
     (96, 192, 1, 1, 0, 1, 1, False, False, 45, 2),
+    # 1x1 projections that used to be vendor GEMMs: flow post 192->96, the style encoder's linears (704->128, 128->512)
+    # and the weight-normed conditioning layers applied to a [B, 512] vector as ONE sequence of B rows
+    (192, 96, 1, 1, 0, 1, 1, False, False, 45, 2),
+    (704, 128, 1, 1, 0, 1, 1, False, False, 40, 2),
+    (128, 512, 1, 1, 0, 1, 1, False, False, 33, 2),
+    (512, 1536, 1, 1, 0, 1, 1, False, True, 16, 1),
+    (512, 512, 1, 1, 0, 1, 1, False, False, 16, 1),
     # ups (models.py:424-436): (k,u,p) = (16,10,3) (16,8,4) (8,2,3) (2,2,0)
     (64, 32, 16, 10, 3, 1, 1, True, True, 12, 2),
     (64, 32, 16, 8, 4, 1, 1, True, True, 12, 2),
