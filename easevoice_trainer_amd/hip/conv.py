@@ -354,6 +354,31 @@ class ConvFn(torch.autograd.Function):
         return dx, None, dres, None, None, None, None
 
 
+def _resunit_params(s1, s2, x, slope):
+    """evt_resunit_params when the fused ResBlock step covers this pair of convolutions and input, else None"""
+    m1, m2 = s1.module, s2.module
+    if (x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
+            or m2.cin != m2.cout or m1.cin != m2.cin or m1.k != m2.k or m2.dil != 1 or m1.stride != 1 or m2.stride != 1
+            or m1.groups != 1 or m2.groups != 1 or m1.transposed or m2.transposed
+            or m1.pad != m1.dil * (m1.k - 1) // 2 or m2.pad != (m2.k - 1) // 2 or s1.bank.impl != L.IMPL_AUTO):
+        return None
+    p = L.ResUnitParams(L.DT_BF16, x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
+    return p if L.lib().evt_resunit_supported(C.byref(p)) else None
+
+
+def _t1_unit(e0, m1, m2, x):
+    """trace record of one fused step: flops of both convolutions; bytes = x in, xa / mid_a / y out, both weight images"""
+    e0, rf = e0
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
+    n, ln, c = x.shape
+    macs = n * ln * c * c * (m1.k + m2.k)
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), "fwd", 2 * macs, 4 * x.numel() * 2 + (m1.v.numel() + m2.v.numel()) * 2,
+                  e0, e1, f"unit {c}>{c} k{m1.k} d{m1.dil} n{n} L{ln}", m1))
+
+
 def _lrelu(x, slope):
     out = torch.empty_like(x)
     L.check(L.lib().evt_leaky_relu(L.dt_of(x), L.ptr(x), C.c_float(slope), L.ptr(out), C.c_int64(x.numel()),
@@ -370,6 +395,22 @@ class ResUnitFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, s1, s2, slope):
+        fused = _resunit_params(s1, s2, x, slope)
+        if fused is not None:
+            # narrow stages (C = 16 / 32): the whole step in one launch (csrc/resunit.hip); it also writes the two
+            # activated tensors the backward launches below take
+            m1, m2 = s1.module, s2.module
+            xa, mid_a, y = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            e0 = _t0()
+            L.check(L.lib().evt_resunit_fwd(C.byref(fused), L.ptr(x), L.ptr(s1.reg), L.ptr(s2.reg),
+                                            L.ptr(m1.bias.data if m1.bias is not None else None),
+                                            L.ptr(m2.bias.data if m2.bias is not None else None), L.ptr(xa), L.ptr(mid_a),
+                                            L.ptr(y), L.stream_ptr()), "evt_resunit_fwd")
+            if e0 is not None:
+                _t1_unit(e0, m1, m2, x)
+            ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
+            ctx.save_for_backward(xa, mid_a)
+            return y
         xa = _lrelu(x, slope)
         mid_a = _fwd(s1, xa, None, 1.0, L.ACT_LRELU, slope)
         y = _fwd(s2, mid_a, x, 1.0, L.ACT_NONE, 1.0)

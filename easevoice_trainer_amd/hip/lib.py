@@ -30,6 +30,11 @@ class ConvParams(C.Structure):
     ]
 
 
+class ResUnitParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("nseq", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("k", C.c_int32),
+                ("dil", C.c_int32), ("slope", C.c_float)]
+
+
 class WLayout(C.Structure):
     _fields_ = [
         ("d0", C.c_int32), ("d1", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32),

@@ -144,6 +144,19 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* p, const void* dy, const void* 
 int evt_conv1d_bwd_weight(const evt_conv1d_params* p, const void* x, const void* dy, const void* y,
                           float* dw, float* dbias, void* stream);
 
+/* One HiFi-GAN ResBlock1 step  y = x + c2(lrelu(c1(lrelu(x), dilation d)))  (modules.py:299-308 of the reference; both
+ * convolutions C -> C, kernel k, "same" padding, c2 undilated) as ONE launch for the narrow vocoder stages: bf16,
+ * C in {16, 32}, k in {3, 7, 11}, d in 1..5.  x, y, xa, mid_a: [nseq][L][C]; w1_reg / w2_reg: the REG images of the two
+ * convolutions; b1 / b2 fp32 [C] or NULL.  xa = lrelu(x) and mid_a = lrelu(c1(xa) + b1) are the operands the backward
+ * launches (evt_conv1d_bwd_*) take; pass NULL to skip writing them (inference). */
+typedef struct evt_resunit_params {
+  int32_t dtype, nseq, L, C, k, dil;
+  float slope;
+} evt_resunit_params;
+int32_t evt_resunit_supported(const evt_resunit_params* p);
+int evt_resunit_fwd(const evt_resunit_params* p, const void* x, const void* w1_reg, const void* w2_reg, const float* b1,
+                    const float* b2, void* xa, void* mid_a, void* y, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Element-wise / reduction helpers of the s2 path.
  * ------------------------------------------------------------------------------------- */

@@ -1,0 +1,51 @@
+"""Times one ResBlock step forward at the B=16 vocoder shapes, fused (csrc/resunit.hip) vs the three launches it replaces.
+usage: python tools/bench_resunit.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from easevoice_trainer_amd.hip import conv as HC   # noqa: E402
+from easevoice_trainer_amd.hip import lib as L    # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    for C_, Lq in ((16, 20480), (32, 10240)):
+        for k, d in ((3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)):
+            pad = lambda kk, dd: (kk * dd - dd) // 2
+            m = torch.nn.ModuleList([HC.EvtConv1d(C_, C_, k, dilation=d, padding=pad(k, d), weight_norm=True),
+                                     HC.EvtConv1d(C_, C_, k, dilation=1, padding=pad(k, 1), weight_norm=True)]).to(dev)
+            bank = HC.WeightBank(m, torch.bfloat16, dev)
+            bank.build_tables()
+            bank.fold()
+            x = torch.randn(16, Lq, C_, device=dev).bfloat16()
+            s1, s2 = m[0]._slot, m[1]._slot
+
+            def unfused():
+                xa = HC._lrelu(x, 0.1)
+                mid = HC._fwd(s1, xa, None, 1.0, L.ACT_LRELU, 0.1)
+                return HC._fwd(s2, mid, x, 1.0, L.ACT_NONE, 1.0)
+
+            def fused():
+                with torch.no_grad():
+                    return HC.res_unit(x, m[0], m[1], 0.1)
+
+            out = {}
+            for name, fn in (("unfused", unfused), ("fused", fused)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                out[name] = e0.elapsed_time(e1) / 20 * 1e3
+            print(f"C={C_:3d} L={Lq:6d} k={k:2d} d={d}: unfused {out['unfused']:6.1f} us  fused {out['fused']:6.1f} us")
+
+
+if __name__ == "__main__":
+    main()
