@@ -480,8 +480,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
 // dK/dV (bf16): block = 4 waves x 2 key tiles (128 keys); query blocks of 64 through LDS.  A lane's two key tiles are
 // the keys kp and kp + 16 of one dropout hash; the per-query hash part comes from an LDS table filled per query block.
 // ---------------------------------------------------------------------------------------------------------
+// one-tile variant: 3 waves per SIMD (168 registers, four values spilled outside the tile loop) -- measured 277 -> 233 us;
+// the same squeeze on forward / dQ (5 waves, 96 registers) spills inside the loop and loses 30 % / 145 %
 template <bool JOINT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16(AP p) {
+__global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[2][64 * PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t Os[2][64 * PITCH];
   __shared__ __attribute__((aligned(16))) float lse_s[2][64];

@@ -146,10 +146,12 @@ class ResidualCouplingLayer(nn.Module, _ComputeDtype):
         h = (self.pre(x0) * x_mask).to(self.cd).contiguous()
         h = self.enc(h, x_mask, g=g, lens=lens)
         stats = (self.post(h) * x_mask).float()
-        if not self.mean_only:
-            m, logs = torch.split(stats, [self.half_channels] * 2, dim=-1)
-        else:
-            m, logs = stats, torch.zeros_like(stats)
+        if self.mean_only:
+            # logs == 0 (modules.py:449-452): exp(logs) is 1, the affine step is a masked shift -- no zero tensor, no exp,
+            # no multiply by one (and none of their backward launches)
+            x1 = stats + x1 * x_mask if not reverse else (x1 - stats) * x_mask
+            return torch.cat([x0, x1], dim=-1)
+        m, logs = torch.split(stats, [self.half_channels] * 2, dim=-1)
         if not reverse:
             x1 = m + x1 * torch.exp(logs) * x_mask
         else:
