@@ -1199,6 +1199,10 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   const int lout = evt_conv1d_lout(c);
   evt_wlayout l; evt_conv1d_layout(c, &l);
+  // a handful of rows (a 1x1 layer applied to one vector per item): weight rows on the MFMA's M side (rows_gemm.hip)
+  if (w_reg && evt_conv::rows16_eligible(c, c->nseq * c->lin, c->cout, c->cin,
+                                         res || c->in_slope != 1.f || c->out_act != EVT_ACT_NONE))
+    return evt_conv::launch_rows16(x, w_reg, bias, y, c->nseq * c->lin, c->cout, c->cin, st);
   evt_set_last_tag("conv_naive_fwd");
   if (c->impl != EVT_IMPL_NAIVE && !res && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;
@@ -1265,6 +1269,8 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
   evt_wlayout l; evt_conv1d_layout(c, &l);
   const void* ysv = c->out_act != EVT_ACT_NONE ? y : nullptr;
   const void* gate = c->in_slope != 1.f ? x : nullptr;
+  if (w_alt && evt_conv::rows16_eligible(c, c->nseq * c->lin, c->cin, c->cout, ysv || gate || dx_add))
+    return evt_conv::launch_rows16(dy, w_alt, nullptr, dx, c->nseq * c->lin, c->cin, c->cout, st);
   evt_set_last_tag("conv_naive_bwd_data");
   if (c->impl != EVT_IMPL_NAIVE && !gate && !dx_add && evt_grouped_supported(c)) {
     if (!w_reg) return EVT_EINVAL;

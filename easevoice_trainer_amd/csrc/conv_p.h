@@ -1,6 +1,7 @@
 // Launch descriptor of the implicit-GEMM conv kernels (conv1d.hip: conv_igemm, conv_deep.hip: conv_deep).
 #pragma once
 #include "evt_common.h"
+#include "../../include/evt.h"
 #include <cstdlib>
 
 namespace evt_conv {
@@ -63,5 +64,9 @@ int launch_wgrad_gemm(const WgP& p, hipStream_t st);
 // ring-pipelined variant for the latency-bound mid-size layers (A channels % 64 == 0); fuses dbias
 bool wgrad_ring_eligible(const WgP& p, int dtype);
 int launch_wgrad_ring(const WgP& p, hipStream_t st);
+
+// rows_gemm.hip: k = 1 layers applied to at most 16 rows in total (one vector per batch item)
+bool rows16_eligible(const struct evt_conv1d_params* c, int rows, int n_out, int k_red, bool fused);
+int launch_rows16(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st);
 
 }  // namespace evt_conv

@@ -33,6 +33,7 @@ CASES = [
     (128, 512, 1, 1, 0, 1, 1, False, False, 33, 2),
     (512, 1536, 1, 1, 0, 1, 1, False, True, 16, 1),
     (512, 512, 1, 1, 0, 1, 1, False, False, 16, 1),
+    (512, 1536, 1, 1, 0, 1, 1, False, True, 5, 1),       # fewer than 16 rows (a batch of 5): rows16 zero-fills the tile
     # ups (models.py:424-436): (k,u,p) = (16,10,3) (16,8,4) (8,2,3) (2,2,0)
     (64, 32, 16, 10, 3, 1, 1, True, True, 12, 2),
     (64, 32, 16, 8, 4, 1, 1, True, True, 12, 2),
