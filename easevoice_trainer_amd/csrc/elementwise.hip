@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* item
 __global__ __launch_bounds__(256) void wn_grad_kernel(const evt_wprep_item* items, const int32_t* rows) {
   __shared__ float red[4];
   const evt_wprep_item it = items[rows[2 * blockIdx.x]];
+  if (!it.dw) return;     // no gradient image: e.g. a member of a packed projection, whose .grad the pack's rows update
   const int d0 = rows[2 * blockIdx.x + 1];
   const evt_wlayout& L = it.lay;
   const int n = L.d1 * L.k;

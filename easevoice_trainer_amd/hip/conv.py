@@ -20,12 +20,13 @@ from . import lib as L
 class ConvSlot:
     """Per-conv record inside a WeightBank: geometry + views into the prepared-weight arenas."""
 
-    __slots__ = ("module", "layout", "reg", "alt", "dw", "bank", "_pcache")
+    __slots__ = ("module", "layout", "reg", "alt", "dw", "bank", "_pcache", "packed_member")
 
     def __init__(self, module, layout, bank):
         self.module, self.layout, self.bank = module, layout, bank
         self.reg = self.alt = self.dw = None
         self._pcache = {}
+        self.packed_member = False   # True: the weight gradient of this conv is produced by a PackedConv over it
 
     def params(self, nseq, lin, in_slope, out_act, out_slope):
         key = (nseq, lin, in_slope, out_act, out_slope, self.bank.impl)
@@ -98,6 +99,40 @@ class EvtConv1d(nn.Module):
                             float(out_slope))
 
 
+class PackedConv:
+    """Several equal-shaped k = 1 convolutions of ONE input as a single convolution with the concatenated output channels
+    (the q | k | v projections of an attention layer: three [C, C] weights -> one dense [3C, C] GEMM, one launch each way
+    instead of three).  Exists only when the members' parameters are adjacent in the runtime's arena (ParamArena honours
+    the owner's `arena_adjacent()`): `v` / `bias` and their gradients are then plain views over the members' storage,
+    so the packed dW image unfolds straight into the members' .grad -- nothing is copied, the members stay usable."""
+    weight_norm, kdims, transposed, groups, stride, pad, dil, k = False, 1, False, 1, 1, 0, 1, 1
+
+    def __init__(self, members):
+        m0 = members[0]
+        self.members = members
+        self.cin, self.cout = m0.cin, sum(m.cout for m in members)
+        n, es = m0.weight.numel(), m0.weight.element_size()
+        ws, bs = [m.weight for m in members], [m.bias for m in members]
+
+        def adjacent(ts, numel):
+            return all(t.data_ptr() == ts[0].data_ptr() + i * numel * es and t.is_contiguous() for i, t in enumerate(ts))
+
+        ok = (all(m.cin == m0.cin and m.cout == m0.cout and m.k == 1 and not m.weight_norm and m.kdims == 1 and
+                  m.bias is not None for m in members) and adjacent(ws, n) and adjacent(bs, m0.cout)
+              and all(t.grad is not None for t in ws + bs) and adjacent([t.grad for t in ws], n)
+              and adjacent([t.grad for t in bs], m0.cout))
+        self.ok = ok
+        if ok:
+            self.v = torch.as_strided(ws[0].data, (self.cout, self.cin, 1), (self.cin, 1, 1))
+            self.v.grad = torch.as_strided(ws[0].grad, (self.cout, self.cin, 1), (self.cin, 1, 1))
+            self.bias = torch.as_strided(bs[0].data, (self.cout,), (1,))
+            self.bias.grad = torch.as_strided(bs[0].grad, (self.cout,), (1,))
+        self._slot = None
+
+    def lout(self, lin):
+        return lin
+
+
 class WeightBank:
     """All prepared conv weights of one model: REG/ALT images in the compute dtype, fp32 dW images,
     and the device tables for the two multi-tensor launches (fold before forward, grad after backward)."""
@@ -117,15 +152,30 @@ class WeightBank:
         reg_n = alt_n = 0
         ALIGN = 128  # elements; keeps every image 256-byte aligned
         offs = []
+        convs = [m for m in model.modules() if isinstance(m, EvtConv1d)]
+        # packed projections (see PackedConv): only for the bf16 bank -- the fused attention node that uses them is bf16
         for m in model.modules():
-            if isinstance(m, EvtConv1d):
-                lay = conv_layout(self.dt, m.cin, m.cout, m.k, m.stride, m.pad, m.dil, m.groups, m.transposed)
-                s = ConvSlot(m, lay, self)
-                m._slot = s
-                self.slots.append(s)
-                offs.append((reg_n, alt_n))
-                reg_n += (lay.reg_elems + ALIGN - 1) // ALIGN * ALIGN
-                alt_n += (lay.alt_elems + ALIGN - 1) // ALIGN * ALIGN
+            fn = getattr(m, "qkv_pack_modules", None)
+            members = fn() if (fn is not None and dtype == torch.bfloat16) else None
+            m_packed = None
+            if members:
+                pc = PackedConv(members)
+                if pc.ok:
+                    convs.append(pc)
+                    m_packed = pc
+            if fn is not None:
+                m._qkv_packed = m_packed
+        for m in convs:
+            lay = conv_layout(self.dt, m.cin, m.cout, m.k, m.stride, m.pad, m.dil, m.groups, m.transposed)
+            s = ConvSlot(m, lay, self)
+            m._slot = s
+            self.slots.append(s)
+            offs.append((reg_n, alt_n))
+            reg_n += (lay.reg_elems + ALIGN - 1) // ALIGN * ALIGN
+            alt_n += (lay.alt_elems + ALIGN - 1) // ALIGN * ALIGN
+            if isinstance(m, PackedConv):
+                for mm in m.members:
+                    mm._slot.packed_member = True
         self.reg_arena = torch.zeros(max(reg_n, 1), dtype=dtype, device=device)
         self.alt_arena = torch.zeros(max(alt_n, 1), dtype=dtype, device=device)
         self.dw_arena = torch.zeros(max(reg_n, 1), dtype=torch.float32, device=device)
@@ -153,7 +203,9 @@ class WeightBank:
             it = L.WPrepItem()
             it.v = v.data_ptr()
             it.g = g.data_ptr() if g is not None else None
-            it.reg, it.alt, it.dw = s.reg.data_ptr(), s.alt.data_ptr(), s.dw.data_ptr()
+            # a packed member's .grad memory is updated by the pack's rows: two blocks doing `dv += ...` on the same
+            # addresses would race (lost update), so the member's own rows are switched off in evt_wn_grad_multi
+            it.reg, it.alt, it.dw = s.reg.data_ptr(), s.alt.data_ptr(), (None if s.packed_member else s.dw.data_ptr())
             it.dv = v.grad.data_ptr()
             it.dg = g.grad.data_ptr() if g is not None else None
             it.lay = s.layout
@@ -292,6 +344,9 @@ def _bwd_data(slot, dy, y, x, dx_add, nseq, lin, in_slope, out_act, out_slope):
 
 def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
     bank = slot.bank
+    if slot.packed_member:
+        raise L.EvtError("weight gradient of a packed projection member requested on its own: inside a bf16 runtime the "
+                         "q / k / v projections of a windowed attention layer run (and are differentiated) as one pack")
     if bank.async_wgrad and TRACE is None:
         side = bank.side_stream()
         side.wait_stream(torch.cuda.current_stream(bank.device))

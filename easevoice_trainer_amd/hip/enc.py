@@ -166,13 +166,21 @@ class RelSelfAttnFn(torch.autograd.Function):
             raise L.EvtError(f"relattn: contiguous bf16 [B, T, C] expected, got {tuple(x.shape)} {x.dtype}")
         D = Cc // n_heads
         ek, ev = emb_k.contiguous(), emb_v.contiguous()
-        qkv = torch.empty((3, B, T, Cc), dtype=x.dtype, device=x.device)
-        for i, s in enumerate(slots):
-            HC._fwd(s, x, None, 1.0, L.ACT_NONE, 1.0, out=qkv[i])
+        packed = len(slots) == 1
+        if packed:       # one [3C, C] GEMM: rows [q | k | v], row stride 3C
+            qkv = torch.empty((B, T, 3 * Cc), dtype=x.dtype, device=x.device)
+            HC._fwd(slots[0], x, None, 1.0, L.ACT_NONE, 1.0, out=qkv)
+            ld, esz, base = 3 * Cc, x.element_size(), qkv.data_ptr()
+            qp, kp, vp = C.c_void_p(base), C.c_void_p(base + Cc * esz), C.c_void_p(base + 2 * Cc * esz)
+        else:            # three launches into the planes of one buffer, row stride C
+            qkv = torch.empty((3, B, T, Cc), dtype=x.dtype, device=x.device)
+            for i, s in enumerate(slots):
+                HC._fwd(s, x, None, 1.0, L.ACT_NONE, 1.0, out=qkv[i])
+            ld, (qp, kp, vp) = Cc, (L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]))
         out = torch.empty((B, T, Cc), dtype=x.dtype, device=x.device)
         lse = torch.empty((B * n_heads, T), dtype=torch.float32, device=x.device)
-        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), Cc, Cc, p, site, rng_counter(x.device).data_ptr())
-        L.check(L.lib().evt_relattn_fwd(C.byref(prm), L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(ek), L.ptr(ev),
+        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), ld, Cc, p, site, rng_counter(x.device).data_ptr())
+        L.check(L.lib().evt_relattn_fwd(C.byref(prm), qp, kp, vp, L.ptr(ek), L.ptr(ev),
                                         L.ptr(lens), L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_relattn_fwd")
         ctx.save_for_backward(x, qkv, out, lse, ek, ev, lens)
         ctx.cfg = (slots, n_heads, window, p, site)
@@ -185,7 +193,8 @@ class RelSelfAttnFn(torch.autograd.Function):
 
         x, qkv, out, lse, ek, ev, lens = ctx.saved_tensors
         slots, n_heads, window, p, site = ctx.cfg
-        _, B, T, Cc = qkv.shape
+        B, T, Cc = x.shape
+        packed = len(slots) == 1
         d_o = d_o.contiguous()
         dqkv = torch.empty_like(qkv)
         sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
@@ -194,25 +203,32 @@ class RelSelfAttnFn(torch.autograd.Function):
         else:
             demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=x.device)   # one fill for both
         delta = torch.empty_like(lse)
-        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), Cc, Cc, p, site,
+        if packed:
+            ld, esz = 3 * Cc, x.element_size()
+            ptrs = [C.c_void_p(t.data_ptr() + i * Cc * esz) for t in (qkv, dqkv) for i in range(3)]
+        else:
+            ld, ptrs = Cc, [L.ptr(t[i]) for t in (qkv, dqkv) for i in range(3)]
+        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), ld, Cc, p, site,
                               rng_counter(x.device).data_ptr())
-        L.check(L.lib().evt_relattn_bwd(C.byref(prm), L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]), L.ptr(out), L.ptr(d_o),
-                                        L.ptr(lse), L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(dqkv[0]), L.ptr(dqkv[1]),
-                                        L.ptr(dqkv[2]), L.ptr(demb[0]), L.ptr(demb[1]), L.ptr(delta), L.stream_ptr()),
+        L.check(L.lib().evt_relattn_bwd(C.byref(prm), ptrs[0], ptrs[1], ptrs[2], L.ptr(out), L.ptr(d_o),
+                                        L.ptr(lse), L.ptr(ek), L.ptr(ev), L.ptr(lens), ptrs[3], ptrs[4], ptrs[5],
+                                        L.ptr(demb[0]), L.ptr(demb[1]), L.ptr(delta), L.stream_ptr()),
                 "evt_relattn_bwd")
         dx = None
         for i, s in enumerate(slots):
+            dy = dqkv if packed else dqkv[i]
             if s.bank.weight_grads:
-                HC._bwd_weight(s, x, dqkv[i], None, B, T, 1.0, L.ACT_NONE, 1.0)
+                HC._bwd_weight(s, x, dy, None, B, T, 1.0, L.ACT_NONE, 1.0)
             if ctx.needs_input_grad[0]:
-                dx = HC._bwd_data(s, dqkv[i], None, x, dx, B, T, 1.0, L.ACT_NONE, 1.0)
+                dx = HC._bwd_data(s, dy, None, x, dx, B, T, 1.0, L.ACT_NONE, 1.0)
         if sunk:
             return dx, None, None, None, None, None, None, None, None, None
         return dx, None, demb[0], demb[1], None, None, None, None, None, None
 
 
-def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site):
-    slots = (conv_q._slot, conv_k._slot, conv_v._slot)
+def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site, packed=None):
+    """packed: hip/conv.py::PackedConv of the three projections (one launch each way) or None (three)"""
+    slots = (packed._slot,) if packed is not None and packed._slot is not None else (conv_q._slot, conv_k._slot, conv_v._slot)
     if any(s is None for s in slots):
         raise L.EvtError("rel_self_attention before WeightBank.attach(); there is no eager fallback")
     return RelSelfAttnFn.apply(x, slots[0].bank.anchor, emb_k, emb_v, lens, slots, int(n_heads), int(window), float(p),

@@ -96,6 +96,21 @@ class MultiHeadAttention(nn.Module):
         nn.init.xavier_uniform_(self.conv_k.weight)
         nn.init.xavier_uniform_(self.conv_v.weight)
         self._site = new_site()      # dropout stream id of the fused attention launch
+        self._qkv_packed = None      # hip/conv.py::PackedConv of the three projections, set by the bf16 WeightBank
+
+    def qkv_pack_modules(self):
+        """the three projections when they can run as ONE [3C, C] GEMM: windowed self-attention layers (the fused path)"""
+        qkv = (self.conv_q, self.conv_k, self.conv_v)
+        if self.window_size is None or not all(isinstance(c, PointwiseEvtConv) for c in qkv):
+            return None
+        return qkv
+
+    def arena_adjacent(self):
+        """parameter groups the runtime's arena lays out back to back (runtime.ParamArena), so that the packed projection is
+        a dense matrix over the members' own storage"""
+        if self.qkv_pack_modules() is None:
+            return []
+        return [["conv_q.weight", "conv_k.weight", "conv_v.weight"], ["conv_q.bias", "conv_k.bias", "conv_v.bias"]]
 
     @staticmethod
     def _rel_to_abs(x):
@@ -143,7 +158,7 @@ class MultiHeadAttention(nn.Module):
         if lens is not None and self.fused_ok(x, c):
             p = self.drop.p if self.training else 0.0
             out = rel_self_attention(x, self.conv_q, self.conv_k, self.conv_v, self.emb_rel_k, self.emb_rel_v, lens,
-                                     self.n_heads, self.window_size, p, self._site)
+                                     self.n_heads, self.window_size, p, self._site, packed=self._qkv_packed)
             return self.conv_o(out)
         b, t_t, _ = x.shape
         t_s = c.size(1)

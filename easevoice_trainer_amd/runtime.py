@@ -27,6 +27,25 @@ class ParamArena:
         GEMM image is padded to more rows than the parameter has (hip/linear.py)"""
         self.device = torch.device(device)
         params = [(n, p) for n, p in model.named_parameters()]
+        # sub-modules may ask for some of their parameters to sit next to each other (`arena_adjacent()`: lists of
+        # relative names), e.g. the q / k / v projection weights of an attention layer, which then form ONE dense
+        # [3C, C] matrix for a single GEMM launch (hip/conv.py::PackedConv).  The arena order is otherwise the
+        # registration order; nothing but the offsets depends on it.
+        order = [n for n, _ in params]
+        for mod_name, mod in model.named_modules():
+            fn = getattr(mod, "arena_adjacent", None)
+            if fn is None:
+                continue
+            for group in fn():
+                full = [f"{mod_name}.{r}" if mod_name else r for r in group]
+                if any(n not in order for n in full):
+                    continue
+                first = min(order.index(n) for n in full)
+                pos = sum(1 for n in order[:first] if n not in full)
+                rest = [n for n in order if n not in full]
+                order = rest[:pos] + full + rest[pos:]
+        by_name = dict(params)
+        params = [(n, by_name[n]) for n in order]
         offs, total = {}, 0
         reserve = reserve or {}
         for n, p in params:

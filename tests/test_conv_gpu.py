@@ -29,6 +29,7 @@ CASES = [
     # 1x1 projections that used to be vendor GEMMs: flow post 192->96, the style encoder's linears (704->128, 128->512)
     # and the weight-normed conditioning layers applied to a [B, 512] vector as ONE sequence of B rows
     (192, 96, 1, 1, 0, 1, 1, False, False, 45, 2),
+    (192, 576, 1, 1, 0, 1, 1, False, False, 200, 3),     # packed q|k|v projection, 600 rows (ragged 64-row stage)
     (704, 128, 1, 1, 0, 1, 1, False, False, 40, 2),
     (128, 512, 1, 1, 0, 1, 1, False, False, 33, 2),
     (512, 1536, 1, 1, 0, 1, 1, False, True, 16, 1),
@@ -153,6 +154,7 @@ RING_CASES = [
     (192, 768, 3, 1, 1, 1, 1, False, False, 61, 16),     # ragged last position tile
     (768, 192, 3, 1, 1, 1, 1, False, False, 60, 16),
     (128, 64, 5, 3, 2, 1, 1, False, True, 310, 24),       # strided forward, polyphase backward-data
+    (192, 576, 1, 1, 0, 1, 1, False, False, 200, 16),     # the packed q|k|v projection (9 output tiles of 64)
 ]
 
 

@@ -98,8 +98,9 @@ def test_relattn_dropout_consistency(gpu):
     assert abs(out.float().mean().item() - out0.float().mean().item()) < 0.05
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["three-launches", "packed-qkv"])
 @pytest.mark.parametrize("shape", [(2, 37, 2, 96), (3, 200, 2, 96)])
-def test_self_attention_block_parity(gpu, shape):
+def test_self_attention_block_parity(gpu, shape, packed):
     """MultiHeadAttention (q / k / v / o projections + relative attention core, attentions.py:179-292) through the fused
     node hip/enc.py::RelSelfAttnFn (three 1x1 conv launches + evt_relattn_*; chained backward-data launches, fused bias
     gradients) against oracle/s2_step.py::mha on the same bf16-rounded weights and inputs: output, dx and every
@@ -119,9 +120,19 @@ def test_self_attention_block_parity(gpu, shape):
             if n_.endswith("bias"):
                 p_.normal_(0, 0.1)
                 p_.copy_(p_.bfloat16().float())
-    bank = HC.WeightBank(m, torch.bfloat16, gpu)
-    bank.build_tables()
-    bank.fold()
+    if packed:
+        # inside a runtime the three projection weights are adjacent in the arena and run as ONE [3C, C] GEMM
+        from easevoice_trainer_amd.runtime import ModelRuntime
+        rt = ModelRuntime(m, torch.bfloat16, gpu)
+        rt.prepare()
+        assert m._qkv_packed is not None and m._qkv_packed._slot is not None
+        finish = rt.finish_grads
+    else:
+        bank = HC.WeightBank(m, torch.bfloat16, gpu)
+        bank.build_tables()
+        bank.fold()
+        assert m._qkv_packed is None
+        finish = bank.grads
     x = (torch.randn(B, T, C, device=gpu) * 1.2).bfloat16()
     lens = torch.tensor([T, max(3, T // 2), 1][:B], device=gpu, dtype=torch.int32)
     live = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)     # [B, T, 1]
@@ -131,7 +142,7 @@ def test_self_attention_block_parity(gpu, shape):
     xg = x.clone().requires_grad_(True)
     out = m(xg, xg, None, lens=lens)
     ((out.float() * live) * wgt).sum().backward()
-    bank.grads()
+    finish()
     torch.cuda.synchronize()
 
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict(keep_vars=True).items()}
