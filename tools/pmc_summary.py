@@ -24,14 +24,14 @@ def main():
     order = sorted(agg, key=lambda k: -agg[k].get("GRBM_GUI_ACTIVE", 0.0))
     for k in order[:30]:
         v = agg[k]
-        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0      # the CSV sums the counter over the 8 XCDs: /8 = kernel cycles
         line = f"{k:70s} dispatches {len(disp[k]):5d}"
         if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
             line += f"  MfmaUtil {100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024):5.1f}%"
         if gui and "SQ_ACTIVE_INST_VALU" in v:
-            line += f"  VALU-issue {100 * v['SQ_ACTIVE_INST_VALU'] / (gui * 1024):5.1f}%"
+            line += f"  VALU-busy {100 * 4 * v['SQ_ACTIVE_INST_VALU'] / (gui * 1024):5.1f}%"      # quad-cycles
         if "SQ_WAVE_CYCLES" in v and gui:
-            line += f"  waves/SIMD {v['SQ_WAVE_CYCLES'] / (gui * 1024):4.2f}"
+            line += f"  waves/SIMD {4 * v['SQ_WAVE_CYCLES'] / (gui * 1024):4.2f}"
         print(line)
         print("      " + "  ".join(f"{c}={x:.3g}" for c, x in sorted(v.items())))
 
