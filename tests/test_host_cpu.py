@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from torch import nn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -314,3 +315,60 @@ def test_single_gpu_id_selects_that_device(monkeypatch):
     assert init_process_group_from_env() == (1, 0, 0)
     monkeypatch.setenv("LOCAL_RANK", "5")
     assert init_process_group_from_env(gpu_ids="2") == (1, 0, 5)
+
+
+def test_param_arena_adjacent_groups_and_prefix_ranges():
+    """ParamArena honours a sub-module's arena_adjacent() (the q / k / v projection weights of an attention layer laid out
+    back to back, so that they form one dense matrix: hip/conv.py::PackedConv) without touching names, shapes or state_dict
+    order; range_of_prefix gives the contiguous range of a sub-model (what the data-parallel step reduces on its own)."""
+    from easevoice_trainer_amd.runtime import ParamArena
+
+    class Att(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv_q, self.conv_k, self.conv_v = nn.Linear(64, 64), nn.Linear(64, 64), nn.Linear(64, 64)
+            self.out = nn.Linear(64, 8)
+
+        def arena_adjacent(self):
+            return [["conv_q.weight", "conv_k.weight", "conv_v.weight"], ["conv_q.bias", "conv_k.bias", "conv_v.bias"]]
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pre = nn.Linear(8, 64)
+            self.att = Att()
+            self.post = nn.Linear(8, 3)
+
+    torch.manual_seed(0)
+    m = Net()
+    keys = list(m.state_dict().keys())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    a = ParamArena(m, "cpu")
+    assert list(m.state_dict().keys()) == keys and all(torch.equal(m.state_dict()[k], before[k]) for k in keys)
+    o = a.offsets
+    w = 64 * 64
+    assert o["att.conv_k.weight"] == o["att.conv_q.weight"] + w and o["att.conv_v.weight"] == o["att.conv_q.weight"] + 2 * w
+    assert o["att.conv_k.bias"] == o["att.conv_q.bias"] + 64 and o["att.conv_v.bias"] == o["att.conv_q.bias"] + 128
+    packed = a.param[o["att.conv_q.weight"]: o["att.conv_q.weight"] + 3 * w].view(192, 64)
+    assert torch.equal(packed, torch.cat([m.att.conv_q.weight, m.att.conv_k.weight, m.att.conv_v.weight]))
+    lo, hi = a.range_of_prefix("att.")
+    names = [n for n in a.names if n.startswith("att.")]
+    assert lo == min(o[n] for n in names) and hi == o["post.weight"]       # the sub-model is one contiguous range
+    lo2, hi2 = a.range_of_prefix("att.", stop_before="att.out.")
+    assert lo2 == lo and hi2 == o["att.out.weight"]
+    # gradients are views of the twin arena at the same offsets
+    assert m.att.conv_k.weight.grad.data_ptr() == a.grad.data_ptr() + 4 * o["att.conv_k.weight"]
+
+
+def test_weight_bank_row_ranges_cpu():
+    """WeightBank.rows_of: the row range of a contiguous run of convolutions (one sub-discriminator / the vocoder) in the
+    multi-tensor gradient launch; non-contiguous selections are refused"""
+    from easevoice_trainer_amd.hip import conv as HC
+
+    m = nn.ModuleList([HC.EvtConv1d(8, 16, 3, padding=1, weight_norm=True), HC.EvtConv1d(16, 16, 1),
+                       HC.EvtConv1d(16, 32, 5, padding=2, weight_norm=True)])
+    bank = HC.WeightBank(m, torch.float32, "cpu")
+    bank.build_tables()
+    assert bank.rows_of([m[0]]) == (0, 16) and bank.rows_of([m[1], m[2]]) == (16, 64) and bank.rows_of(list(m)) == (0, 64)
+    with pytest.raises(HC.L.EvtError):
+        bank.rows_of([m[0], m[2]])
