@@ -133,14 +133,26 @@ class LinearFn(torch.autograd.Function):
         p = slot.params(M, False)
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
-            if slot.bias is not None and ctx.needs_input_grad[2]:
-                db = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device)
-            L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db),
+            # inside an engine the parameters carry the fp32 view of their slot in the flat gradient arena
+            # (`_evt_grad_view`): the launch accumulates (+=) straight into it -- across the accumulation micro-batches too --
+            # and autograd gets no tensor: no zero-filled [N, K] scratch per layer and micro-step, nothing to add afterwards
+            wv = getattr(slot.weight, "_evt_grad_view", None)
+            want_b = slot.bias is not None and ctx.needs_input_grad[2]
+            bv = getattr(slot.bias, "_evt_grad_view", None) if want_b else None
+            sunk = (wv is not None and slot.Np == slot.N and wv.dtype == torch.float32 and wv.is_contiguous()
+                    and tuple(wv.shape) == (slot.N, slot.K) and (not want_b or (bv is not None and bv.numel() == slot.N)))
+            if sunk:
+                dw_buf, db_buf = wv, bv
+            else:
+                dw_buf = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
+                db_buf = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device) if want_b else None
+            L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
                                                      L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
-            if slot.Np != slot.N:
-                dw = dw[:slot.N]
-                db = db[:slot.N] if db is not None else None
+            if not sunk:
+                dw, db = dw_buf, db_buf
+                if slot.Np != slot.N:
+                    dw = dw[:slot.N]
+                    db = db[:slot.N] if db is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

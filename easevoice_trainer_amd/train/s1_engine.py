@@ -31,6 +31,8 @@ class S1Engine:
                                                 total_steps=o["decay_steps"])
         self.arena.zero_grad()
         self._views = [(p, p.grad) for p in self.model.parameters()]
+        for p, v in self._views:       # the GEMM weight-gradient launches accumulate straight into these (hip/linear.py)
+            p._evt_grad_view = v
 
     def micro_step(self, batch: dict, batch_idx: int):
         """one micro-batch: forward_old (or the DPO `forward` when config train.if_dpo, t2s_lightning_module.py:44) +

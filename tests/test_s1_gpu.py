@@ -230,6 +230,7 @@ def test_s1_dpo_matches_reference_fixture(gpu):
         c = gold["config"]
         b = s1_batch(c["B"], c["x_len"], c["y_len"])
         eng.model.zero_grad(set_to_none=True)
+        eng.arena.zero_grad()        # inside an engine the GEMM weight gradients accumulate straight into the flat arena
         torch.manual_seed(c["seed"])
         loss, acc = eng.model.forward(b["phoneme_ids"].to(gpu), torch.tensor(c["x_lens"]).to(gpu),
                                       b["semantic_ids"].to(gpu), torch.tensor(c["y_lens"]).to(gpu),
@@ -239,12 +240,16 @@ def test_s1_dpo_matches_reference_fixture(gpu):
         assert abs(float(loss) - gold["loss"]) <= 1e-3 * gold["loss"], c["seed"]
         assert abs(float(acc) - gold["acc"]) < 1e-6
         params = dict(eng.model.named_parameters())
+
+        def grad_of(p_):             # autograd's tensor, or the parameter's slot in the gradient arena (hip/linear.py)
+            return p_.grad if p_.grad is not None else p_._evt_grad_view
+
         for n, s in gold["grad_slices"].items():
-            assert rel(params[n].grad.flatten()[:96], s) < 3e-3, (c["seed"], n)
+            assert rel(grad_of(params[n]).flatten()[:96], s) < 3e-3, (c["seed"], n)
         tot = {}
         for n, p in params.items():
             top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
-            tot[top] = tot.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+            tot[top] = tot.get(top, 0.0) + float(grad_of(p).double().pow(2).sum())
         for k, v in gold["grad_sumsq"].items():
             assert abs(tot[k] - v) <= 5e-3 * v, (c["seed"], k, tot[k], v)
 
