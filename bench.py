@@ -73,7 +73,8 @@ def run_s2(args, world, rank, local):
     eng.build_optimizers()
     use_graphs = bool(getattr(args, "graphs", 0))
     if use_graphs:
-        # fixed-shape batches: after two eager steps the step is captured once and replayed as three HIP graphs
+        # fixed-shape batches: after two eager steps the step is captured once and replayed as HIP graphs (three on one GPU;
+        # ten smaller ones with the collectives between them when data-parallel)
         eng.enable_graphs(warmup_steps=2)
     B, T, t_text = args.batch, args.clip_seconds * 50, 60
     wav, ssl, text, lengths, tl = synth_s2_batch(B, T, t_text, dev, 1234 + rank)
@@ -108,7 +109,8 @@ def run_s2(args, world, rank, local):
         "config": {"workload": f"s2 SoVITS generator+discriminator GAN step, batch={B}/GPU, {args.clip_seconds} s 32 kHz "
                                f"clips (T={T} frames), configs/s2.json, random-init weights",
                    "global_batch": world * B, "parallelism": f"dp{world}",
-                   "launch": "hip-graph replay (3 graphs/step)" if use_graphs else "eager"},
+                   "launch": (f"hip-graph replay ({len(eng._program())} graphs/step"
+                              f"{', gradient reductions between them' if world > 1 else ''})") if use_graphs else "eager"},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
