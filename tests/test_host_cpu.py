@@ -372,3 +372,45 @@ def test_weight_bank_row_ranges_cpu():
     assert bank.rows_of([m[0]]) == (0, 16) and bank.rows_of([m[1], m[2]]) == (16, 64) and bank.rows_of(list(m)) == (0, 64)
     with pytest.raises(HC.L.EvtError):
         bank.rows_of([m[0], m[2]])
+
+
+def test_s2_data_parallel_program_plumbing_cpu():
+    """The data-parallel s2 step's bookkeeping without launching anything (train/s2_engine.py::_program): ten pieces
+    (D forward, six per-sub-discriminator backward pieces, two generator backward pieces, the G optimiser); the
+    sub-discriminators' arena ranges tile the discriminator arena and their weight-gradient row ranges tile the bank's row
+    table; the vocoder's range and rows are contiguous, exclude its conditioning layer's parameters and leave two rest
+    ranges; the generator is switched to the cut backward.  (The arithmetic of the overlapped step is checked on the GPU:
+    tests/test_zz_dp_overlap_gpu.py.)"""
+    import json
+    from easevoice_trainer_amd.train.s2_engine import S2Engine
+
+    class FakeReducer:
+        world = 2
+
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    eng = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
+    assert eng.overlap and eng.net_g.split_backward
+    prog = eng._program()
+    assert len(prog) == 10 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
+    # discriminator: ranges tile the arena in order, row ranges tile the row table
+    d = eng.rt_d.arena
+    at = 0
+    for lo, hi in eng._d_ranges:
+        assert lo == at and hi > lo
+        at = hi
+    assert at == d.numel
+    rows = [eng.rt_d.bank.rows_of(c) for c in eng._d_convs]
+    assert rows[0][0] == 0 and all(rows[i][1] == rows[i + 1][0] for i in range(5)) and rows[-1][1] == eng.rt_d.bank._nrows
+    # generator: the vocoder's parameters (without its conditioning layer) are one range strictly inside the arena
+    g = eng.rt_g.arena
+    lo, hi = eng._dec_range
+    names = [n for n in g.names if lo <= g.offsets[n] < hi]
+    assert names and all(n.startswith("dec.") and not n.startswith("dec.cond.") for n in names)
+    assert sum(1 for n in g.names if n.startswith("dec.") and not n.startswith("dec.cond.")) == len(names)
+    assert 0 < lo < hi < g.numel
+    rlo, rhi = eng.rt_g.bank.rows_of(eng._dec_convs)
+    assert 0 < rlo < rhi <= eng.rt_g.bank._nrows
+    # the attention layers' projections are adjacent in the generator's arena (what the packed projection needs)
+    o = g.offsets
+    pre = "enc_p.encoder_ssl.attn_layers.0."
+    assert o[pre + "conv_k.weight"] == o[pre + "conv_q.weight"] + 192 * 192 == o[pre + "conv_v.weight"] - 192 * 192
