@@ -140,10 +140,11 @@ def spawn_ranks(argv, gpu_ids, poll_s=0.2):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    stamp = os.environ.get("EVT_RUN_STAMP") or time.strftime("%Y%m%d-%H%M%S")     # one run name for all ranks (train/helper.py)
     for rank, dev in enumerate(ids):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(dev), WORLD_SIZE=str(len(ids)), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                   EVT_SPAWNED="1")
+                   EVT_SPAWNED="1", EVT_RUN_STAMP=stamp)
         procs.append(subprocess.Popen(list(argv), env=env))
     codes = [None] * len(procs)
     while any(c is None for c in codes):

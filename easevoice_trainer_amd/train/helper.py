@@ -8,7 +8,10 @@ train_logs_path = "logs"
 
 
 def generate_random_name():
-    return datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+    """timestamp name of a run without `output_model_name` (src/train/helper.py:13-15).  Ranks started by dist.spawn_ranks
+    share the launcher's stamp (EVT_RUN_STAMP): each would otherwise take its own clock reading, and ranks that start on
+    different seconds would write to -- and look for resume checkpoints in -- different directories."""
+    return os.environ.get("EVT_RUN_STAMP") or datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
 
 
 def get_gpt_train_dir(project_dir: str, name: Optional[str]):

@@ -414,3 +414,21 @@ def test_s2_data_parallel_program_plumbing_cpu():
     o = g.offsets
     pre = "enc_p.encoder_ssl.attn_layers.0."
     assert o[pre + "conv_k.weight"] == o[pre + "conv_q.weight"] + 192 * 192 == o[pre + "conv_v.weight"] - 192 * 192
+
+
+def test_spawned_ranks_share_the_run_name(tmp_path):
+    """a run without output_model_name gets a timestamp name; the ranks of one launch must agree on it"""
+    import sys
+    from easevoice_trainer_amd.dist import spawn_ranks
+
+    w = tmp_path / "w.py"
+    w.write_text(f"""
+import os, sys, time
+sys.path.insert(0, {ROOT!r})
+time.sleep(1.2 * int(os.environ['RANK']))          # ranks reach the naming code on different seconds
+from easevoice_trainer_amd.train.helper import get_sovits_train_dir
+open(os.path.join({str(tmp_path)!r}, 'name' + os.environ['RANK']), 'w').write(get_sovits_train_dir('/p', ''))
+""")
+    assert spawn_ranks([sys.executable, str(w)], [0, 1]) == [0, 0]
+    a, b = (tmp_path / "name0").read_text(), (tmp_path / "name1").read_text()
+    assert a == b and "sovits_" in a
