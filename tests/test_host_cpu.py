@@ -432,3 +432,25 @@ open(os.path.join({str(tmp_path)!r}, 'name' + os.environ['RANK']), 'w').write(ge
     assert spawn_ranks([sys.executable, str(w)], [0, 1]) == [0, 0]
     a, b = (tmp_path / "name0").read_text(), (tmp_path / "name1").read_text()
     assert a == b and "sovits_" in a
+
+
+def test_attention_dropout_hash_statistics():
+    """the counter hash behind the s1 attention dropout mask (csrc/attention.hip: one 32-bit hash decides the keys k and
+    k ^ 16 of a query through its two 16-bit halves; python mirror in tests/test_s1_gpu.py, which the GPU parity test
+    checks the kernels against): drop rate = p, no structure between neighbouring keys, the two halves of one hash,
+    neighbouring queries or neighbouring (batch, head) slices"""
+    from test_s1_gpu import _hash_keep
+
+    L_, p = 512, 0.1
+    thr16 = int(p * 65536.0 + 0.5)
+    drop = torch.stack([(~_hash_keep(seed, bh, L_, thr16)).double() for bh in range(0, 64, 7) for seed in (0, 12345, 0xDEADBEEF)])
+    assert abs(drop.mean().item() - p) < 1e-3
+    assert abs(drop.mean(dim=2).std().item() - (p * (1 - p) / L_) ** 0.5) < 3e-3        # per-query rates spread like Bernoulli draws
+    c = drop - drop.mean()
+    var = (c * c).mean()
+
+    def corr(a, b):
+        return abs(((a * b).mean() / var).item())
+
+    assert corr(c[:, :, :-1], c[:, :, 1:]) < 0.02 and corr(c[:, :, :-16], c[:, :, 16:]) < 0.02     # key neighbours, hash halves
+    assert corr(c[:, :-1, :], c[:, 1:, :]) < 0.02 and corr(c[:-1], c[1:]) < 0.02                   # queries, slices
