@@ -34,21 +34,17 @@ S2_BUCKET_BOUNDARIES = [32] + list(range(300, 2000, 100))  # src/train/sovits.py
 def load_symbol_table(exp_dir=None):
     """symbol -> id map of `cleaned_text_to_sequence` (src/easevoice/text/__init__.py:4-13).
 
-    Looked up in: $EVT_SYMBOLS_JSON, <exp_dir>/symbols.json (a JSON list, index == id), then the reference package
-    itself when this runs inside a reference checkout."""
+    Looked up in: $EVT_SYMBOLS_JSON, then <exp_dir>/symbols.json (a JSON list, index == id).  The table is data of the
+    reference's text front-end; `tools/dump_symbols.py <reference checkout> <exp_dir>/symbols.json` writes it once.  The
+    product never imports the reference."""
     for path in (os.environ.get("EVT_SYMBOLS_JSON"), os.path.join(exp_dir, "symbols.json") if exp_dir else None):
         if path and os.path.isfile(path):
             with open(path, "r", encoding="utf8") as f:
                 symbols = json.load(f)
             return {s: i for i, s in enumerate(symbols)}
-    try:
-        from src.easevoice.text.symbols import SYMBOLS_TO_ID  # noqa: reference checkout on sys.path (drop-in use)
-
-        return dict(SYMBOLS_TO_ID)
-    except Exception as e:
-        raise FileNotFoundError(
-            "phoneme table not found: set EVT_SYMBOLS_JSON or put symbols.json (tools/dump_symbols.py) next to the "
-            "feature directories, or run inside a reference checkout where src.easevoice.text is importable") from e
+    raise FileNotFoundError(
+        "phoneme table not found: set EVT_SYMBOLS_JSON or put symbols.json (tools/dump_symbols.py) next to the feature "
+        "directories")
 
 
 def read_name2text(path):
