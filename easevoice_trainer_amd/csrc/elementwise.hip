@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* item
   const evt_wprep_item it = items[rows[2 * trow]];
   const int d0 = rows[2 * trow + 1];
   const evt_wlayout& L = it.lay;
-  const int n = L.d1 * L.k;
+  const int n = (it.src_d1 ? it.src_d1 : L.d1) * L.k;     // src_d1: the image has more (zero) columns than the parameter
   const float* v = it.v + (long)d0 * n;
   float scale = 1.f;
   if (it.g) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void wn_grad_kernel(const evt_wprep_item* item
   if (!it.dw) return;     // no gradient image: e.g. a member of a packed projection, whose .grad the pack's rows update
   const int d0 = rows[2 * blockIdx.x + 1];
   const evt_wlayout& L = it.lay;
-  const int n = L.d1 * L.k;
+  const int n = (it.src_d1 ? it.src_d1 : L.d1) * L.k;
   const float* v = it.v + (long)d0 * n;
   float* dv = it.dv + (long)d0 * n;
   if (!it.g) {

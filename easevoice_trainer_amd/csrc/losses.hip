@@ -120,7 +120,7 @@ int64_t evt_workspace_bytes(int32_t op, const int64_t* dims, int32_t ndims) {
       return 4 * evt_mel_workspace_floats((int32_t)dims[0], (int32_t)dims[1], (int32_t)dims[2], (int32_t)dims[3],
                                           (int32_t)dims[4]);
     case EVT_WS_ATTN_BWD:      // dims: B, H, L -> delta_ws fp32 [B][H][L]
-    case EVT_WS_RELATTN_BWD:   // dims: B, H, T -> delta_ws fp32 [B*H][T]
+    case EVT_WS_MHA_BWD:   // dims: B, H, Tq -> delta_ws fp32 [B*H][Tq]
       if (ndims != 3) return -1;
       return 4 * dims[0] * dims[1] * dims[2];
     case EVT_WS_MASKED_KL:     // out2: (sum, live frames)

@@ -210,6 +210,7 @@ class WeightBank:
             it.dg = g.grad.data_ptr() if g is not None else None
             it.lay = s.layout
             it.dtype = self.dt
+            it.src_d1 = int(getattr(m, "src_d1", 0))
             items.append(it)
             rows.extend((i, r) for r in range(s.layout.d0))
         self._items = L.struct_to_device(items, self.device)
@@ -257,6 +258,75 @@ class WeightBank:
             return
         rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
         L.check(L.lib().evt_wn_grad_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_grad_multi")
+
+
+class FrozenConv:
+    """geometry + tensor getters of a convolution whose weight is never trained (ssl_proj, the RVQ codebook as a 1x1
+    layer): what ConvSlot / _fwd need from a module, nothing that WeightBank would pick up from model.modules()"""
+    weight_norm, kdims, transposed, groups, dil = False, 1, False, 1, 1
+
+    def __init__(self, weight_fn, bias_fn, cin, cout, k=1, stride=1, padding=0):
+        self.weight_fn, self.bias_fn = weight_fn, bias_fn
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, padding
+        self._slot = None
+
+    @property
+    def v(self):
+        w = self.weight_fn()
+        return w if w.dim() == 3 else w.unsqueeze(-1)
+
+    @property
+    def bias(self):
+        return self.bias_fn() if self.bias_fn is not None else None
+
+    def lout(self, lin):
+        return (lin + 2 * self.pad - (self.k - 1) - 1) // self.stride + 1
+
+
+class FrozenBank:
+    """fp32 images of weights outside the trained bank -- the s2 quantizer path runs in fp32 whatever the compute dtype of
+    the step (models.py:912-921 disables autocast there).  Folded on first use and again whenever the tensors were
+    replaced or written through torch (load_state_dict, the k-means initialisation): torch's version counters tell."""
+    weight_grads = False
+
+    def __init__(self, convs, device, impl=L.IMPL_AUTO):
+        self.dt, self.dtype, self.device, self.impl = L.DT_F32, torch.float32, torch.device(device), impl
+        self.slots, offs, reg_n, alt_n = [], [], 0, 0
+        for m in convs:
+            lay = conv_layout(self.dt, m.cin, m.cout, m.k, m.stride, m.pad, m.dil, m.groups, m.transposed)
+            s = ConvSlot(m, lay, self)
+            m._slot = s
+            self.slots.append(s)
+            offs.append((reg_n, alt_n))
+            reg_n += (lay.reg_elems + 127) // 128 * 128
+            alt_n += (lay.alt_elems + 127) // 128 * 128
+        self.reg_arena = torch.zeros(max(reg_n, 1), dtype=torch.float32, device=device)
+        self.alt_arena = torch.zeros(max(alt_n, 1), dtype=torch.float32, device=device)
+        for s, (ro, ao) in zip(self.slots, offs):
+            s.reg = self.reg_arena[ro: ro + s.layout.reg_elems]
+            s.alt = self.alt_arena[ao: ao + s.layout.alt_elems]
+        self._stamp = self._items = None
+
+    def prepare(self):
+        vs = [s.module.v for s in self.slots]
+        stamp = tuple((v.data_ptr(), v._version) for v in vs)
+        if stamp == self._stamp:
+            return
+        items, rows = [], []
+        for i, (s, v) in enumerate(zip(self.slots, vs)):
+            if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                raise L.EvtError("FrozenBank: contiguous fp32 weights on the bank's device expected")
+            it = L.WPrepItem()
+            it.v, it.g, it.reg, it.alt = v.data_ptr(), None, s.reg.data_ptr(), s.alt.data_ptr()
+            it.dw = it.dv = it.dg = None
+            it.lay, it.dtype = s.layout, self.dt
+            items.append(it)
+            rows.extend((i, r) for r in range(s.layout.d0))
+        self._items = L.struct_to_device(items, self.device)
+        self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+        L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), L.ptr(self._rows), len(rows), L.stream_ptr()),
+                "evt_wn_fold_multi")
+        self._stamp = stamp
 
 
 TRACE = None   # profiling only (set_trace): (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch

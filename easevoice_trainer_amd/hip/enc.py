@@ -99,73 +99,152 @@ def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
     return ResDropLNFn.apply(x, y, gamma, beta, lens, float(p), int(site), float(eps))
 
 
-class RelAttnFn(torch.autograd.Function):
-    """Fused windowed relative-position self-attention core (csrc/relattn.hip) on a packed projection
-    qkv [B, T, 3*H*D] (bf16): one launch forward, two backward; returns [B, T, H*D]."""
+def _mha_params(dtype, B, H, D, Tq, Tk, window, n_heads_rel, ldq, ldk, ldo, scale, p, site, device):
+    """evt_mha_params (include/evt.h): window None = no relative positions"""
+    return L.MhaParams(L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32, B, H, D, Tq, Tk,
+                       -1 if window is None else int(window), int(n_heads_rel), ldq, ldk, ldo, float(scale), float(p),
+                       int(site), 0, rng_counter(device).data_ptr())
+
+
+class MhaCoreFn(torch.autograd.Function):
+    """Multi-head attention core (csrc/mha.hip) on projected rows: q [B, Tq, H*D], k / v [B, Tk, H*D] in bf16 or fp32 ->
+    [B, Tq, H*D].  window None: plain attention (MRTE cross-attention, style self-attention); window w: the
+    relative-position self-attention of enc_p with its two [Hr, 2w+1, D] embeddings.  One launch forward, two backward."""
 
     @staticmethod
-    def forward(ctx, qkv, emb_k, emb_v, lens, n_heads, window, p, site):
+    def forward(ctx, q, k, v, emb_k, emb_v, lens_q, lens_k, n_heads, window, p, site, scale):
+        B, Tq, Cc = q.shape
+        Tk = k.size(1)
+        if q.dtype not in (torch.bfloat16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype:
+            raise L.EvtError(f"mha: q / k / v must share bf16 or fp32, got {q.dtype} {k.dtype} {v.dtype}")
+        if Cc % n_heads or k.shape != (B, Tk, Cc) or v.shape != k.shape:
+            raise L.EvtError(f"mha: shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} heads {n_heads}")
+        if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+            raise L.EvtError("mha: contiguous q / k / v expected (a packed projection goes through rel_attention)")
+        D = Cc // n_heads
+        ek = emb_k.contiguous() if window is not None else None
+        ev = emb_v.contiguous() if window is not None else None
+        out = torch.empty((B, Tq, Cc), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B * n_heads, Tq), dtype=torch.float32, device=q.device)
+        hr = ek.size(0) if ek is not None else 1
+        prm = _mha_params(q.dtype, B, n_heads, D, Tq, Tk, window, hr, Cc, Cc, Cc, scale, p, site, q.device)
+        L.check(L.lib().evt_mha_fwd(C.byref(prm), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(ek), L.ptr(ev), L.ptr(lens_q), L.ptr(lens_k),
+                                    L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_mha_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, ek, ev, lens_q, lens_k)
+        ctx.cfg = (n_heads, window, p, site, scale)
+        ctx.sinks = (grad_sink(emb_k), grad_sink(emb_v)) if window is not None else (None, None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, out, lse, ek, ev, lens_q, lens_k = ctx.saved_tensors
+        n_heads, window, p, site, scale = ctx.cfg
+        B, Tq, Cc = q.shape
+        Tk = k.size(1)
+        d_o = d_o.contiguous()
+        dq = torch.empty((B, Tq, Cc), dtype=q.dtype, device=q.device)
+        dkv = torch.empty((2, B, Tk, Cc), dtype=q.dtype, device=q.device)
+        sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
+        demb = None
+        if window is not None:
+            demb = ctx.sinks if sunk else torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=q.device)
+        delta = torch.empty_like(lse)
+        hr = ek.size(0) if ek is not None else 1
+        prm = _mha_params(q.dtype, B, n_heads, Cc // n_heads, Tq, Tk, window, hr, Cc, Cc, Cc, scale, p, site, q.device)
+        L.check(L.lib().evt_mha_bwd(C.byref(prm), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(d_o), L.ptr(lse), L.ptr(ek), L.ptr(ev),
+                                    L.ptr(lens_q), L.ptr(lens_k), L.ptr(dq), L.ptr(dkv[0]), L.ptr(dkv[1]),
+                                    L.ptr(demb[0]) if demb is not None else None,
+                                    L.ptr(demb[1]) if demb is not None else None, L.ptr(delta), L.stream_ptr()),
+                "evt_mha_bwd")
+        dek = dev = None
+        if window is not None and not sunk:
+            dek, dev = demb[0], demb[1]
+        return dq, dkv[0], dkv[1], dek, dev, None, None, None, None, None, None, None
+
+
+def mha_core(q, k, v, lens_q, lens_k, n_heads, p, site, scale, emb_k=None, emb_v=None, window=None):
+    return MhaCoreFn.apply(q, k, v, emb_k, emb_v, lens_q, lens_k, int(n_heads), window, float(p), int(site), float(scale))
+
+
+class RelAttnFn(torch.autograd.Function):
+    """The attention core on a packed projection qkv [B, T, 3*H*D] (bf16 or fp32; rows [q | k | v], the layout the packed
+    [3C, C] projection GEMM writes): gradients come back as one packed [B, T, 3*H*D] tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv, emb_k, emb_v, lens, n_heads, window, p, site, scale):
         B, T, C3 = qkv.shape
         Cc = C3 // 3
-        if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or C3 % 3 or Cc % n_heads:
-            raise L.EvtError(f"relattn: packed bf16 contiguous [B, T, 3*H*D] expected, got {tuple(qkv.shape)} {qkv.dtype}")
+        if qkv.dtype not in (torch.bfloat16, torch.float32) or not qkv.is_contiguous() or C3 % 3 or Cc % n_heads:
+            raise L.EvtError(f"mha: packed contiguous [B, T, 3*H*D] expected, got {tuple(qkv.shape)} {qkv.dtype}")
         D = Cc // n_heads
-        ek, ev = emb_k.contiguous(), emb_v.contiguous()
+        ek = emb_k.contiguous() if window is not None else None
+        ev = emb_v.contiguous() if window is not None else None
         out = torch.empty((B, T, Cc), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B * n_heads, T), dtype=torch.float32, device=qkv.device)
-        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), C3, Cc, p, site, rng_counter(qkv.device).data_ptr())
+        hr = ek.size(0) if ek is not None else 1
+        scale = D ** -0.5 if scale is None else scale
+        prm = _mha_params(qkv.dtype, B, n_heads, D, T, T, window, hr, C3, C3, Cc, scale, p, site, qkv.device)
         base, esz = qkv.data_ptr(), qkv.element_size()
-        L.check(L.lib().evt_relattn_fwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
-                                        C.c_void_p(base + 2 * Cc * esz), L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(out),
-                                        L.ptr(lse), L.stream_ptr()), "evt_relattn_fwd")
+        L.check(L.lib().evt_mha_fwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
+                                    C.c_void_p(base + 2 * Cc * esz), L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(lens),
+                                    L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_mha_fwd")
         ctx.save_for_backward(qkv, out, lse, ek, ev, lens)
-        ctx.cfg = (n_heads, window, p, site)
+        ctx.cfg = (n_heads, window, p, site, scale)
         return out
 
     @staticmethod
     def backward(ctx, d_o):
         qkv, out, lse, ek, ev, lens = ctx.saved_tensors
-        n_heads, window, p, site = ctx.cfg
+        n_heads, window, p, site, scale = ctx.cfg
         B, T, C3 = qkv.shape
         Cc = C3 // 3
         d_o = d_o.contiguous()
         dqkv = torch.empty_like(qkv)
-        demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=qkv.device)   # one fill for both
-        dek, dev = demb[0], demb[1]
+        demb = None
+        if window is not None:
+            demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=qkv.device)   # one fill for both
         delta = torch.empty_like(lse)
-        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), C3, Cc, p, site,
-                              rng_counter(qkv.device).data_ptr())
+        hr = ek.size(0) if ek is not None else 1
+        prm = _mha_params(qkv.dtype, B, n_heads, Cc // n_heads, T, T, window, hr, C3, C3, Cc, scale, p, site, qkv.device)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
-        L.check(L.lib().evt_relattn_bwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
-                                        C.c_void_p(base + 2 * Cc * esz), L.ptr(out), L.ptr(d_o), L.ptr(lse), L.ptr(ek),
-                                        L.ptr(ev), L.ptr(lens), C.c_void_p(dbase), C.c_void_p(dbase + Cc * esz),
-                                        C.c_void_p(dbase + 2 * Cc * esz), L.ptr(dek), L.ptr(dev), L.ptr(delta),
-                                        L.stream_ptr()), "evt_relattn_bwd")
-        return dqkv, dek, dev, None, None, None, None, None
+        L.check(L.lib().evt_mha_bwd(C.byref(prm), C.c_void_p(base), C.c_void_p(base + Cc * esz),
+                                    C.c_void_p(base + 2 * Cc * esz), L.ptr(out), L.ptr(d_o), L.ptr(lse), L.ptr(ek),
+                                    L.ptr(ev), L.ptr(lens), L.ptr(lens), C.c_void_p(dbase),
+                                    C.c_void_p(dbase + Cc * esz), C.c_void_p(dbase + 2 * Cc * esz),
+                                    L.ptr(demb[0]) if demb is not None else None,
+                                    L.ptr(demb[1]) if demb is not None else None, L.ptr(delta), L.stream_ptr()),
+                "evt_mha_bwd")
+        return (dqkv, demb[0] if demb is not None else None, demb[1] if demb is not None else None, None, None, None,
+                None, None, None)
 
 
-def rel_attention(qkv, emb_k, emb_v, lens, n_heads, window, p, site):
-    return RelAttnFn.apply(qkv, emb_k, emb_v, lens, int(n_heads), int(window), float(p), int(site))
+def rel_attention(qkv, emb_k, emb_v, lens, n_heads, window, p, site, scale=None):
+    return RelAttnFn.apply(qkv, emb_k, emb_v, lens, int(n_heads), window, float(p), int(site), scale)
 
 
 class RelSelfAttnFn(torch.autograd.Function):
-    """The q / k / v projections (three 1x1 convs of the fused conv family, attentions.py:196-205 of the reference) AND the
-    fused relative-position attention core as ONE autograd node: x [B, T, C] bf16 -> [B, T, C].
-    Forward: three k = 1 conv launches write the planes of one [3, B, T, C] buffer, evt_relattn_fwd reads them through its
-    three row pointers (row stride C).  Backward: evt_relattn_bwd, three weight-gradient launches (each also produces the
-    bias gradient), three backward-data launches chained through their add-epilogue -- so the sum over the three
-    branches needs no element-wise launch.  (Through F.linear this was: two weight concatenations, a cast of the packed
-    weight, a vendor GEMM, two more GEMMs, a column-sum launch and the concatenation's backward per layer and step.)"""
+    """The q / k / v projections (three 1x1 convs of the fused conv family, attentions.py:196-205 of the reference; the
+    style encoder's three nn.Linear, modules.py:611-613) AND the fused attention core as ONE autograd node:
+    x [B, T, C] (bf16 or fp32) -> [B, T, C].
+    Forward: three k = 1 conv launches write the planes of one [3, B, T, C] buffer (or ONE packed [3C, C] GEMM writes
+    rows [q | k | v]), evt_mha_fwd reads them through its three row pointers.  Backward: evt_mha_bwd, the
+    weight-gradient launches (each also produces the bias gradient), the backward-data launches chained through their
+    add-epilogue -- so the sum over the three branches needs no element-wise launch.  (Through F.linear this was: two
+    weight concatenations, a cast of the packed weight, a vendor GEMM, two more GEMMs, a column-sum launch and the
+    concatenation's backward per layer and step.)"""
 
     @staticmethod
-    def forward(ctx, x, anchor, emb_k, emb_v, lens, slots, n_heads, window, p, site):
+    def forward(ctx, x, anchor, emb_k, emb_v, lens, slots, n_heads, window, p, site, scale):
         from . import conv as HC
 
-        B, T, Cc = x.shape
-        if x.dtype != torch.bfloat16 or not x.is_contiguous() or Cc % n_heads:
-            raise L.EvtError(f"relattn: contiguous bf16 [B, T, C] expected, got {tuple(x.shape)} {x.dtype}")
+        B, T, _ = x.shape
+        Cc = slots[0].module.cout // 3 if len(slots) == 1 else slots[0].module.cout
+        if x.dtype != slots[0].bank.dtype or not x.is_contiguous() or Cc % n_heads:
+            raise L.EvtError(f"self-attention: contiguous {slots[0].bank.dtype} [B, T, C] expected, got "
+                             f"{tuple(x.shape)} {x.dtype}")
         D = Cc // n_heads
-        ek, ev = emb_k.contiguous(), emb_v.contiguous()
+        ek = emb_k.contiguous() if window is not None else None
+        ev = emb_v.contiguous() if window is not None else None
         packed = len(slots) == 1
         if packed:       # one [3C, C] GEMM: rows [q | k | v], row stride 3C
             qkv = torch.empty((B, T, 3 * Cc), dtype=x.dtype, device=x.device)
@@ -179,12 +258,13 @@ class RelSelfAttnFn(torch.autograd.Function):
             ld, (qp, kp, vp) = Cc, (L.ptr(qkv[0]), L.ptr(qkv[1]), L.ptr(qkv[2]))
         out = torch.empty((B, T, Cc), dtype=x.dtype, device=x.device)
         lse = torch.empty((B * n_heads, T), dtype=torch.float32, device=x.device)
-        prm = L.RelAttnParams(B, T, n_heads, D, window, ek.size(0), ld, Cc, p, site, rng_counter(x.device).data_ptr())
-        L.check(L.lib().evt_relattn_fwd(C.byref(prm), qp, kp, vp, L.ptr(ek), L.ptr(ev),
-                                        L.ptr(lens), L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_relattn_fwd")
+        hr = ek.size(0) if ek is not None else 1
+        prm = _mha_params(x.dtype, B, n_heads, D, T, T, window, hr, ld, ld, Cc, scale, p, site, x.device)
+        L.check(L.lib().evt_mha_fwd(C.byref(prm), qp, kp, vp, L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(lens),
+                                    L.ptr(out), L.ptr(lse), L.stream_ptr()), "evt_mha_fwd")
         ctx.save_for_backward(x, qkv, out, lse, ek, ev, lens)
-        ctx.cfg = (slots, n_heads, window, p, site)
-        ctx.sinks = (grad_sink(emb_k), grad_sink(emb_v))
+        ctx.cfg = (slots, n_heads, window, p, site, scale, Cc)
+        ctx.sinks = (grad_sink(emb_k), grad_sink(emb_v)) if window is not None else (None, None)
         return out
 
     @staticmethod
@@ -192,28 +272,28 @@ class RelSelfAttnFn(torch.autograd.Function):
         from . import conv as HC
 
         x, qkv, out, lse, ek, ev, lens = ctx.saved_tensors
-        slots, n_heads, window, p, site = ctx.cfg
-        B, T, Cc = x.shape
+        slots, n_heads, window, p, site, scale, Cc = ctx.cfg
+        B, T, _ = x.shape
         packed = len(slots) == 1
         d_o = d_o.contiguous()
         dqkv = torch.empty_like(qkv)
         sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
-        if sunk:
-            demb = ctx.sinks
-        else:
-            demb = torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=x.device)   # one fill for both
+        demb = None
+        if window is not None:
+            demb = ctx.sinks if sunk else torch.zeros((2,) + tuple(ek.shape), dtype=torch.float32, device=x.device)
         delta = torch.empty_like(lse)
         if packed:
             ld, esz = 3 * Cc, x.element_size()
             ptrs = [C.c_void_p(t.data_ptr() + i * Cc * esz) for t in (qkv, dqkv) for i in range(3)]
         else:
             ld, ptrs = Cc, [L.ptr(t[i]) for t in (qkv, dqkv) for i in range(3)]
-        prm = L.RelAttnParams(B, T, n_heads, Cc // n_heads, window, ek.size(0), ld, Cc, p, site,
-                              rng_counter(x.device).data_ptr())
-        L.check(L.lib().evt_relattn_bwd(C.byref(prm), ptrs[0], ptrs[1], ptrs[2], L.ptr(out), L.ptr(d_o),
-                                        L.ptr(lse), L.ptr(ek), L.ptr(ev), L.ptr(lens), ptrs[3], ptrs[4], ptrs[5],
-                                        L.ptr(demb[0]), L.ptr(demb[1]), L.ptr(delta), L.stream_ptr()),
-                "evt_relattn_bwd")
+        hr = ek.size(0) if ek is not None else 1
+        prm = _mha_params(x.dtype, B, n_heads, Cc // n_heads, T, T, window, hr, ld, ld, Cc, scale, p, site, x.device)
+        L.check(L.lib().evt_mha_bwd(C.byref(prm), ptrs[0], ptrs[1], ptrs[2], L.ptr(out), L.ptr(d_o), L.ptr(lse),
+                                    L.ptr(ek), L.ptr(ev), L.ptr(lens), L.ptr(lens), ptrs[3], ptrs[4], ptrs[5],
+                                    L.ptr(demb[0]) if demb is not None else None,
+                                    L.ptr(demb[1]) if demb is not None else None, L.ptr(delta), L.stream_ptr()),
+                "evt_mha_bwd")
         dx = None
         for i, s in enumerate(slots):
             dy = dqkv if packed else dqkv[i]
@@ -221,18 +301,21 @@ class RelSelfAttnFn(torch.autograd.Function):
                 HC._bwd_weight(s, x, dy, None, B, T, 1.0, L.ACT_NONE, 1.0)
             if ctx.needs_input_grad[0]:
                 dx = HC._bwd_data(s, dy, None, x, dx, B, T, 1.0, L.ACT_NONE, 1.0)
-        if sunk:
-            return dx, None, None, None, None, None, None, None, None, None
-        return dx, None, demb[0], demb[1], None, None, None, None, None, None
+        if sunk or window is None:
+            return dx, None, None, None, None, None, None, None, None, None, None
+        return dx, None, demb[0], demb[1], None, None, None, None, None, None, None
 
 
-def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site, packed=None):
-    """packed: hip/conv.py::PackedConv of the three projections (one launch each way) or None (three)"""
+def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site, packed=None, scale=None):
+    """packed: hip/conv.py::PackedConv of the three projections (one launch each way) or None (three); window None: no
+    relative positions (emb_k / emb_v ignored); scale None: 1/sqrt(head width)"""
     slots = (packed._slot,) if packed is not None and packed._slot is not None else (conv_q._slot, conv_k._slot, conv_v._slot)
     if any(s is None for s in slots):
         raise L.EvtError("rel_self_attention before WeightBank.attach(); there is no eager fallback")
-    return RelSelfAttnFn.apply(x, slots[0].bank.anchor, emb_k, emb_v, lens, slots, int(n_heads), int(window), float(p),
-                               int(site))
+    if scale is None:
+        scale = (conv_q.cout // n_heads) ** -0.5
+    return RelSelfAttnFn.apply(x, slots[0].bank.anchor, emb_k, emb_v, lens, slots, int(n_heads), window, float(p),
+                               int(site), float(scale))
 
 
 class WNResidualFn(torch.autograd.Function):

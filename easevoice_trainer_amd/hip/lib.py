@@ -48,7 +48,7 @@ class WPrepItem(C.Structure):
     _fields_ = [
         ("v", C.c_void_p), ("g", C.c_void_p), ("reg", C.c_void_p), ("alt", C.c_void_p),
         ("dw", C.c_void_p), ("dv", C.c_void_p), ("dg", C.c_void_p),
-        ("lay", WLayout), ("dtype", C.c_int32), ("pad_", C.c_int32),
+        ("lay", WLayout), ("dtype", C.c_int32), ("src_d1", C.c_int32),
     ]
 
 
@@ -94,10 +94,11 @@ class ScaledAdamHP(C.Structure):
                 ("scalar_lr_scale", C.c_float), ("scalar_max", C.c_float), ("step", C.c_int32), ("pad_", C.c_int32)]
 
 
-class RelAttnParams(C.Structure):
-    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("window", C.c_int32),
-                ("n_heads_rel", C.c_int32), ("ld", C.c_int64), ("ldo", C.c_int64), ("dropout_p", C.c_float),
-                ("site", C.c_uint32), ("seed_dev", C.c_void_p)]
+class MhaParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("Tq", C.c_int32),
+                ("Tk", C.c_int32), ("window", C.c_int32), ("n_heads_rel", C.c_int32), ("ldq", C.c_int64),
+                ("ldk", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("dropout_p", C.c_float),
+                ("site", C.c_uint32), ("pad_", C.c_uint32), ("seed_dev", C.c_void_p)]
 
 
 _lib = None

@@ -2,20 +2,19 @@
 
 Mirrors (names, parameter keys and arithmetic) src/easevoice/module/attentions.py:12-90 (Encoder),
 :179-292 (MultiHeadAttention with window-4 relative position embeddings), :379-435 (FFN) of the
-reference.  Tensors are [B, T, C] here ([B, C, T] in the reference); masks are [B, T, 1].
+reference.  Tensors are [B, T, C] here ([B, C, T] in the reference); padding is described by per-item lengths.
 
-T <= a few hundred frames, so the attention itself stays on rocBLAS GEMMs through torch; the two
-k=3 FFN convolutions (most of this block's MACs) run on the fused HIP conv kernel.
+Everything runs on the library: the projections and FFN convolutions on the fused conv kernels, the attention core
+(scores, relative logits, key mask, softmax, dropout, values, relative values) as one launch of csrc/mha.hip each way.
+There is no torch attention path: a shape the kernels do not cover raises.
 """
-import math
-
 import torch
 from torch import nn
 from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import EvtConv1d
-from ..hip.enc import new_site, rel_self_attention, relu_dropout, res_drop_ln
+from ..hip.enc import mha_core, new_site, rel_self_attention, relu_dropout, res_drop_ln
 
 
 class LayerNorm(nn.Module):
@@ -29,19 +28,6 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return F.layer_norm(x, (self.channels,), self.gamma, self.beta, self.eps)
-
-
-class PointwiseConv(nn.Module):
-    """nn.Conv1d(cin, cout, 1) parameters ([cout, cin, 1] weight) applied as a GEMM on [B, T, C]."""
-
-    def __init__(self, cin, cout, bias=True):
-        super().__init__()
-        c = nn.Conv1d(cin, cout, 1, bias=bias)
-        self.weight = c.weight
-        self.bias = c.bias
-
-    def forward(self, x):
-        return F.linear(x, self.weight.squeeze(-1), self.bias)
 
 
 class PointwiseEvtConv(EvtConv1d):
@@ -64,15 +50,32 @@ class PointwiseEvtConv(EvtConv1d):
         return super().forward(x.reshape(1, -1, x.size(-1))).reshape(*lead, self.cout)
 
 
+class PaddedInPointwise(PointwiseEvtConv):
+    """nn.Conv1d(cin, cout, 1) whose input width is not a multiple of 8 (enc_q.pre: the 1025 spectrogram bins,
+    models.py:338): the parameter keeps the reference's shape [cout, cin, 1]; the prepared GEMM image is padded with zero
+    columns to `cin_pad` (a multiple of 64) and the module takes rows of cin_pad values whose tail is zero
+    (hip/frontend.py::ncl_to_nlc writes them), so the projection runs on the LDS-DMA GEMM kernels like every other 1x1
+    layer instead of a vendor GEMM on unaligned rows."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout)
+        self.src_d1 = cin                       # the parameter's own row length (evt_wprep_item.src_d1)
+        self.cin = (cin + 63) // 64 * 64        # what the kernels see
+
+
 def pointwise(cin, cout):
-    """1x1 conv on [B, T, C]: the library's conv kernels whenever the rows are 16-byte aligned (both widths multiples
-    of 8); only the 1025-bin spectrogram projection of the posterior encoder stays on a vendor GEMM"""
-    return PointwiseEvtConv(cin, cout) if cin % 8 == 0 and cout % 8 == 0 else PointwiseConv(cin, cout)
+    """1x1 conv on [B, T, C] rows on the library's conv kernels; an input width that is not a multiple of 8 (only the
+    1025-bin spectrogram projection of the posterior encoder) gets a zero-padded image"""
+    if cout % 8:
+        raise L.EvtError(f"pointwise({cin}, {cout}): output rows must be 16-byte multiples")
+    return PointwiseEvtConv(cin, cout) if cin % 8 == 0 else PaddedInPointwise(cin, cout)
 
 
 def linear_rows(cin, cout):
     """an nn.Linear (state_dict keys `weight` [cout, cin], `bias`) on the same kernels"""
-    return PointwiseEvtConv(cin, cout, kdims=0) if cin % 8 == 0 and cout % 8 == 0 else nn.Linear(cin, cout)
+    if cin % 8 or cout % 8:
+        raise L.EvtError(f"linear_rows({cin}, {cout}): rows must be 16-byte multiples")
+    return PointwiseEvtConv(cin, cout, kdims=0)
 
 
 class MultiHeadAttention(nn.Module):
@@ -99,11 +102,11 @@ class MultiHeadAttention(nn.Module):
         self._qkv_packed = None      # hip/conv.py::PackedConv of the three projections, set by the bf16 WeightBank
 
     def qkv_pack_modules(self):
-        """the three projections when they can run as ONE [3C, C] GEMM: windowed self-attention layers (the fused path)"""
-        qkv = (self.conv_q, self.conv_k, self.conv_v)
-        if self.window_size is None or not all(isinstance(c, PointwiseEvtConv) for c in qkv):
+        """the three projections when they can run as ONE [3C, C] GEMM: the windowed self-attention layers of the
+        encoders (forward() takes the fused node for every self-attention call, so packing and use cannot disagree)"""
+        if self.window_size is None:
             return None
-        return qkv
+        return (self.conv_q, self.conv_k, self.conv_v)
 
     def arena_adjacent(self):
         """parameter groups the runtime's arena lays out back to back (runtime.ParamArena), so that the packed projection is
@@ -112,75 +115,27 @@ class MultiHeadAttention(nn.Module):
             return []
         return [["conv_q.weight", "conv_k.weight", "conv_v.weight"], ["conv_q.bias", "conv_k.bias", "conv_v.bias"]]
 
-    @staticmethod
-    def _rel_to_abs(x):
-        """[b, h, l, 2l-1] relative logits -> [b, h, l, l] (entry (i, j) = rel[i, j - i + l - 1]) by the
-        pad / reshape skew: pure copies forward and backward, no gather/scatter atomics."""
-        b, h, l, _ = x.shape
-        x = F.pad(x, (0, 1)).reshape(b, h, l * 2 * l)
-        x = F.pad(x, (0, l - 1)).reshape(b, h, l + 1, 2 * l - 1)
-        return x[:, :, :l, l - 1:]
-
-    @staticmethod
-    def _abs_to_rel(x):
-        """[b, h, l, l] -> [b, h, l, 2l-1] (entry (i, r) = abs[i, i + r - (l-1)], zero outside)"""
-        b, h, l, _ = x.shape
-        x = F.pad(x, (0, l - 1)).reshape(b, h, l * (2 * l - 1))
-        x = F.pad(x, (l, 0)).reshape(b, h, l, 2 * l)
-        return x[:, :, :, 1:]
-
-    def _band_to_full(self, band, length):
-        """[.., 2w+1] band around offset 0 -> [.., 2l-1] full relative axis (zeros outside the window)"""
-        w = self.window_size
-        extra = length - 1 - w
-        if extra >= 0:
-            return F.pad(band, (extra, extra))
-        return band[..., -extra: band.size(-1) + extra]
-
-    def _full_to_band(self, full, length):
-        w = self.window_size
-        extra = length - 1 - w
-        if extra >= 0:
-            return full[..., extra: extra + 2 * w + 1]
-        return F.pad(full, (-extra, -extra))
-
-    def fused_ok(self, x, c):
-        """self-attention with relative window in bf16 on the GPU -> csrc/relattn.hip"""
-        return (x is c and self.window_size is not None and x.is_cuda and x.dtype == torch.bfloat16
-                and x.is_contiguous() and isinstance(self.conv_q, PointwiseEvtConv)
-                and self.k_channels % 32 == 0 and self.k_channels <= 128 and 2 * self.window_size + 1 <= 16)
-
-    def forward(self, x, c, attn_mask=None, lens=None):
-        """x [B, Tt, C] queries, c [B, Ts, C] keys/values, attn_mask [B, 1, Tt, Ts] (1 = attend).
-        With `lens` [B] int32 (live frames, the mask being lens x lens) and bf16 self-attention, the whole core --
-        scores, relative logits, mask, softmax, dropout, values, relative values -- is one fused launch behind the three
-        1x1 projections, all of it one autograd node (hip/enc.py::RelSelfAttnFn)."""
-        if lens is not None and self.fused_ok(x, c):
-            p = self.drop.p if self.training else 0.0
-            out = rel_self_attention(x, self.conv_q, self.conv_k, self.conv_v, self.emb_rel_k, self.emb_rel_v, lens,
-                                     self.n_heads, self.window_size, p, self._site, packed=self._qkv_packed)
+    def forward(self, x, c, lens, lens_c=None):
+        """x [B, Tt, C] queries, c [B, Ts, C] keys/values (`c is x`: self-attention), lens [B] int32 live query rows,
+        lens_c [B] int32 live key rows (cross-attention).  The reference's attn_mask (attentions.py:268-269) is the outer
+        product of the two length masks: padded keys are excluded, padded query rows come out as zeros (their value is
+        discarded by every caller's own mask).
+        Self-attention: the three projections + the core are ONE autograd node (hip/enc.py::RelSelfAttnFn).
+        Cross-attention (MRTE, mrte_model.py:25-61): three projection launches + the core node."""
+        p = self.drop.p if self.training else 0.0
+        cd = self.conv_q._slot.bank.dtype if self.conv_q._slot is not None else x.dtype
+        self_attn = c is x
+        x = x.to(cd).contiguous()
+        if self_attn:
+            out = rel_self_attention(x, self.conv_q, self.conv_k, self.conv_v, getattr(self, "emb_rel_k", None),
+                                     getattr(self, "emb_rel_v", None), lens, self.n_heads, self.window_size, p,
+                                     self._site, packed=self._qkv_packed)
             return self.conv_o(out)
-        b, t_t, _ = x.shape
-        t_s = c.size(1)
-        h, d = self.n_heads, self.k_channels
-        q = self.conv_q(x).view(b, t_t, h, d).transpose(1, 2)    # [b, h, t, d]
-        k = self.conv_k(c).view(b, t_s, h, d).transpose(1, 2)
-        v = self.conv_v(c).view(b, t_s, h, d).transpose(1, 2)
-        qs = q / math.sqrt(d)
-        scores = torch.matmul(qs, k.transpose(-2, -1))
         if self.window_size is not None:
-            assert t_s == t_t, "relative attention is only available for self-attention"
-            # logits against the 2w+1 relative key embeddings, skewed onto the |i-j| <= w band
-            qe = torch.matmul(qs, self.emb_rel_k.unsqueeze(0).transpose(-2, -1))       # [b, h, l, 2w+1]
-            scores = scores + self._rel_to_abs(self._band_to_full(qe, t_s))
-        if attn_mask is not None:
-            scores = scores.masked_fill(attn_mask == 0, -1e4)
-        p_attn = self.drop(F.softmax(scores, dim=-1))
-        out = torch.matmul(p_attn, v)
-        if self.window_size is not None:
-            relw = self._full_to_band(self._abs_to_rel(p_attn), t_s)                    # [b, h, l, 2w+1]
-            out = out + torch.matmul(relw, self.emb_rel_v.unsqueeze(0))
-        out = out.transpose(1, 2).reshape(b, t_t, h * d)
+            raise L.EvtError("relative attention is only available for self-attention")       # attentions.py:259-261
+        c = c.to(cd).contiguous()
+        q, k, v = self.conv_q(x), self.conv_k(c), self.conv_v(c)
+        out = mha_core(q, k, v, lens, lens_c, self.n_heads, p, self._site, self.k_channels ** -0.5)
         return self.conv_o(out)
 
 
@@ -237,12 +192,10 @@ class Encoder(nn.Module):
         lens = (lengths if lengths is not None else x_mask.sum(dim=(1, 2))).to(torch.int32)
         mask_cd = x_mask.to(cd)
         x = (x * x_mask).to(cd).contiguous()
-        fused = self.n_layers > 0 and self.attn_layers[0].fused_ok(x, x)
-        attn_mask = None if fused else (x_mask.transpose(1, 2).unsqueeze(2) * x_mask.unsqueeze(1))   # [B, 1, T, T]
         p = self.drop.p if self.training else 0.0
         for i in range(self.n_layers):
             n1, n2 = self.norm_layers_1[i], self.norm_layers_2[i]
-            y = self.attn_layers[i](x, x, attn_mask, lens=lens).to(cd).contiguous()
+            y = self.attn_layers[i](x, x, lens)
             x = res_drop_ln(x, y, n1.gamma, n1.beta, lens, p, self._sites[2 * i], n1.eps)
             y = self.ffn_layers[i](x, mask_cd, cd, premasked=True, lens=lens)
             x = res_drop_ln(x, y, n2.gamma, n2.beta, lens, p, self._sites[2 * i + 1], n2.eps)

@@ -1,12 +1,14 @@
 """Mel / spectrogram front-end of the s2 step, src/easevoice/module/mel_processing.py:40-142.
 
 `mel_spectrogram_torch` (needs a backward: it is applied to the generated waveform) is the fused HIP
-STFT->magnitude->mel->log kernel with an analytic backward; `spec_to_mel_torch` (target side, no grad) is a
-plain GEMM; `spectrogram_torch` (dataset side) reuses the HIP kernel's magnitude output."""
+STFT->magnitude->mel->log kernel with an analytic backward; `spec_to_mel_torch` (target side, no grad) is the
+LDS-tiled projection kernel of csrc/frontend.hip (`spec_to_mel_slices`: only the frames of the training segment);
+`spectrogram_torch` (dataset side) reuses the HIP kernel's magnitude output."""
 import numpy as np
 import torch
 
 from ..hip import lib as L
+from ..hip.frontend import spec_to_mel
 
 _mel_basis = {}
 _hann_window = {}
@@ -102,6 +104,14 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
 
 
 def spec_to_mel_torch(spec, n_fft, num_mels, sampling_rate, fmin, fmax):
-    """[B, n_fft//2+1, T] -> log-mel [B, num_mels, T] (mel_processing.py:77-90); plain GEMM, no grad path."""
-    basis = _basis(n_fft, num_mels, sampling_rate, fmin, fmax, spec.device)
-    return torch.log(torch.clamp(torch.matmul(basis, spec.float()), min=1e-5))
+    """[B, n_fft//2+1, T] -> log-mel [B, num_mels, T] (mel_processing.py:77-90); no grad path."""
+    with torch.no_grad():
+        return spec_to_mel(spec, _basis(n_fft, num_mels, sampling_rate, fmin, fmax, spec.device))
+
+
+def spec_to_mel_slices(spec, ids_slice, segment_frames, n_fft, num_mels, sampling_rate, fmin, fmax):
+    """the mel of the training segments only: spec_to_mel_torch followed by commons.slice_segments(mel, ids_slice,
+    segment_frames) (sovits.py:470-480) in one launch -> [B, num_mels, segment_frames]"""
+    with torch.no_grad():
+        return spec_to_mel(spec, _basis(n_fft, num_mels, sampling_rate, fmin, fmax, spec.device), ids_slice,
+                           segment_frames)

@@ -8,7 +8,10 @@ mrte_model.py:9-61, core_vq.py:172-228), re-laid-out for the hardware:
     (tap, channel) is contiguous in HBM/LDS; the reference's [B, C, T] only exists at the module boundary;
   * every Conv1d / ConvTranspose1d / Conv2d((k,1)) is one fused HIP launch (hip/conv.py): leaky-relu
     prologue, bias / activation / residual epilogues, weight-norm folded once per step for the whole model;
-  * 1x1 convolutions on [B, T, C] are plain GEMMs (hipBLASLt through F.linear);
+  * 1x1 convolutions / nn.Linear layers on [B, T, C] rows are k = 1 members of the same conv family; the attention cores
+    (relative-position self-attention, MRTE cross-attention, style self-attention) are csrc/mha.hip; the frozen
+    quantizer, the spectrogram's layout change and the target mel are csrc/frontend.hip -- no vendor GEMM, no torch
+    matmul / softmax on the training path;
   * DiscriminatorP's period axis is laid out as extra sequences ([B*p, T/p, C]) instead of a 2-D image.
 
 There is no CPU / eager fallback: the modules need a WeightBank (hip/conv.py) and a GPU.
@@ -20,10 +23,11 @@ from torch.nn import functional as F
 
 from ..hip import lib as L
 from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
-from ..hip.enc import unbind_rows, wn_residual, wn_residual_last
+from ..hip.enc import new_site, rel_self_attention, unbind_rows, wn_residual, wn_residual_last
+from ..hip.frontend import RvqEncoder, ncl_to_nlc
 from ..hip.wn import wn_stack
 from . import commons
-from .attentions import Encoder, MultiHeadAttention, PointwiseConv, PointwiseEvtConv, linear_rows, pointwise
+from .attentions import Encoder, MultiHeadAttention, PointwiseEvtConv, linear_rows, pointwise
 
 LRELU_SLOPE = 0.1
 N_SYMBOLS = 732  # len(SYMBOLS), src/easevoice/text/symbols.py:410-412 (pinned by tests/easevoice/text_test.py)
@@ -113,7 +117,9 @@ class PosteriorEncoder(nn.Module, _ComputeDtype):
         self.proj = pointwise(hidden_channels, out_channels * 2)
 
     def forward(self, x, x_mask, g=None, eps=None, lens=None):
-        """x [B, T, spec] -> z, m, logs [B, T, out]; eps (the randn_like draw of models.py:358) may be injected"""
+        """x [B, T, self.pre.cin] channels-last in the compute dtype (the spectrogram after hip/frontend.py::ncl_to_nlc:
+        transposed, cast and zero-padded to the projection's image width in one launch) -> z, m, logs [B, T, out];
+        eps (the randn_like draw of models.py:358) may be injected"""
         if g is not None:
             g = g.detach()
         h = (self.pre(x) * x_mask).to(self.cd).contiguous()
@@ -195,12 +201,12 @@ class MRTE(nn.Module):
         self.text_pre = pointwise(content_enc_channels, hidden_size)
         self.c_post = pointwise(hidden_size, out_channels)
 
-    def forward(self, ssl_enc, ssl_mask, text, text_mask, ge):
-        """ssl_enc [B, T, C], text [B, Tt, C], ge [B, 512] or None"""
-        attn_mask = text_mask.transpose(1, 2).unsqueeze(2) * ssl_mask.unsqueeze(1)   # [B, 1, T, Tt]
+    def forward(self, ssl_enc, ssl_mask, text, text_mask, ge, ssl_lens, text_lens):
+        """ssl_enc [B, T, C], text [B, Tt, C], ge [B, 512] or None; ssl_lens / text_lens [B] int32 (the masks as lengths:
+        the reference's attn_mask = text_mask x ssl_mask, mrte_model.py:28)"""
         ssl_enc = self.c_pre(ssl_enc * ssl_mask)
         text_enc = self.text_pre(text * text_mask)
-        x = self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, attn_mask) + ssl_enc
+        x = self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, ssl_lens, text_lens) + ssl_enc
         if ge is not None:
             x = x + ge.unsqueeze(1)
         return self.c_post(x * ssl_mask)
@@ -225,12 +231,14 @@ class TextEncoder(nn.Module, _ComputeDtype):
         """y [B, T, 768] (quantized ssl), text [B, Tt] ids, ge [B, 512]; the encoders mask their own input / output.
         speed != 1 (inference only, models.py:246-248) resamples the encoded sequence to int(T/speed)+1 frames before
         the projection and returns the resampled mask as a fourth value."""
+        yl = (y_lengths if y_lengths is not None else y_mask.sum(dim=(1, 2))).to(torch.int32)
+        tl = (text_lengths if text_lengths is not None else text_mask.sum(dim=(1, 2))).to(torch.int32)
         y = self.ssl_proj(y * y_mask)
-        y = self.encoder_ssl(y, y_mask, self.cd, lengths=y_lengths)
+        y = self.encoder_ssl(y, y_mask, self.cd, lengths=yl)
         t = self.text_embedding(text)
-        t = self.encoder_text(t, text_mask, self.cd, lengths=text_lengths)
-        y = self.mrte(y, y_mask, t, text_mask, ge)
-        y = self.encoder2(y, y_mask, self.cd, lengths=y_lengths)
+        t = self.encoder_text(t, text_mask, self.cd, lengths=tl)
+        y = self.mrte(y, y_mask, t, text_mask, ge, yl, tl)
+        y = self.encoder2(y, y_mask, self.cd, lengths=yl)
         if speed != 1:
             n = int(y.size(1) / speed) + 1
             y = F.interpolate(y.transpose(1, 2).float(), size=n, mode="linear").transpose(1, 2).to(y.dtype).contiguous()
@@ -246,7 +254,9 @@ class TextEncoder(nn.Module, _ComputeDtype):
 class LinearNorm(nn.Module):
     def __init__(self, cin, cout, bias=True):
         super().__init__()
-        self.fc = linear_rows(cin, cout) if bias else nn.Linear(cin, cout, bias)
+        if not bias:
+            raise L.EvtError("LinearNorm without a bias is not used by the style encoder (modules.py:521-545)")
+        self.fc = linear_rows(cin, cout)
 
     def forward(self, x):
         return self.fc(x)
@@ -291,23 +301,24 @@ class StyleAttention(nn.Module):
         self.w_qs = linear_rows(d_model, n_head * d_k)
         self.w_ks = linear_rows(d_model, n_head * d_k)
         self.w_vs = linear_rows(d_model, n_head * d_v)
+        if d_k != d_v:
+            raise L.EvtError("the fused attention core takes one head width (d_k == d_v, as the style encoder has it)")
         self.temperature = float(d_model) ** 0.5
         self.fc = linear_rows(n_head * d_v, d_model)
         self.dropout = nn.Dropout(dropout)
         self.attn_dropout = nn.Dropout(dropout)
+        self._site = new_site()
 
-    def forward(self, x, mask=None):
-        """x [B, T, d_model]; mask [B, T, T] bool, True = masked"""
-        b, t, _ = x.shape
-        h = self.n_head
-        q = self.w_qs(x).view(b, t, h, self.d_k).transpose(1, 2)
-        k = self.w_ks(x).view(b, t, h, self.d_k).transpose(1, 2)
-        v = self.w_vs(x).view(b, t, h, self.d_v).transpose(1, 2)
-        attn = torch.matmul(q, k.transpose(-2, -1)) / self.temperature
-        if mask is not None:
-            attn = attn.masked_fill(mask.unsqueeze(1), float("-inf"))
-        attn = self.attn_dropout(F.softmax(attn, dim=-1))
-        out = torch.matmul(attn, v).transpose(1, 2).reshape(b, t, h * self.d_v)
+    def forward(self, x, lens):
+        """x [B, T, d_model]; lens [B] int32 live frames (the reference's [B, T, T] mask blocks padded KEYS with -inf,
+        modules.py:672-673).  The three projections + softmax(q k^T / sqrt(d_model)) v are one autograd node on the
+        library (hip/enc.py::RelSelfAttnFn, no relative positions); padded query rows come out as fc(0) + x and are
+        dropped by the encoder's masked mean."""
+        p = self.attn_dropout.p if self.training else 0.0
+        cd = self.w_qs._slot.bank.dtype if self.w_qs._slot is not None else x.dtype
+        x = x.to(cd).contiguous()
+        out = rel_self_attention(x, self.w_qs, self.w_ks, self.w_vs, None, None, lens, self.n_head, None, p, self._site,
+                                 scale=1.0 / self.temperature)
         return self.dropout(self.fc(out)) + x
 
 
@@ -325,14 +336,15 @@ class MelStyleEncoder(nn.Module):
                                        style_hidden // style_head, dropout)
         self.fc = LinearNorm(style_hidden, style_vector_dim)
 
-    def forward(self, x, x_mask):
-        """x [B, T, n_mel], x_mask [B, T, 1] -> [B, style_vector_dim]"""
+    def forward(self, x, x_mask, lens=None):
+        """x [B, T, n_mel], x_mask [B, T, 1], lens [B] (= x_mask.sum(1)) -> [B, style_vector_dim]"""
         pad = x_mask.squeeze(-1) == 0                     # [B, T] True = padding
-        attn_mask = pad.unsqueeze(1).expand(-1, x.size(1), -1)
+        if lens is None:
+            lens = x_mask.sum(dim=(1, 2))
         x = self.spectral(x)
         x = self.temporal(x)
         x = x.masked_fill(pad.unsqueeze(-1), 0)
-        x = self.slf_attn(x, mask=attn_mask)
+        x = self.slf_attn(x, lens.to(torch.int32))
         x = self.fc(x)
         n = (~pad).sum(dim=1, keepdim=True)
         return x.masked_fill(pad.unsqueeze(-1), 0).sum(dim=1) / n
@@ -352,12 +364,6 @@ class _Codebook(nn.Module):
         self.register_buffer("cluster_size", torch.zeros(codebook_size))
         self.register_buffer("embed", torch.zeros(codebook_size, dim))
         self.register_buffer("embed_avg", torch.zeros(codebook_size, dim))
-
-    def nearest(self, x):
-        """core_vq.py:172-180: argmax of -(|x|^2 - 2 x.e + |e|^2); x [N, D] fp32"""
-        e = self.embed.t()
-        dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
-        return dist.max(dim=-1).indices
 
     @torch.no_grad()
     def init_embed_(self, data):
@@ -410,24 +416,20 @@ class ResidualVectorQuantizer(nn.Module):
         self.n_q, self.dimension, self.bins = n_q, dimension, bins
         self.vq = _RVQ(dimension, bins, n_q)
 
-    @torch.no_grad()
-    def forward(self, x):
-        """x [B, T, D] fp32 -> (quantized [B, T, D], codes [1, B, T])"""
+    def ensure_init(self, h):
+        """h [B, T, D] fp32 projected features of the first batch.  Checked once (a host sync), not every step: without
+        a pretrained codebook, k-means on the first batch like the reference (core_vq.py:140-149); with several ranks
+        every rank takes rank 0's result (DDP's buffer broadcast does that in the reference)"""
+        if getattr(self, "_inited_ok", False):
+            return
         cb = self.vq.layers[0]._codebook
-        b, t, d = x.shape
-        if not getattr(self, "_inited_ok", False):     # checked once (a host sync), not every step
-            if not bool(cb.inited.cpu().item()):
-                # no pretrained codebook: k-means on the first batch like the reference (core_vq.py:140-149); with
-                # several ranks every rank takes rank 0's result (DDP's buffer broadcast does that in the reference)
-                cb.init_embed_(x.reshape(b * t, d))
-                import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    for buf in (cb.embed, cb.embed_avg, cb.cluster_size, cb.inited):
-                        dist.broadcast(buf, src=0)
-            self._inited_ok = True
-        ind = cb.nearest(x.reshape(b * t, d).float())
-        q = F.embedding(ind, cb.embed).view(b, t, d)
-        return q, ind.view(1, b, t)
+        if not bool(cb.inited.cpu().item()):
+            cb.init_embed_(h.reshape(-1, h.size(-1)))
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                for buf in (cb.embed, cb.embed_avg, cb.cluster_size, cb.inited):
+                    dist.broadcast(buf, src=0)
+        self._inited_ok = True
 
     @torch.no_grad()
     def decode(self, codes):
@@ -438,6 +440,15 @@ class ResidualVectorQuantizer(nn.Module):
             e = F.embedding(ind, layer._codebook.embed)
             q = e if q is None else q + e
         return q
+
+
+def rvq_encode(enc, quantizer, ssl, rep):
+    """ssl fp32 [B, D, T] -> (quantized fp32 [B, T' * rep, D], codes [1, B, T']): the projection, the k-means
+    initialisation of an empty codebook on the first call, the nearest-code look-up (hip/frontend.py::RvqEncoder)"""
+    h = enc.project(ssl)
+    quantizer.ensure_init(h)
+    q, codes = enc.lookup(h, rep)
+    return q, codes.unsqueeze(0)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -666,27 +677,28 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         self.split_backward = False      # set by a data-parallel S2Engine (see forward)
         self._cut = None
 
-    def _quantize(self, ssl_cl):
-        """ssl_proj (fp32, no grad reaches it: models.py:912-921) + code look-up + x2 nearest upsample"""
+    def _rvq(self):
+        """the fp32 images + launches of the frozen quantizer path (hip/frontend.py::RvqEncoder), built on first use"""
+        enc = getattr(self, "_rvq_enc", None)
+        cb = self.quantizer.vq.layers[0]._codebook
+        if enc is None or enc.bank.device != cb.embed.device:
+            k = 2 if self.semantic_frame_rate == "25hz" else 1
+            enc = RvqEncoder(lambda: self.ssl_proj.weight, lambda: self.ssl_proj.bias, lambda: cb.embed,
+                             cb.embed.size(1), cb.codebook_size, k, k, cb.embed.device)
+            object.__setattr__(self, "_rvq_enc", enc)
+        return enc
+
+    def _quantize(self, ssl):
+        """ssl [B, 768, T] fp32 (reference layout): ssl_proj (fp32, no grad reaches it: models.py:912-921) + code look-up
+        + x2 nearest upsample -> (quantized fp32 [B, T', 768] channels-last, codes [1, B, T'/2])"""
         with torch.no_grad(), torch.autocast("cuda", enabled=False):
-            b, t, c = ssl_cl.shape
-            w = self.ssl_proj.weight.float()
-            if self.semantic_frame_rate == "25hz":
-                t2 = t // 2
-                xr = ssl_cl[:, : 2 * t2].float().reshape(b, t2, 2 * c)
-                h = F.linear(xr, w.permute(0, 2, 1).reshape(w.size(0), 2 * c), self.ssl_proj.bias.float())
-            else:
-                h = F.linear(ssl_cl.float(), w.squeeze(-1), self.ssl_proj.bias.float())
-            q, codes = self.quantizer(h)
-            if self.semantic_frame_rate == "25hz":
-                q = q.repeat_interleave(2, dim=1)
-        return q, codes
+            return rvq_encode(self._rvq(), self.quantizer, ssl, 2 if self.semantic_frame_rate == "25hz" else 1)
 
     @torch.no_grad()
     def extract_latent(self, x):
         """ssl features [B, 768, T] -> semantic codes [B, n_q=1, T'] (models.py:1015-1018), the tokens the s1 stage
         learns to predict (6-name2semantic.tsv)"""
-        _q, codes = self._quantize(x.transpose(1, 2))
+        _q, codes = self._quantize(x)
         return codes.transpose(0, 1)
 
     @torch.no_grad()
@@ -736,16 +748,17 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         T = y.size(2)
         y_mask = commons.sequence_mask(y_lengths, T).unsqueeze(-1).to(torch.float32)        # [B, T, 1]
         text_mask = commons.sequence_mask(text_lengths, text.size(1)).unsqueeze(-1).to(torch.float32)
-        y_cl = y.transpose(1, 2)                                                               # [B, T, spec]
         amp = self.cd == torch.bfloat16
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            ref_in = y_cl if self.version == "v1" else y_cl[..., :704]
-            ge = self.ref_enc(ref_in * y_mask, y_mask)                                         # [B, gin]
-            quantized, _codes = self._quantize(ssl.transpose(1, 2))
+            lens32 = y_lengths.to(torch.int32)
+            # the spectrogram once as channels-last rows in the compute dtype, zero-padded to enc_q.pre's image width
+            y_cl = ncl_to_nlc(y.float(), self.enc_q.pre.cin, self.cd)                          # [B, T, 1088]
+            ref_in = y_cl[..., :self.spec_channels] if self.version == "v1" else y_cl[..., :704]
+            ge = self.ref_enc(ref_in * y_mask.to(self.cd), y_mask, lens32)                     # [B, gin]
+            quantized, _codes = self._quantize(ssl)
             x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
             eps_cl = eps.transpose(1, 2) if eps is not None else None
             ym = y_mask.to(self.cd)      # 0/1 mask in the compute dtype: the WN stacks stay in one dtype (no cast kernels)
-            lens32 = y_lengths.to(torch.int32)
             z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge, eps=eps_cl, lens=lens32)
             z_p = self.flow(z, ym, g=ge, lens=lens32)
             if ids_slice is None:

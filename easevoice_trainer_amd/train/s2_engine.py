@@ -21,7 +21,7 @@ from ..hip import lib as L
 from ..hip.enc import bump_rng
 from ..module import commons
 from ..module.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
-from ..module.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
+from ..module.mel_processing import mel_spectrogram_torch, spec_to_mel_slices
 from ..module.models import MultiPeriodDiscriminator, SynthesizerTrn
 from ..runtime import FlatAdamW, ModelRuntime
 
@@ -111,9 +111,8 @@ class S2Engine:
         rt_d.prepare()
         (st.y_hat, st.kl_ssl, st.ids_slice, st.x_mask, st.z_mask, st.lat, st.q) = net_g(
             st.ssl, st.spec, st.spec_lengths, st.text, st.text_lengths, eps=st.eps, ids_slice=st.ids_slice_in)
-        mel = spec_to_mel_torch(st.spec, d["filter_length"], d["n_mel_channels"], d["sampling_rate"], d["mel_fmin"],
-                                d["mel_fmax"])
-        st.y_mel = commons.slice_segments(mel.transpose(1, 2), st.ids_slice, seg // hop).transpose(1, 2)
+        st.y_mel = spec_to_mel_slices(st.spec, st.ids_slice, seg // hop, d["filter_length"], d["n_mel_channels"],
+                                      d["sampling_rate"], d["mel_fmin"], d["mel_fmax"])
         st.y_hat_mel = mel_spectrogram_torch(st.y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
                                              d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
         st.y_seg = commons.slice_segments_1d(st.y.squeeze(1), st.ids_slice * hop, seg)

@@ -49,13 +49,13 @@ void evt_debug_attn_variant(int32_t joint);
  * a wrong dims count.  The library never allocates.
  *   EVT_WS_MEL          dims = {nseq, wav_len, n_fft, hop, n_mels}   ws of evt_mel_fwd / evt_mel_bwd
  *   EVT_WS_ATTN_BWD     dims = {B, H, L}                             delta_ws of evt_attn_prefixlm_bwd
- *   EVT_WS_RELATTN_BWD  dims = {B, H, T}                             delta_ws of evt_relattn_bwd
+ *   EVT_WS_MHA_BWD      dims = {B, H, Tq}                            delta_ws of evt_mha_bwd
  *   EVT_WS_MASKED_KL    dims = {}                                    out2 of evt_masked_kl_fwd (sum, live frames)
  *   EVT_WS_NONE         every other entry point: 0 */
 #define EVT_WS_NONE 0
 #define EVT_WS_MEL 1
 #define EVT_WS_ATTN_BWD 2
-#define EVT_WS_RELATTN_BWD 3
+#define EVT_WS_MHA_BWD 3
 #define EVT_WS_MASKED_KL 4
 int64_t evt_workspace_bytes(int32_t op, const int64_t* dims, int32_t ndims);
 
@@ -121,7 +121,8 @@ typedef struct evt_wprep_item {
   float* dg;        /* [d0] fp32, += (NULL when g == NULL) */
   evt_wlayout lay;
   int32_t dtype;
-  int32_t pad_;
+  int32_t src_d1;   /* 0, or the parameter's own d1 when lay.d1 was padded up (enc_q.pre: 1025 spectrogram bins in an image
+                     * of 1088 columns); v / dv rows then hold src_d1 * k values, the image's extra columns stay zero */
 } evt_wprep_item;
 /* items is a DEVICE pointer to n items; row_index is a DEVICE int32 [nrows][2] table of
  * (item, d0-row) pairs, one workgroup each. */
@@ -197,6 +198,30 @@ int evt_mel_bwd(const float* dmel, const float* window, const float* mel_basis, 
                 float* dwav, int32_t nseq, int32_t wav_len, int32_t n_fft, int32_t hop, int32_t n_mels, void* stream);
 /* workspace floats needed by evt_mel_fwd/bwd */
 int64_t evt_mel_workspace_floats(int32_t nseq, int32_t wav_len, int32_t n_fft, int32_t hop, int32_t n_mels);
+
+/* ---------------------------------------------------------------------------------------
+ * Input front-end of the s2 step (no gradients).
+ * ------------------------------------------------------------------------------------- */
+/* Layout change at the model boundary: src fp32 [B][C][T] (the reference's layout: spectrogram, ssl features) ->
+ * dst [B][T][Cp] in `dtype`, channels c >= C written as zeros.  With Cp a multiple of 64 the 1025-bin projection
+ * enc_q.pre (models.py:348-352) runs on the library's GEMM kernels (its prepared image is padded to Cp columns). */
+int evt_ncl_to_nlc(int32_t dtype, const float* src, void* dst, int32_t B, int32_t C, int32_t T, int32_t Cp, void* stream);
+
+/* Frozen quantizer look-up (models.py:912-926 -> quantize.py:70-94 -> core_vq.py:172-228, n_q = 1, eval):
+ *   evt_rvq_norms : ee[k] = |embed[k]|^2                                                   (embed fp32 [K][D])
+ *   evt_rvq_select: code[n] = argmax_k -(|h_n|^2 - 2 dots[n][k] + ee[k]), first maximum; q_out rows n*rep .. n*rep+rep-1
+ *                   = embed[code[n]]  (rep = 2: the x2 nearest up-sampling of the 25 Hz codes)
+ * dots [N][K] = h . embed^T comes from evt_conv1d_fwd (a 1x1 layer whose weight is the codebook), h [N][D] from the
+ * ssl_proj convolution, both in fp32 whatever the compute dtype of the step (the reference disables autocast there). */
+int evt_rvq_norms(const float* embed, float* ee, int32_t K, int32_t D, void* stream);
+int evt_rvq_select(const float* h, const float* dots, const float* embed, const float* ee, int64_t* codes, float* q_out,
+                   int32_t N, int32_t D, int32_t K, int32_t rep, void* stream);
+
+/* Target-side mel (mel_processing.py:77-90 + commons.slice_segments at sovits.py:478-480):
+ *   out[b][m][f] = log(max(sum_k basis[m][k] * spec[b][k][starts[b] + f], 1e-5)),  f < nfr
+ * spec fp32 [B][F][T] (reference layout), basis fp32 [M][F], starts int64 [B] or NULL (= 0), out fp32 [B][M][nfr]. */
+int evt_spec_to_mel(const float* spec, const float* basis, const int64_t* starts, float* out, int32_t B, int32_t F,
+                    int32_t T, int32_t M, int32_t nfr, void* stream);
 
 /* Fused loss reductions (src/easevoice/module/losses.py:7-61).  Pointer tables are DEVICE arrays.
  * feature_loss: out[0] += 2 * sum_i mean|r_i - g_i| ; optional dg_i = 2*sign(g_i-r_i)/n_i * dloss. */
@@ -340,27 +365,37 @@ int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void
 int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out, const int32_t* lens,
                         int32_t rows_per_seq, void* dx, void* drs, int64_t rows, int32_t H, int32_t last, void* stream);
 
-/* Windowed relative-position multi-head SELF-attention core (attentions.py:214-292, window_size = w), bf16:
- *   scores[i][j] = (q_i . k_j + [|j-i| <= w] q_i . Ek[j-i+w]) / sqrt(D);  keys j >= lens[b] excluded
- *   p = dropout(softmax_j(scores));   out_i = sum_j p[i][j] (v_j + [|j-i| <= w] Ev[j-i+w])
- * q, k, v: bf16 rows [B][T][ld] with head h in columns [h*D, (h+1)*D) (three slices of one packed projection are fine);
- * out [B][T][ldo] likewise; emb_k / emb_v fp32 [n_heads_rel][2w+1][D]; lse fp32 [B*H][T] is saved for the backward.
- * Query rows i >= lens[b] are written as zeros.  Dropout mask = hash(*seed_dev, site, b, h, i, j). */
-typedef struct evt_relattn_params {
-  int32_t B, T, H, D;      /* D % 32 == 0, D <= 128 */
-  int32_t window;          /* w, 2w+1 <= 16 */
+/* Multi-head attention core of the s2 encoders: the windowed relative-position SELF-attention of enc_p
+ * (attentions.py:214-292, window_size = w), the window-less CROSS-attention of MRTE (mrte_model.py:25-61 -> the same
+ * MultiHeadAttention.attention with window_size = None, queries = ssl frames, keys / values = phonemes) and the style
+ * encoder's ScaledDotProductAttention (modules.py:605-682, scale = 1/sqrt(d_model)):
+ *   scores[i][j] = scale * (q_i . k_j + [window >= 0 and |j-i| <= w] q_i . Ek[j-i+w]);  keys j >= lens_k[b] excluded
+ *   p = dropout(softmax_j(scores));   out_i = sum_j p[i][j] (v_j + [window >= 0 and |j-i| <= w] Ev[j-i+w])
+ * q: rows [B][Tq][ldq], k, v: rows [B][Tk][ldk], head h in columns [h*D, (h+1)*D) (slices of one packed projection are
+ * fine); out [B][Tq][ldo] likewise, all in `dtype` (bf16: MFMA flash kernels, D % 32 == 0; fp32: the 1e-3 parity path,
+ * D % 4 == 0; D <= 128).  emb_k / emb_v fp32 [n_heads_rel][2w+1][D] (NULL when window < 0); lse fp32 [B*H][Tq] is saved
+ * for the backward.  lens_q / lens_k int32 [B] or NULL (= all rows live).  Query rows i >= lens_q[b] are written as
+ * zeros.  Dropout mask = hash(*seed_dev, site, b, h, i, j), regenerated by the backward. */
+typedef struct evt_mha_params {
+  int32_t dtype;           /* EVT_DT_* of q, k, v, out and their gradients */
+  int32_t B, H, D;
+  int32_t Tq, Tk;          /* query rows / key rows per item */
+  int32_t window;          /* w >= 0: relative positions (needs Tq == Tk, 2w+1 <= 16); < 0: none */
   int32_t n_heads_rel;     /* 1 (heads share the embeddings) or H */
-  int64_t ld, ldo;         /* row strides in elements, multiples of 8 */
+  int64_t ldq, ldk, ldo;   /* row strides in elements; 16-byte multiples */
+  float scale;             /* logit scale: 1/sqrt(D) (attentions.py:257), 1/sqrt(d_model) (modules.py:618) */
   float dropout_p;
   uint32_t site;
+  uint32_t pad_;
   const uint32_t* seed_dev;
-} evt_relattn_params;
-int evt_relattn_fwd(const evt_relattn_params* p, const void* q, const void* k, const void* v, const float* emb_k,
-                    const float* emb_v, const int32_t* lens, void* out, float* lse, void* stream);
-/* dq, dk, dv: bf16 rows with stride ld; demb_k / demb_v fp32, accumulated (+=); delta_ws fp32 [B*H][T] scratch. */
-int evt_relattn_bwd(const evt_relattn_params* p, const void* q, const void* k, const void* v, const void* o,
-                    const void* d_o, const float* lse, const float* emb_k, const float* emb_v, const int32_t* lens,
-                    void* dq, void* dk, void* dv, float* demb_k, float* demb_v, float* delta_ws, void* stream);
+} evt_mha_params;
+int evt_mha_fwd(const evt_mha_params* p, const void* q, const void* k, const void* v, const float* emb_k,
+                const float* emb_v, const int32_t* lens_q, const int32_t* lens_k, void* out, float* lse, void* stream);
+/* dq (stride ldq), dk, dv (stride ldk) in `dtype`; demb_k / demb_v fp32, accumulated (+=), NULL when window < 0;
+ * delta_ws fp32 [B*H][Tq] scratch. */
+int evt_mha_bwd(const evt_mha_params* p, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                const float* lse, const float* emb_k, const float* emb_v, const int32_t* lens_q, const int32_t* lens_k,
+                void* dq, void* dk, void* dv, float* demb_k, float* demb_v, float* delta_ws, void* stream);
 
 /* Cross-entropy, reduction="sum" (t2s_model.py:486-489): logits [rows][V] (any dtype), targets int64.
  * loss[0] += sum_r (lse_r - logit[r][t_r]); dlogits = (softmax - onehot) * dloss[0]; top-k hit counts for

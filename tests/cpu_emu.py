@@ -19,7 +19,35 @@ def _w(m):
     return m.weight.squeeze(-1) if m.kdims == 2 else m.weight
 
 
+def _attn_core(q, k, v, lens_q, lens_k, n_heads, scale, emb_k=None, emb_v=None, window=None):
+    """MultiHeadAttention.attention (attentions.py:243-292) / ScaledDotProductAttention (modules.py:664-682) on
+    channels-last rows, through the oracle's relative-position helpers; padded keys excluded, padded query rows zero"""
+    from oracle import s2_step as OS
+
+    b, tq, c = q.shape
+    tk, d = k.size(1), c // n_heads
+    qh = q.float().view(b, tq, n_heads, d).transpose(1, 2) * scale
+    kh = k.float().view(b, tk, n_heads, d).transpose(1, 2)
+    vh = v.float().view(b, tk, n_heads, d).transpose(1, 2)
+    scores = torch.matmul(qh, kh.transpose(-2, -1))
+    if window is not None:
+        ke = OS._rel_emb(emb_k, tk, window)
+        scores = scores + OS._rel2abs(torch.matmul(qh, ke.unsqueeze(0).transpose(-2, -1)))
+    live_k = torch.arange(tk)[None, :] < (lens_k if lens_k is not None else torch.full((b,), tk))[:, None]
+    live_q = torch.arange(tq)[None, :] < (lens_q if lens_q is not None else torch.full((b,), tq))[:, None]
+    scores = scores.masked_fill(~live_k[:, None, None, :], float("-inf"))
+    p = F.softmax(scores, dim=-1)
+    out = torch.matmul(p, vh)
+    if window is not None:
+        ve = OS._rel_emb(emb_v, tk, window)
+        out = out + torch.matmul(OS._abs2rel(p), ve.unsqueeze(0))
+    out = out.transpose(1, 2).reshape(b, tq, c)
+    return (out * live_q.unsqueeze(-1)).to(q.dtype)
+
+
 def _conv_forward(self, x, res=None, in_slope=1.0, out_act=0, out_slope=1.0):
+    if getattr(self, "src_d1", 0):
+        x = x[..., :self.src_d1]                  # the zero-padded tail of a PaddedInPointwise input
     y = O.conv_block(x.transpose(1, 2), _w(self), self.bias, res.transpose(1, 2) if res is not None else None,
                      stride=self.stride, pad=self.pad, dil=self.dil, groups=self.groups, transposed=self.transposed,
                      in_slope=in_slope, out_act=out_act, out_slope=out_slope)
@@ -33,6 +61,49 @@ def cpu_emulation():
     from easevoice_trainer_amd.train import s2_engine as PE
 
     saved_enc = (PA.res_drop_ln, PE.bump_rng)
+    saved_attn = (PA.rel_self_attention, PA.mha_core, PMod.rel_self_attention, PMod.ncl_to_nlc, PMod.rvq_encode,
+                  PM.spec_to_mel_torch, PM.spec_to_mel_slices, PE.spec_to_mel_slices, PA.PointwiseEvtConv.forward)
+
+    def rel_self_attention(x, conv_q, conv_k, conv_v, emb_k, emb_v, lens, n_heads, window, p, site, packed=None,
+                           scale=None):
+        assert p == 0.0, "the CPU wiring emulation has no dropout stream"
+        q, k, v = (_conv_forward(c, x) for c in (conv_q, conv_k, conv_v))
+        scale = (conv_q.cout // n_heads) ** -0.5 if scale is None else scale
+        return _attn_core(q, k, v, lens, lens, n_heads, scale, emb_k, emb_v, window)
+
+    def mha_core(q, k, v, lens_q, lens_k, n_heads, p, site, scale, emb_k=None, emb_v=None, window=None):
+        assert p == 0.0
+        return _attn_core(q, k, v, lens_q, lens_k, n_heads, scale, emb_k, emb_v, window)
+
+    def ncl_to_nlc(x, cpad=None, dtype=torch.float32):
+        y = x.transpose(1, 2)
+        if cpad is not None and cpad > y.size(-1):
+            y = F.pad(y, (0, cpad - y.size(-1)))
+        return y.to(dtype).contiguous()
+
+    def rvq_encode(enc, quantizer, ssl, rep):
+        """SynthesizerTrn's ssl_proj + EuclideanCodebook.quantize / dequantize (core_vq.py:172-190) in torch"""
+        net, cb = enc                              # (the SynthesizerTrn, its codebook): see _rvq below
+        w, bias = net.ssl_proj.weight.float(), net.ssl_proj.bias.float()
+        h = F.conv1d(ssl.float(), w, bias, stride=w.size(-1)).transpose(1, 2)            # [B, T', D]
+        quantizer.ensure_init(h)
+        x = h.reshape(-1, h.size(-1))
+        e = cb.embed.t()
+        dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
+        ind = dist.max(dim=-1).indices
+        q = F.embedding(ind, cb.embed).view(h.shape)
+        return q.repeat_interleave(rep, dim=1) if rep > 1 else q, ind.view(1, h.size(0), h.size(1))
+
+    def pointwise_forward(self, x):
+        lead = x.shape[:-1]
+        y = _conv_forward(self, x.reshape(1, -1, x.size(-1)) if x.dim() != 3 else x)
+        return y if x.dim() == 3 else y.reshape(*lead, self.cout)
+
+    saved_rvq = PMod.SynthesizerTrn._rvq
+    PMod.SynthesizerTrn._rvq = lambda self: (self, self.quantizer.vq.layers[0]._codebook)
+    PA.rel_self_attention, PA.mha_core, PMod.rel_self_attention = rel_self_attention, mha_core, rel_self_attention
+    PMod.ncl_to_nlc, PMod.rvq_encode = ncl_to_nlc, rvq_encode
+    PA.PointwiseEvtConv.forward = pointwise_forward
 
     def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
         assert p == 0.0, "the CPU wiring emulation has no dropout stream"
@@ -111,6 +182,17 @@ def cpu_emulation():
     def spectrogram_torch(y, n_fft, sr, hop, win, center=False):
         return _stft_mag(y.float(), n_fft, hop)
 
+    def spec_to_mel_torch(spec, n_fft, num_mels, sr, fmin, fmax):
+        basis = torch.from_numpy(PM.mel_filterbank(sr, n_fft, num_mels, fmin, fmax))
+        return torch.log(torch.clamp(torch.matmul(basis, spec.float()), min=1e-5))
+
+    def spec_to_mel_slices(spec, ids_slice, nfr, n_fft, num_mels, sr, fmin, fmax):
+        from easevoice_trainer_amd.module import commons
+        mel = spec_to_mel_torch(spec, n_fft, num_mels, sr, fmin, fmax)
+        return commons.slice_segments(mel.transpose(1, 2), ids_slice, nfr).transpose(1, 2)
+
+    PM.spec_to_mel_torch, PM.spec_to_mel_slices, PE.spec_to_mel_slices = spec_to_mel_torch, spec_to_mel_slices, spec_to_mel_slices
+
     def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
         z_p, logs_q, m_p, logs_p, z_mask = z_p.float(), logs_q.float(), m_p.float(), logs_p.float(), z_mask.float()
         kl = logs_p - logs_q - 0.5 + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
@@ -128,6 +210,9 @@ def cpu_emulation():
         (HC.EvtConv1d.forward, PMod.res_unit, PMod.Add3ScaleFn, PMod.GatedActFn, PL.feature_loss,
          PL.discriminator_loss, PL.generator_loss, PM.mel_spectrogram_torch, PM.spectrogram_torch) = saved
         PA.res_drop_ln, PE.bump_rng = saved_enc
+        (PA.rel_self_attention, PA.mha_core, PMod.rel_self_attention, PMod.ncl_to_nlc, PMod.rvq_encode,
+         PM.spec_to_mel_torch, PM.spec_to_mel_slices, PE.spec_to_mel_slices, PA.PointwiseEvtConv.forward) = saved_attn
+        PMod.SynthesizerTrn._rvq = saved_rvq
         PL.kl_loss, PE.kl_loss = saved_kl
         PMod.wn_residual, PMod.wn_residual_last = saved_wn
 

@@ -234,7 +234,7 @@ def test_kmeans_codebook_init_matches_reference():
         assert after_ref == after_ours
         assert torch.equal(ours.embed, ref.embed) and torch.equal(ours.embed_avg, ref.embed_avg)
         assert torch.equal(ours.cluster_size, ref.cluster_size) and float(ours.inited) == float(ref.inited) == 1.0
-        assert torch.equal(ours.nearest(data), ind_ref[0])
+        # (the nearest-code look-up on the initialised codebook is the HIP select kernel: tests/test_frontend_gpu.py)
 
 
 def _ref_optim_g(net_g, lr, low, betas, eps):
