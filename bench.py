@@ -110,7 +110,7 @@ def run_s2(args, world, rank, local):
                                f"clips (T={T} frames), configs/s2.json, random-init weights",
                    "global_batch": world * B, "parallelism": f"dp{world}",
                    "launch": (f"hip-graph replay ({len(eng._program())} graphs/step"
-                              f"{', gradient reductions between them' if world > 1 else ''})") if use_graphs else "eager"},
+                              f"{', gradient reductions between them' if world > 1 else ''})") if eng.graphs_enabled else "eager"},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }

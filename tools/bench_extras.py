@@ -63,24 +63,26 @@ def kernel_profile(run):
     return kernels, seq
 
 
-_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_)")
+_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_|resunit_|rows16_)")
 
 
 def align_records(rec, seq):
     """{record index: kernel microseconds}: trace records (launch order) against the profiler's kernel records (start
     order; one stream, so the same order).  Every traced entry point launches exactly one kernel of the conv family
     (plus, for some weight gradients, a column-sum helper), and the library's tags start with that kernel's function
-    name -- so the i-th record is the i-th conv-family kernel; the names are cross-checked."""
+    name -- so the records are a subsequence of the conv-family kernels of the run; conv-family kernels launched by an
+    untraced entry point are stepped over (greedy two-pointer match on the function name)."""
     base = lambda n: n.split("<")[0].strip()
     main = [(base(short_name(n)), us) for _t, n, us in seq if _MAIN.match(base(short_name(n)))]
-    if len(main) != len(rec):
-        return {}
-    out = {}
-    for i, (r, (kb, us)) in enumerate(zip(rec, main)):
+    out, j = {}, 0
+    for i, r in enumerate(rec):
         tb = base(r[0])
-        if not (kb == tb or kb.startswith(tb) or tb.startswith(kb)):
-            return {}
-        out[i] = us
+        while j < len(main) and not (main[j][0] == tb or main[j][0].startswith(tb) or tb.startswith(main[j][0])):
+            j += 1
+        if j >= len(main):
+            break
+        out[i] = main[j][1]
+        j += 1
     return out
 
 

@@ -1,8 +1,11 @@
 """The s1 leg of bench.py: the AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th micro-batch
 as in the reference) at BASELINE configs[2]: batch 32, x_len 256 + y_len 768 = 1024, bf16.
 metric: tokens/sec = N * B * 1024 / micro-step time.  Roofline: the attention forward kernel against the dense bf16
-MFMA peak (4 * L^2 * D * H * B flops per layer, the skippable upper triangle of the y x y block is NOT
-credited), its duration from torch.profiler's kernel records; north_star's "attention at batch 16" point is timed too."""
+MFMA peak on the flops it EXECUTES ("attention FLOPs executed / (time x peak)"): the prefix-LM mask lets a text
+row see the x text columns only and an audio row the text plus its own past, so of the L^2 score elements of a (batch,
+head) x^2 + y*x + y(y+1)/2 are computed (53 % at 256 + 768) -- the kernel skips the other tiles.  `frac_credited` keeps the
+full-square accounting (4 * L^2 * D * H * B) for comparison with earlier rounds.  Durations from torch.profiler's kernel
+records; north_star's "attention at batch 16" point is timed too; the GEMM kernels get their own TFLOP/s (`gemm`)."""
 import os
 import time
 
@@ -23,7 +26,18 @@ def _batch(B, x_len, y_len, dev, seed):
                 bert_feature=torch.randn(B, 1024, x_len, generator=g).to(dev))
 
 
-def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2):
+def _pmc_util():
+    """MFMA utilisation of the three attention kernels from the committed PMC pass (profiles/attn_pmc.json, written by
+    tools/pmc_summary.py --json from a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...` run); None when
+    the file is absent"""
+    import json
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))
+    except Exception:
+        return None
+
+
+def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2, x_len=256):
     """per-kernel records of `n_micro` micro-steps -> roofline object of the attention forward kernel (+ the two
     backward kernels and the GEMM kernels in `also`)"""
     from tools.bench_extras import kernel_profile, short_name
@@ -46,28 +60,48 @@ def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2):
         return (sum(c[0] for _, c in v), sum(c[1] for _, c in v)) if v else (0, 0.0)
 
     peak = MFMA_BF16_PEAK_TF if dtype_name == "bf16" else MFMA_F32_PEAK_TF
-    flops_fwd = 4.0 * Lq * Lq * D * H * B                  # QK^T and PV, per layer
+    y_len = Lq - x_len
+    scores_exec = x_len * x_len + y_len * x_len + y_len * (y_len + 1) // 2     # per (batch, head): what the mask leaves
+    flops_full = 4.0 * Lq * Lq * D * H * B                 # QK^T and PV over the full square, per layer
+    flops_fwd = 4.0 * scores_exec * D * H * B              # ... over the computed score elements
     calls, us = pick("attn_fwd")
     total_us = sum(c[1] for c in kernels.values())
     out = dict(bound="mfma", peak=peak, unit="TFLOP/s", traffic=None, kernel="attn_fwd_" + ("bf16" if dtype_name == "bf16" else "f32"),
                timing="torch.profiler kernel records (roctracer, the clock rocprofv3 uses)",
-               flops_per_launch=flops_fwd, causal_skip_credited=False, batch=B, seq_len=Lq, head_dim=D, heads=H)
+               flops_per_launch=flops_fwd, flops_per_launch_full_square=flops_full, executed_share=flops_fwd / flops_full,
+               causal_skip_credited=False, batch=B, seq_len=Lq, head_dim=D, heads=H)
     if calls:
         avg = us / calls
-        out.update(achieved=flops_fwd / (avg * 1e-6) / 1e12, frac=flops_fwd / (avg * 1e-6) / 1e12 / peak, avg_launch_us=avg,
+        out.update(achieved=flops_fwd / (avg * 1e-6) / 1e12, frac=flops_fwd / (avg * 1e-6) / 1e12 / peak,
+                   frac_credited=flops_full / (avg * 1e-6) / 1e12 / peak, avg_launch_us=avg,
                    launches_per_micro_step=calls / n_micro)
     else:
         out.update(achieved=None, frac=None)
+    pmc = _pmc_util()
+    if pmc is not None:
+        out["mfma_util_pmc"] = pmc
     also = {}
     for name, mult in (("attn_bwd_dq", 2.0), ("attn_bwd_dkv", 2.0)):     # each recomputes S and does two more products
         c, u = pick(name)
         if c:
             also[name] = dict(avg_us=round(u / c, 1), tflops=round(mult * flops_fwd / (u / c * 1e-6) / 1e12, 1))
     att_us = sum(pick(n)[1] for n in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_delta"))
-    gemm = sorted(((k, c) for k, c in kernels.items() if k.startswith("Cijk_") or "gemm_bf16" in k), key=lambda kv: -kv[1][1])
+    # the Linear layers run on the k = 1 members of the conv family (csrc/gemm.hip); anything named Cijk_* would be a
+    # vendor GEMM
+    is_gemm = lambda k: any(t in short_name(k) for t in ("conv_deep", "conv_ring", "wgrad_gemm", "wgrad_ring", "wgrad_deep",
+                                                          "gemm_bf16", "conv_igemm", "rows16_gemm"))
+    gemm = sorted(((k, c) for k, c in kernels.items() if k.startswith("Cijk_") or is_gemm(k)), key=lambda kv: -kv[1][1])
     out["also"] = also
     out["attention_ms_per_micro_step"] = round(att_us / 1e3 / n_micro, 3)
-    out["gemm_ms_per_micro_step"] = round(sum(c[1] for _, c in gemm) / 1e3 / n_micro, 3)
+    gemm_ms = sum(c[1] for _, c in gemm) / 1e3 / n_micro
+    out["gemm_ms_per_micro_step"] = round(gemm_ms, 3)
+    # forward MACs of the dense layers: 24 blocks x 12 d^2 per token, the vocabulary projection on the y tokens, bert_proj
+    # on the x tokens; forward + backward-data + backward-weight = 3 x 2 flops per MAC
+    macs = B * (Lq * nl * 12 * E * E + y_len * 1025 * E + x_len * 1024 * E)
+    if gemm_ms > 0:
+        tf = 6.0 * macs / (gemm_ms * 1e-3) / 1e12
+        out["gemm"] = dict(tflops=round(tf, 1), frac=round(tf / peak, 4), gflop_per_micro_step=round(6.0 * macs / 1e9, 1),
+                           kernels={short_name(k)[:40]: round(c[1] / 1e3 / n_micro, 3) for k, c in gemm[:6]})
     out["vendor_gemm_kernels"] = sum(1 for k, _ in gemm if k.startswith("Cijk_"))
     out["gpu_kernel_ms_per_micro_step"] = round(total_us / 1e3 / n_micro, 3)
     out["gpu_kernels_top"] = [dict(kernel=short_name(k)[:60], calls=c[0] // n_micro, avg_us=round(c[1] / c[0], 1),
@@ -130,8 +164,8 @@ def run(args, world, rank, local, extras=True):
                 b16 = _batch(16, x_len, y_len, dev, 99)
                 eng.micro_step(b16, 1)
                 r16 = attention_roofline(eng, b16, 16, x_len + y_len, args.dtype)
-                res["roofline"]["at_batch_16"] = {k: r16.get(k) for k in ("achieved", "frac", "avg_launch_us", "also",
-                                                                          "attention_ms_per_micro_step")}
+                res["roofline"]["at_batch_16"] = {k: r16.get(k) for k in ("achieved", "frac", "frac_credited", "avg_launch_us",
+                                                                          "also", "attention_ms_per_micro_step")}
         except Exception as e:
             res["roofline_error"] = repr(e)
         if world == 1 and rank == 0:
