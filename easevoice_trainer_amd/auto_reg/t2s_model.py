@@ -22,6 +22,7 @@ from torch.nn import functional as F
 from ..hip import lib as L
 from ..hip.enc import bump_rng, new_site, relu_dropout, res_drop_ln
 from ..hip.linear import LinearBank, linear as _hip_linear
+from .blocks import attn_block, ffn_block
 from .ops import AddLayerNormFn, CrossEntropyRowsFn, CrossEntropySumFn, PrefixLMAttentionFn
 from .utils import dpo_loss, make_reject_y
 
@@ -119,14 +120,13 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, x, x_lens, y_lens, x_len, seed):
         p = self.dropout.p if self.training else 0.0
+        if x.is_cuda:
+            # each sub-block is ONE autograd node (auto_reg/blocks.py): dropout1 / dropout2 ride in the residual +
+            # LayerNorm launch, the inner relu + dropout in linear1's store, its derivative and the residual gradient sums
+            # in the backward GEMMs' epilogues (masks from the device-counter hash stream of hip/enc.py, one id per site)
+            x = attn_block(x, self.self_attn, self.norm1, x_lens, y_lens, x_len, seed, p, self._sites[0])
+            return ffn_block(x, self.linear1, self.linear2, self.norm2, p, self._sites[1], self._sites[2])
         sa = self.self_attn(x, x_lens, y_lens, x_len, seed)
-        if p > 0.0 and x.is_cuda:
-            # training: dropout1 / dropout2 ride in the residual+LayerNorm launch, the inner dropout in the relu launch
-            # (masks from the device-counter hash stream of hip/enc.py, one stream id per site)
-            x = res_drop_ln(x, sa.contiguous(), self.norm1.weight, self.norm1.bias, None, p, self._sites[0], self.norm1.eps)
-            h = relu_dropout(linear(x, self.linear1.weight, self.linear1.bias), p, self._sites[1])
-            ff = linear(h, self.linear2.weight, self.linear2.bias)
-            return res_drop_ln(x, ff.contiguous(), self.norm2.weight, self.norm2.bias, None, p, self._sites[2], self.norm2.eps)
         sa = self.dropout1(sa)
         x = AddLayerNormFn.apply(x, sa, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = linear(x, self.linear1.weight, self.linear1.bias, relu=True)       # relu = the GEMM's epilogue

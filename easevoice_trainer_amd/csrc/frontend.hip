@@ -86,44 +86,44 @@ __global__ __launch_bounds__(256) void rvq_select_kernel(const float* h, const f
   }
 }
 
-// out[b][m][f] = log(max(sum_k basis[m][k] * spec[b][k][start_b + f], 1e-5)), f < nfr.  Block = 32 frames x 128 mels of one
-// item; the spectrogram tile [64 bins][32 frames] and the basis tile [128 mels][64 bins] go through LDS.
-constexpr int MB = 128, KB = 64, FB = 32;
+// out[b][m][f] = log(max(sum_k basis[m][k] * spec[b][k][start_b + f], 1e-5)), f < nfr.  Block = 32 frames x 8 mels of one
+// item (the training segment is 32 frames: B x 16 blocks fill the chip; one block per item took 340 us); the 8 basis rows
+// sit in LDS, the 8 thread groups of a block split the bins (k = kp, kp + 8, ...) and read the spectrogram straight from
+// global memory (32 consecutive frames per row: 128-byte runs), partial sums meet in LDS.
+constexpr int SM_M = 8, SM_F = 32, SM_KP = 8;
 __global__ __launch_bounds__(256) void spec_to_mel_kernel(const float* spec, const float* basis, const int64_t* starts,
                                                           float* out, int F, int Tn, int M, int nfr) {
-  __shared__ float sp[KB][FB + 1];
-  __shared__ float bs[MB][KB + 1];
-  const int tid = threadIdx.x, fx = tid & 31, mg = tid >> 5;          // 8 groups x 16 mels
-  const int b = blockIdx.y, f0 = blockIdx.x * FB, m0 = blockIdx.z * MB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* bs = reinterpret_cast<float*>(smem);             // [SM_M][F]
+  float* part = bs + SM_M * F;                             // [SM_KP][SM_M][SM_F]
+  const int tid = threadIdx.x, fx = tid & 31, kp = tid >> 5;
+  const int b = blockIdx.y, f0 = blockIdx.x * SM_F, m0 = blockIdx.z * SM_M;
   const long st = starts ? (long)starts[b] : 0;
-  const float* s = spec + (long)b * F * Tn;
-  float acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < F; k0 += KB) {
-    __syncthreads();
-    for (int i = tid; i < KB * FB; i += 256) {
-      const int kk = i / FB, ff = i - kk * FB;
-      const long t = st + f0 + ff;
-      sp[kk][ff] = (k0 + kk < F && f0 + ff < nfr && t >= 0 && t < Tn) ? s[(long)(k0 + kk) * Tn + t] : 0.f;
-    }
-    for (int i = tid; i < MB * KB; i += 256) {
-      const int mm = i / KB, kk = i - mm * KB;
-      bs[mm][kk] = (m0 + mm < M && k0 + kk < F) ? basis[(long)(m0 + mm) * F + k0 + kk] : 0.f;
-    }
-    __syncthreads();
-    for (int kk = 0; kk < KB; ++kk) {
-      const float v = sp[kk][fx];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += bs[mg * 16 + i][kk] * v;
-    }
+  for (int i = tid; i < SM_M * F; i += 256) {
+    const int mm = i / F, kk = i - mm * F;
+    bs[i] = m0 + mm < M ? basis[(long)(m0 + mm) * F + kk] : 0.f;
   }
-  if (f0 + fx < nfr) {
+  __syncthreads();
+  const long t = st + f0 + fx;
+  const bool ok = f0 + fx < nfr && t >= 0 && t < Tn;
+  const float* s = spec + (long)b * F * Tn + (ok ? t : 0);
+  float acc[SM_M];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = m0 + mg * 16 + i;
-      if (m < M) out[((long)b * M + m) * nfr + f0 + fx] = logf(fmaxf(acc[i], 1e-5f));
-    }
+  for (int i = 0; i < SM_M; ++i) acc[i] = 0.f;
+  for (int k = kp; k < F; k += SM_KP) {
+    const float v = ok ? s[(long)k * Tn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_M; ++i) acc[i] += bs[i * F + k] * v;
+  }
+#pragma unroll
+  for (int i = 0; i < SM_M; ++i) part[(kp * SM_M + i) * SM_F + fx] = acc[i];
+  __syncthreads();
+  {
+    const int mm = tid >> 5;                               // 8 mels x 32 frames = 256 outputs, one per thread
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < SM_KP; ++q) v += part[(q * SM_M + mm) * SM_F + fx];
+    if (f0 + fx < nfr && m0 + mm < M) out[((long)b * M + m0 + mm) * nfr + f0 + fx] = logf(fmaxf(v, 1e-5f));
   }
 }
 
@@ -163,8 +163,10 @@ int evt_spec_to_mel(const float* spec, const float* basis, const int64_t* starts
                     int32_t T, int32_t M, int32_t nfr, void* stream) {
   if (!spec || !basis || !out || B <= 0 || F <= 0 || T <= 0 || M <= 0 || nfr <= 0) return EVT_EINVAL;
   evt_set_last_tag("spec_to_mel");
-  const dim3 grid((nfr + FB - 1) / FB, B, (M + MB - 1) / MB);
-  hipLaunchKernelGGL(spec_to_mel_kernel, grid, dim3(256), 0, (hipStream_t)stream, spec, basis, starts, out, F, T, M, nfr);
+  const dim3 grid((nfr + SM_F - 1) / SM_F, B, (M + SM_M - 1) / SM_M);
+  const size_t lds = ((size_t)SM_M * F + SM_KP * SM_M * SM_F) * sizeof(float);
+  if (lds > 64 * 1024) return EVT_ENOTSUP;                 // 2048-point STFT: 41 KB
+  hipLaunchKernelGGL(spec_to_mel_kernel, grid, dim3(256), lds, (hipStream_t)stream, spec, basis, starts, out, F, T, M, nfr);
   return evt_check_launch();
 }
 

@@ -1,0 +1,299 @@
+// gemm256: 256 x 256 x 64 bf16 GEMM for the dense layers of the s1 transformer (gfx950), forward and backward-data.
+//
+// Reference call sites: F.linear of the packed in-projection / out-projection (patched_mha_with_cache.py:242,460) and
+// linear1 / linear2 (transformer.py:207-224,330-334) at M = B x L = 32768 rows, K, N in {512, 1536, 2048}: 16 of the 26 ms
+// of GEMM time per micro-step.  The 128 x 128 kernels of conv_deep.hip move (128 + 128) x K operand bytes through LDS-DMA
+// per 128 x 128 outputs; at K = 512 a block lives for 8-16 stages, so fill / drain and operand traffic, not MFMA rate,
+// set their 560-600 TFLOP/s.  This kernel halves the traffic per flop and keeps three operand pieces in flight:
+//
+//   out[M][NO] = epilogue( B[M][K] . A[NO][K]^T )      A = weight rows (REG image: forward; ALT image = W^T: backward-data)
+//
+// Block = 256 (NO) x 256 (M) outputs, 8 waves as 2 x 4, a wave owns 128 x 64 = 8 x 4 MFMA tiles (mfma_f32_16x16x32_bf16,
+// A operand = weight rows, B operand = token rows: a lane ends up with 4 consecutive output channels of one token).
+// One K tile (64 wide) is FOUR 16 KiB pieces -- a0 / a1: the weight rows the first / second half of every wave's M-tiles
+// read, b0 / b1 likewise for the token rows -- so that each of the four phases of a K tile (one 64 x 32 quadrant of the
+// wave's accumulators = 16 MFMAs) reads ONE new piece (phase 0: a0 + b0, 1: b1, 2: a1, 3: b0 again) and every LDS region
+// is dead a known number of phases after it was filled.  Pieces are written by LDS-DMA (global_load_lds_dwordx4, the
+// bank swizzle on the per-lane source address, undone on the ds_read_b128), one piece per phase, FIVE pieces ahead of
+// the phase that issues it: the piece overwritten was last read two phases ago, the piece needed next was issued four
+// phases ago.  Waits are counted (s_waitcnt vmcnt(6): three pieces stay in flight), one raw s_barrier per phase.
+// Two K-tile buffers = 128 KiB LDS, one block per CU.
+//
+// Epilogue (all optional): + bias, relu, dropout (the counter hash of enc_ops.hip on the flat output index), gate
+// (x gate_pos where gate > 0, else 0: the relu + dropout derivative read off the saved activation), + add (the residual
+// branch's gradient) -- what the s1 block otherwise runs as separate element-wise launches.
+#include "evt_common.h"
+#include "../../include/evt.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g256_zero_page[64];  // 256 zero bytes
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct G256 {
+  const bf16_t* a;      // [NO][K] weight-side rows
+  const bf16_t* b;      // [M][K] token-side rows
+  bf16_t* out;          // [M][NO]
+  const float* bias;    // [NO] or null
+  const bf16_t* gate;   // [M][NO] or null
+  const bf16_t* add;    // [M][NO] or null
+  const unsigned* seed_dev;
+  int M, NO, K;
+  int relu;
+  unsigned thr, site;   // dropout: keep iff hash >= thr (0 = off)
+  float keep, gate_pos;
+  int P, Y;             // token tiles, channel tiles
+};
+
+constexpr int PIECE = 128 * 128;       // bytes: 128 rows of 64 bf16
+constexpr int KTB = 4 * PIECE;         // one K tile: regions a0 | b0 | b1 | a1
+constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {   // lowbias32 finaliser (enc_ops.hip)
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+// one quadrant of the wave's accumulators: M-tiles 4*QA .. 4*QA+3, N-tiles 2*QB, 2*QB+1, both k sub-steps
+template <int QA, int QB>
+__device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&bfr)[2][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[QA * 4 + i][QB * 2 + j] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[QA * 4 + i][QB * 2 + j], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // XCD-aware decode (as conv_deep): all channel tiles of a token tile on one XCD, so the token rows are fetched once per L2
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int yi = slot % p.Y;
+  const int pb = xcd + 8 * (slot / p.Y);
+  if (pb >= p.P) return;
+
+  // ---- per-lane DMA sources.  A wave fills local rows [16 w, 16 w + 16) of every piece, 8 rows per instruction.
+  //      piece-local row lr -> tile row:  a-piece h: (lr >> 6) * 128 + h * 64 + (lr & 63)   (wave row-half, M-tile half)
+  //                                       b-piece h: (lr >> 5) * 64 + h * 32 + (lr & 31)    (wave column, N-tile half)
+  const int rsub = lane >> 3, pslot = lane & 7;
+  unsigned offs[4][2];          // element offsets of this lane's 16 bytes at K tile 0, per region and instruction
+  bool bok[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 16 + i * 8 + rsub;
+    const int c = pslot ^ (lr & 7);                       // logical 16-byte k-slot this lane fetches
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ar = yi * 256 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      offs[h ? R_A1 : R_A0][i] = (unsigned)ar * (unsigned)p.K + c * 8;
+      const int br = pb * 256 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+      bok[h][i] = br < p.M;
+      offs[h ? R_B1 : R_B0][i] = (unsigned)(bok[h][i] ? br : 0) * (unsigned)p.K + c * 8;
+    }
+  }
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g256_zero_page) + pslot * 8;
+  unsigned char* my = smem + wave * 2048;                  // + buf * KTB + region * PIECE + i * 1024
+  const int nt = p.K >> 6;
+
+  // piece (kt, region): two DMA instructions per wave
+  auto issue_a = [&](int kt, int region) {
+    unsigned char* dst = my + (kt & 1) * KTB + region * PIECE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(p.a + offs[region][i] + kt * 64, dst + i * 1024);
+  };
+  auto issue_b = [&](int kt, int region) {
+    unsigned char* dst = my + (kt & 1) * KTB + region * PIECE;
+    const int h = region == R_B1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(bok[h][i] ? p.b + offs[region][i] + kt * 64 : zsrc, dst + i * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a piece: local row = wave part + tile * 16 + n, logical slot = ks * 4 + g
+  const int sw = n & 7;
+  const int so0 = ((0 + g) ^ sw) * 16, so1 = ((4 + g) ^ sw) * 16;
+  const int a_row = (wr * 64 + n) * 128;                   // + (i & 3) * 16 * 128
+  const int b_row = (wc * 32 + n) * 128;                   // + (j & 1) * 16 * 128
+
+  bf16x8 af[4][2], bfr[2][2];
+  auto load_a = [&](const unsigned char* piece) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *reinterpret_cast<const bf16x8*>(piece + a_row + i * 2048 + so0);
+      af[i][1] = *reinterpret_cast<const bf16x8*>(piece + a_row + i * 2048 + so1);
+    }
+  };
+  auto load_b = [&](const unsigned char* piece) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bfr[j][0] = *reinterpret_cast<const bf16x8*>(piece + b_row + j * 2048 + so0);
+      bfr[j][1] = *reinterpret_cast<const bf16x8*>(piece + b_row + j * 2048 + so1);
+    }
+  };
+
+  // ---- prologue: pieces 0..4 = a0, b0, b1, a1 of K tile 0 and a0 of K tile 1 ----
+  issue_a(0, R_A0);
+  issue_b(0, R_B0);
+  issue_b(0, R_B1);
+  issue_a(0, R_A1);
+  issue_a(1, R_A0);
+
+  // phase g = 4 kt + ph: wait until pieces <= g + 1 have landed (WAIT instructions may remain in flight), meet, read this
+  // phase's piece(s), issue piece g + 5 (guarded by EXISTS), 16 MFMAs
+#define PHASE(WAIT, READS, ISSUE, QA, QB)              \
+  {                                                     \
+    wait_vmcnt<WAIT>();                                 \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+    READS;                                              \
+    ISSUE;                                              \
+    __builtin_amdgcn_s_setprio(1);                      \
+    mma_quadrant<QA, QB>(acc, af, bfr);                 \
+    __builtin_amdgcn_s_setprio(0);                      \
+    asm volatile("" ::: "memory");                      \
+  }
+
+  int kt = 0;
+  for (; kt < nt - 1; ++kt) {
+    const unsigned char* buf = smem + (kt & 1) * KTB;
+    const bool more = kt + 2 < nt;                          // K tile kt + 2 exists
+    PHASE(6, { load_b(buf + R_B0 * PIECE); load_a(buf + R_A0 * PIECE); }, issue_b(kt + 1, R_B0), 0, 0)
+    PHASE(6, load_b(buf + R_B1 * PIECE), issue_b(kt + 1, R_B1), 0, 1)
+    PHASE(6, load_a(buf + R_A1 * PIECE), issue_a(kt + 1, R_A1), 1, 1)
+    if (more) {
+      PHASE(6, load_b(buf + R_B0 * PIECE), issue_a(kt + 2, R_A0), 1, 0)
+    } else {
+      PHASE(6, load_b(buf + R_B0 * PIECE), {}, 1, 0)
+    }
+  }
+  {   // last K tile: nothing left to issue, the queue drains
+    const unsigned char* buf = smem + (kt & 1) * KTB;
+    PHASE(4, { load_b(buf + R_B0 * PIECE); load_a(buf + R_A0 * PIECE); }, {}, 0, 0)
+    PHASE(2, load_b(buf + R_B1 * PIECE), {}, 0, 1)
+    PHASE(0, load_a(buf + R_A1 * PIECE), {}, 1, 1)
+    PHASE(0, load_b(buf + R_B0 * PIECE), {}, 1, 0)
+  }
+#undef PHASE
+
+  // ---- epilogue: lane holds channels g*4..g*4+3 (rows) of token n (column) of each 16 x 16 tile ----
+  unsigned key = 0;
+  if (p.thr) key = mix32((p.seed_dev ? *p.seed_dev : 0u) * 0x9E3779B1u + p.site * 0x85EBCA77u + 0x165667B1u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = pb * 256 + wc * 64 + j * 16 + n;
+    if (row >= p.M) continue;
+    const long rbase = (long)row * p.NO;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int co = yi * 256 + wr * 128 + i * 16 + g * 4;
+      const long off = rbase + co;
+      uint2 gv = make_uint2(0, 0), av = make_uint2(0, 0);
+      if (p.gate) gv = *reinterpret_cast<const uint2*>(p.gate + off);
+      if (p.add) av = *reinterpret_cast<const uint2*>(p.add + off);
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
+      const bf16_t* ap = reinterpret_cast<const bf16_t*>(&av);
+      bf16_t outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[co + r];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.thr) {
+          const unsigned long idx = (unsigned long)(off + r);
+          const unsigned hsh = mix32((unsigned)idx ^ key ^ (unsigned)(idx >> 32) * 0xC2B2AE35u);
+          v = hsh >= p.thr ? v * p.keep : 0.f;
+        }
+        if (p.gate) v = bf2f(gp[r]) > 0.f ? v * p.gate_pos : 0.f;
+        if (p.add) v += bf2f(ap[r]);
+        outv[r] = f2bf(v);
+      }
+      *reinterpret_cast<uint2*>(p.out + off) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+}
+
+bool eligible(const evt_gemm_params* g, int kred, int nout) {
+  if (g->dtype != EVT_DT_BF16) return false;
+  if (nout % 256 || kred % 64 || kred < 128) return false;
+  if ((long)g->M * kred >= (1L << 31) || (long)nout * kred >= (1L << 31)) return false;
+  if (g->M < 2048) return false;                             // few token tiles: the 128 / 64 tiles fill the chip better
+  static const bool off = getenv("EVT_NO_GEMM256") != nullptr;   // A/B switch for measurements
+  return !off;
+}
+
+int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int nout, const float* bias, int relu,
+           const evt_gemm_epilogue* e, void* out, hipStream_t st) {
+  G256 p{};
+  p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.out = (bf16_t*)out; p.bias = bias;
+  p.M = g->M; p.NO = nout; p.K = kred; p.relu = relu;
+  p.keep = 1.f; p.gate_pos = 1.f;
+  if (e) {
+    if (e->dropout_p < 0.f || e->dropout_p >= 1.f) return EVT_EINVAL;
+    p.gate = (const bf16_t*)e->gate; p.add = (const bf16_t*)e->add; p.gate_pos = e->gate_pos;
+    p.seed_dev = e->seed_dev; p.site = e->site;
+    if (e->dropout_p > 0.f) {
+      p.thr = (unsigned)fminf(e->dropout_p * 4294967296.f, 4294967040.f);
+      p.keep = 1.f / (1.f - e->dropout_p);
+    }
+  }
+  p.Y = nout / 256;
+  p.P = (g->M + 255) / 256;
+  static bool attr = false;
+  const size_t lds = 2 * KTB;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  evt_set_last_tag("gemm256_nt<bf16, 256, 256, 64>");
+  hipLaunchKernelGGL(gemm256_nt, dim3(8 * ((p.P + 7) / 8) * p.Y), dim3(512), lds, st, p);
+  return evt_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t evt_gemm_bf16_fused_supported(const evt_gemm_params* g, int32_t backward_data) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return 0;
+  return backward_data ? eligible(g, g->N, g->K) : eligible(g, g->K, g->N);
+}
+
+int evt_gemm_bf16_fwd_ex(const evt_gemm_params* g, const void* x, const void* w_reg, const void* w_alt, const float* bias,
+                         const evt_gemm_epilogue* epi, void* y, void* stream) {
+  if (!g || !x || !w_reg || !y) return EVT_EINVAL;
+  if (!eligible(g, g->K, g->N)) return EVT_ENOTSUP;
+  (void)w_alt;
+  return launch(g, w_reg, x, g->K, g->N, bias, g->relu, epi, y, (hipStream_t)stream);
+}
+
+int evt_gemm_bf16_bwd_data_ex(const evt_gemm_params* g, const void* dy, const void* w_reg, const void* w_alt,
+                              const evt_gemm_epilogue* epi, void* dx, void* stream) {
+  if (!g || !dy || !w_alt || !dx) return EVT_EINVAL;
+  if (!eligible(g, g->N, g->K)) return EVT_ENOTSUP;
+  (void)w_reg;
+  return launch(g, w_alt, dy, g->N, g->K, nullptr, 0, epi, dx, (hipStream_t)stream);
+}
+
+}  // extern "C"

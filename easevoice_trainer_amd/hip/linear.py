@@ -21,6 +21,12 @@ class GemmParams(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("relu", C.c_int32)]
 
 
+class GemmEpilogue(C.Structure):
+    """evt_gemm_epilogue (include/evt.h)"""
+    _fields_ = [("dropout_p", C.c_float), ("site", C.c_uint32), ("seed_dev", C.c_void_p), ("gate", C.c_void_p),
+                ("gate_pos", C.c_float), ("pad_", C.c_uint32), ("add", C.c_void_p)]
+
+
 class LinearSlot:
     __slots__ = ("name", "weight", "bias", "N", "Np", "K", "layout", "reg", "alt", "bank", "_pcache")
 
@@ -37,6 +43,15 @@ class LinearSlot:
         if p is None:
             p = self._pcache[(M, relu)] = GemmParams(self.bank.dt, M, self.Np, self.K, 1 if relu else 0)
         return p
+
+    def fused(self, M, backward_data):
+        """does the 256 x 256 kernel with fused epilogues (csrc/gemm256.hip) cover this layer at M rows?"""
+        key = ("fused", M, backward_data)
+        f = self._pcache.get(key)
+        if f is None:
+            f = self._pcache[key] = bool(L.lib().evt_gemm_bf16_fused_supported(C.byref(self.params(M, False)),
+                                                                               1 if backward_data else 0))
+        return f
 
 
 class LinearBank:
@@ -103,61 +118,127 @@ class LinearBank:
             self._stamp, self.dirty = stamp, False
 
 
+def _rng(device):
+    from .enc import rng_counter
+    return rng_counter(device)
+
+
+def gemm_fwd(slot, x, relu=False, drop=None, add=None):
+    """y = [dropout](act(x W^T + b)) [+ add] over the last dimension.  drop = (p, site): the inner dropout of the FFN
+    (transformer.py:330-334).  On the 256 x 256 kernel the whole epilogue rides in the GEMM's store; other shapes run the
+    plain GEMM and the element-wise launches."""
+    if x.dtype != slot.bank.dtype or not x.is_contiguous() or x.size(-1) != slot.K:
+        raise L.EvtError(f"linear {slot.name}: contiguous [..., {slot.K}] {slot.bank.dtype} expected, got "
+                         f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
+    M = x.numel() // slot.K
+    y = torch.empty(x.shape[:-1] + (slot.Np,), dtype=x.dtype, device=x.device)
+    bias = slot.bias.data if slot.bias is not None else None
+    lib = L.lib()
+    p_drop, site = drop if drop is not None else (0.0, 0)
+    if slot.fused(M, False):
+        epi = None
+        if p_drop > 0.0 or add is not None:
+            epi = GemmEpilogue(float(p_drop), int(site), _rng(x.device).data_ptr(), None, 1.0, 0,
+                               add.data_ptr() if add is not None else None)
+        L.check(lib.evt_gemm_bf16_fwd_ex(C.byref(slot.params(M, relu)), L.ptr(x), L.ptr(slot.reg), L.ptr(slot.alt),
+                                         L.ptr(bias), C.byref(epi) if epi is not None else None, L.ptr(y),
+                                         L.stream_ptr()), "evt_gemm_bf16_fwd_ex")
+        return y
+    L.check(lib.evt_gemm_bf16_fwd(C.byref(slot.params(M, relu and p_drop == 0.0)), L.ptr(x), L.ptr(slot.reg),
+                                  L.ptr(slot.alt), L.ptr(bias), L.ptr(y), L.stream_ptr()), "evt_gemm_bf16_fwd")
+    if p_drop > 0.0:
+        if not relu:
+            raise L.EvtError("dropout epilogue without relu is not used by the s1 blocks")
+        z = y
+        y = torch.empty_like(z)
+        L.check(lib.evt_relu_dropout_fwd(L.dt_of(z), L.ptr(z), C.c_float(p_drop), L.ptr(_rng(x.device)), C.c_uint32(site),
+                                         None, 0, 0, L.ptr(y), C.c_int64(z.numel()), L.stream_ptr()),
+                "evt_relu_dropout_fwd")
+    if add is not None:
+        y.add_(add)
+    return y
+
+
+def gemm_bwd_data(slot, dy, gate=None, gate_pos=1.0, add=None):
+    """dx = (dy W) [* (gate > 0 ? gate_pos : 0)] [+ add];  dy [..., Np] contiguous -> dx [..., K]"""
+    M = dy.numel() // slot.Np
+    dx = torch.empty(dy.shape[:-1] + (slot.K,), dtype=dy.dtype, device=dy.device)
+    lib = L.lib()
+    p = slot.params(M, False)
+    if slot.fused(M, True):
+        epi = None
+        if gate is not None or add is not None:
+            epi = GemmEpilogue(0.0, 0, None, gate.data_ptr() if gate is not None else None, float(gate_pos), 0,
+                               add.data_ptr() if add is not None else None)
+        L.check(lib.evt_gemm_bf16_bwd_data_ex(C.byref(p), L.ptr(dy), L.ptr(slot.reg), L.ptr(slot.alt),
+                                              C.byref(epi) if epi is not None else None, L.ptr(dx), L.stream_ptr()),
+                "evt_gemm_bf16_bwd_data_ex")
+        return dx
+    L.check(lib.evt_gemm_bf16_bwd_data(C.byref(p), L.ptr(dy), L.ptr(slot.reg), L.ptr(slot.alt), L.ptr(dx),
+                                       L.stream_ptr()), "evt_gemm_bf16_bwd_data")
+    if gate is not None:     # the same derivative as its own launch (odd shapes, the fp32 parity path)
+        g = torch.empty_like(dx)
+        L.check(lib.evt_dact_mul(L.dt_of(dx), L.ptr(dx), L.ptr(gate), L.ACT_LRELU, C.c_float(0.0), L.ptr(g),
+                                 C.c_int64(dx.numel()), L.stream_ptr()), "evt_dact_mul")
+        dx = g if gate_pos == 1.0 else g.mul_(gate_pos)
+    if add is not None:
+        dx.add_(add)
+    return dx
+
+
+def gemm_bwd_weight(slot, x, dy, want_bias=True):
+    """dW += dy^T x (and db += column sums of dy) straight into the parameters' fp32 arena views when the engine
+    attached them (`_evt_grad_view`): returns (None, None) then; otherwise (dw [N, K], db [N] or None) fp32 tensors."""
+    M = x.numel() // slot.K
+    p = slot.params(M, False)
+    wv = getattr(slot.weight, "_evt_grad_view", None)
+    want_b = slot.bias is not None and want_bias
+    bv = getattr(slot.bias, "_evt_grad_view", None) if want_b else None
+    sunk = (wv is not None and slot.Np == slot.N and wv.dtype == torch.float32 and wv.is_contiguous()
+            and tuple(wv.shape) == (slot.N, slot.K) and (not want_b or (bv is not None and bv.numel() == slot.N)))
+    if sunk:
+        dw_buf, db_buf = wv, bv
+    else:
+        dw_buf = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
+        db_buf = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device) if want_b else None
+    L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
+                                             L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
+    if sunk:
+        return None, None
+    dw, db = dw_buf, db_buf
+    if slot.Np != slot.N:
+        dw = dw[:slot.N]
+        db = db[:slot.N] if db is not None else None
+    return dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) on the last dimension; x [..., K] contiguous in the bank's dtype -> y [..., Np]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, anchor, slot, relu):
-        if x.dtype != slot.bank.dtype or not x.is_contiguous() or x.size(-1) != slot.K:
-            raise L.EvtError(f"linear {slot.name}: contiguous [..., {slot.K}] {slot.bank.dtype} expected, got "
-                             f"{tuple(x.shape)} {x.dtype} contiguous={x.is_contiguous()}")
-        M = x.numel() // slot.K
-        y = torch.empty(x.shape[:-1] + (slot.Np,), dtype=x.dtype, device=x.device)
-        L.check(L.lib().evt_gemm_bf16_fwd(C.byref(slot.params(M, relu)), L.ptr(x), L.ptr(slot.reg), L.ptr(slot.alt),
-                                          L.ptr(bias.data if bias is not None else None), L.ptr(y), L.stream_ptr()),
-                "evt_gemm_bf16_fwd")
-        ctx.slot, ctx.relu, ctx.M = slot, relu, M
+        y = gemm_fwd(slot, x, relu=relu)
+        ctx.slot, ctx.relu = slot, relu
         ctx.save_for_backward(x, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        slot, M = ctx.slot, ctx.M
+        slot = ctx.slot
         dy = dy.contiguous()
         if ctx.relu:
             dy_eff = torch.empty_like(dy)
             L.check(L.lib().evt_dact_mul(L.dt_of(dy), L.ptr(dy), L.ptr(y), L.ACT_LRELU, C.c_float(0.0), L.ptr(dy_eff),
                                          C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
             dy = dy_eff
-        p = slot.params(M, False)
         dw = db = None
         if ctx.needs_input_grad[1]:
             # inside an engine the parameters carry the fp32 view of their slot in the flat gradient arena
             # (`_evt_grad_view`): the launch accumulates (+=) straight into it -- across the accumulation micro-batches too --
             # and autograd gets no tensor: no zero-filled [N, K] scratch per layer and micro-step, nothing to add afterwards
-            wv = getattr(slot.weight, "_evt_grad_view", None)
-            want_b = slot.bias is not None and ctx.needs_input_grad[2]
-            bv = getattr(slot.bias, "_evt_grad_view", None) if want_b else None
-            sunk = (wv is not None and slot.Np == slot.N and wv.dtype == torch.float32 and wv.is_contiguous()
-                    and tuple(wv.shape) == (slot.N, slot.K) and (not want_b or (bv is not None and bv.numel() == slot.N)))
-            if sunk:
-                dw_buf, db_buf = wv, bv
-            else:
-                dw_buf = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
-                db_buf = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device) if want_b else None
-            L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
-                                                     L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
-            if not sunk:
-                dw, db = dw_buf, db_buf
-                if slot.Np != slot.N:
-                    dw = dw[:slot.N]
-                    db = db[:slot.N] if db is not None else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            L.check(L.lib().evt_gemm_bf16_bwd_data(C.byref(p), L.ptr(dy), L.ptr(slot.reg), L.ptr(slot.alt), L.ptr(dx),
-                                                   L.stream_ptr()), "evt_gemm_bf16_bwd_data")
+            dw, db = gemm_bwd_weight(slot, x, dy, want_bias=ctx.needs_input_grad[2])
+        dx = gemm_bwd_data(slot, dy) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None, None, None
 
 

@@ -293,6 +293,31 @@ int evt_gemm_bf16_bwd_data(const evt_gemm_params* g, const void* dy, const void*
 int evt_gemm_bf16_bwd_weight(const evt_gemm_params* g, const void* x, const void* dy, float* dw, float* dbias,
                              void* stream);
 
+/* The same GEMMs with fused epilogues, on the 256 x 256 x 64 kernel of csrc/gemm256.hip (bf16, N and K multiples of 256 /
+ * 64 on the output / reduction side, M >= 2048: the shapes of the s1 blocks at training batch sizes).  What the s1 block
+ * (transformer.py:311-334) otherwise runs as separate element-wise launches rides in the GEMM's store:
+ *   forward       y  = dropout(act(x . W^T + bias)) [+ add]     mask = counter hash of (*seed_dev, site, row * N + col),
+ *                                                                the one evt_relu_dropout_fwd draws
+ *   backward-data dx = (dy . W) * (gate > 0 ? gate_pos : 0) [+ add]
+ *                 gate = the saved dropout(relu(.)) output of the layer below (its sign pattern IS the relu + dropout
+ *                 derivative, gate_pos = 1 / (1 - p)); add = the residual branch's gradient.
+ * evt_gemm_bf16_fused_supported says whether a shape is covered (callers fall back to the plain entry points plus the
+ * element-wise launches); the _ex entry points return EVT_ENOTSUP otherwise.  epi may be NULL (plain GEMM). */
+typedef struct evt_gemm_epilogue {
+  float dropout_p;          /* 0 = off */
+  uint32_t site;
+  const uint32_t* seed_dev; /* device counter of the dropout stream (may be NULL = 0) */
+  const void* gate;         /* [M][out columns] in the GEMM's dtype, or NULL */
+  float gate_pos;
+  uint32_t pad_;
+  const void* add;          /* [M][out columns] in the GEMM's dtype, or NULL; added last */
+} evt_gemm_epilogue;
+int32_t evt_gemm_bf16_fused_supported(const evt_gemm_params* g, int32_t backward_data);
+int evt_gemm_bf16_fwd_ex(const evt_gemm_params* g, const void* x, const void* w_reg, const void* w_alt, const float* bias,
+                         const evt_gemm_epilogue* epi, void* y, void* stream);
+int evt_gemm_bf16_bwd_data_ex(const evt_gemm_params* g, const void* dy, const void* w_reg, const void* w_alt,
+                              const evt_gemm_epilogue* epi, void* dx, void* stream);
+
 /* Flash attention with the ANALYTIC prefix-LM + key-padding mask of
  * src/easevoice/soundstorm/auto_reg/models/t2s_model.py:456-479 (no [B*H,L,L] mask tensor):
  *   key j visible from query i  <=>  j is not padding  AND  ( j < x_len  if i < x_len  else  j <= i )

@@ -83,3 +83,107 @@ def test_bank_refolds_after_weight_change(gpu):
     bank.mark_dirty()                   # ... is announced, as S1Engine does after the optimiser launch
     bank.prepare()
     assert rel(linear(x, w), 2 * y0) < 1e-2
+
+
+def _bank(N, K, gpu, g, bias=True):
+    from easevoice_trainer_amd.hip.linear import LinearBank
+
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().float().to(gpu))
+    b = torch.nn.Parameter((torch.randn(N, generator=g) * 0.1).to(gpu)) if bias else None
+    bank = LinearBank([("t", w, b)], torch.bfloat16, gpu)
+    bank.prepare()
+    return w, b, w._evt_slot
+
+
+@pytest.mark.parametrize("shape", [(4096, 2048, 512), (2304, 512, 2048), (3000, 1536, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_gemm256_fused_epilogues(gpu, shape):
+    """the 256 x 256 kernel's epilogues (csrc/gemm256.hip): relu + dropout in the forward store, gate + add in the
+    backward-data store, against fp32 arithmetic on the CPU; the dropout mask is the one evt_relu_dropout_fwd draws for
+    the same (seed, site)"""
+    import ctypes as C
+    from easevoice_trainer_amd.hip import enc as E, lib as L
+    from easevoice_trainer_amd.hip.linear import gemm_bwd_data, gemm_fwd
+
+    M, N, K = shape
+    g = torch.Generator().manual_seed(N + K)
+    w, b, slot = _bank(N, K, gpu, g)
+    assert slot.fused(M, False) and slot.fused(M, True)
+    x = torch.randn(M, K, generator=g).bfloat16().to(gpu)
+    E.seed_rng(gpu, 123)
+    p, site = 0.25, 9
+    z = (x.float().cpu() @ w.detach().cpu().t() + b.detach().cpu())                       # fp32 reference
+    y0 = gemm_fwd(slot, x, relu=True)                                                       # relu only
+    assert rel(y0, torch.relu(z)) < 2e-2
+    y = gemm_fwd(slot, x, relu=True, drop=(p, site))
+    # the standalone kernel on the same positions draws the same mask
+    zz = torch.relu(z).bfloat16().to(gpu)
+    yk = torch.empty_like(zz)
+    L.check(L.lib().evt_relu_dropout_fwd(L.DT_BF16, L.ptr(zz), C.c_float(p), L.ptr(E.rng_counter(gpu)), C.c_uint32(site), None,
+                                         0, 0, L.ptr(yk), C.c_int64(zz.numel()), L.stream_ptr()), "evt_relu_dropout_fwd")
+    live = zz.float() > 1e-2
+    assert torch.equal((y.float() > 0) & live, (yk.float() > 0) & live)
+    assert rel(y, yk) < 2e-2
+    kept = ((y.float() > 0) & live).float().sum() / live.float().sum()
+    assert abs(kept.item() - (1 - p)) < 0.01
+    # forward add-epilogue
+    addt = torch.randn(M, N, generator=g).bfloat16().to(gpu)
+    ya = gemm_fwd(slot, x, relu=False, add=addt)
+    assert rel(ya, z + addt.float().cpu()) < 2e-2
+    # backward-data: gate (derivative of relu + dropout read off the saved activation) and add (residual gradient)
+    dy = torch.randn(M, N, generator=g).bfloat16().to(gpu)
+    gate = (torch.randn(M, K, generator=g) * (torch.rand(M, K, generator=g) > 0.4)).clamp(min=0).bfloat16().to(gpu)
+    addk = torch.randn(M, K, generator=g).bfloat16().to(gpu)
+    ref = dy.float().cpu() @ w.detach().cpu()
+    assert rel(gemm_bwd_data(slot, dy), ref) < 2e-2
+    got = gemm_bwd_data(slot, dy, gate=gate, gate_pos=1.0 / (1 - p), add=addk)
+    want = ref * (gate.float().cpu() > 0).float() / (1 - p) + addk.float().cpu()
+    assert rel(got, want) < 2e-2
+
+
+@pytest.mark.parametrize("dtype,B", [(torch.bfloat16, 3), (torch.float32, 1)], ids=["bf16-gemm256", "f32-fallback"])
+def test_s1_blocks_match_composition(gpu, dtype, B):
+    """auto_reg/blocks.py (attention block / FFN block as one autograd node each, fused epilogues) against the same
+    arithmetic composed from torch ops in fp32 on the CPU (transformer.py:311-334 with dropout off), with every
+    parameter gradient; bf16 at 3072 rows runs the 256 x 256 kernel, fp32 the fallback composition"""
+    from easevoice_trainer_amd.auto_reg.blocks import attn_block, ffn_block
+    from easevoice_trainer_amd.auto_reg.t2s_model import TransformerEncoderLayer
+    from easevoice_trainer_amd.hip.linear import LinearBank
+    from oracle import s1_step as OS
+
+    Lq, E, x_len = 1024, 512, 256
+    torch.manual_seed(5)
+    layer = TransformerEncoderLayer(E, 16, 2048, 0.0).to(gpu)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            p_.copy_((p_ + 0.02 * torch.randn_like(p_)).to(dtype).float())
+    specs = [("in", layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias),
+             ("out", layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias),
+             ("l1", layer.linear1.weight, layer.linear1.bias), ("l2", layer.linear2.weight, layer.linear2.bias)]
+    LinearBank(specs, dtype, gpu).prepare()
+    layer.eval()
+    x = torch.randn(B, Lq, E, device=gpu).to(dtype)
+    x_lens = torch.full((B,), x_len, dtype=torch.int32, device=gpu)
+    y_lens = torch.tensor([Lq - x_len, 500, 17][:B], dtype=torch.int32, device=gpu)
+    wgt = torch.randn(B, Lq, E, device=gpu)
+    xg = x.clone().requires_grad_(True)
+    h = attn_block(xg, layer.self_attn, layer.norm1, x_lens, y_lens, x_len, 1, 0.0, 1)
+    out = ffn_block(h, layer.linear1, layer.linear2, layer.norm2, 0.0, 2, 3)
+    (out.float() * wgt).sum().backward()
+    torch.cuda.synchronize()
+
+    F_ = torch.nn.functional
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    xr = x.float().cpu().requires_grad_(True)
+    qkv = F_.linear(xr, P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"])
+    mask = OS.prefix_lm_mask(x_lens.cpu().long(), y_lens.cpu().long(), x_len, Lq - x_len)
+    sa = F_.linear(OS.attention(qkv, mask, 16), P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"])
+    h1 = F_.layer_norm(xr + sa, (E,), P["norm1.weight"], P["norm1.bias"], layer.norm1.eps)
+    ff = F_.linear(torch.relu(F_.linear(h1, P["linear1.weight"], P["linear1.bias"])), P["linear2.weight"], P["linear2.bias"])
+    ref = F_.layer_norm(h1 + ff, (E,), P["norm2.weight"], P["norm2.bias"], layer.norm2.eps)
+    (ref * wgt.cpu()).sum().backward()
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-3
+    assert rel(out, ref) < tol
+    # padded query rows of the reference still attend; their keys are masked for everybody: compare all rows
+    assert rel(xg.grad, xr.grad) < tol
+    for k, p_ in layer.named_parameters():
+        assert rel(p_.grad, P[k].grad) < tol, k
