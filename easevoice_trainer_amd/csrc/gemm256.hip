@@ -54,6 +54,8 @@ struct G256 {
 constexpr int PIECE = 128 * 128;       // bytes: 128 rows of 64 bf16
 constexpr int KTB = 4 * PIECE;         // one K tile: regions a0 | b0 | b1 | a1
 constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
+constexpr int EP_PITCH = 272;            // epilogue staging: a wave's 64 token rows x 128 channels (256 B) + 16 B pad
+constexpr int EP_WAVE = 64 * EP_PITCH;   // 17 KiB per wave, 136 KiB per block
 
 __device__ __forceinline__ unsigned mix32(unsigned x) {   // lowbias32 finaliser (enc_ops.hip)
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -73,6 +75,17 @@ __device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[8][4], const bf16x8 (&
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[QA * 4 + i][QB * 2 + j], 0, 0, 0);
 }
 
+// ablation variants: the fragment registers stay live (and their ds_reads issued) without the matrix pipe
+__device__ __forceinline__ void keep_frags(const bf16x8 (&af)[4][2], const bf16x8 (&bfr)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(af[i][0])); asm volatile("" ::"v"(af[i][1])); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(bfr[j][0])); asm volatile("" ::"v"(bfr[j][1])); }
+}
+
+// VAR: measurement variants (tools/bench_gemm256.py; the product launches VAR = 0): bit 0 no MFMAs, bit 1 no DMA after the
+// prologue, bit 2 no fragment reads, bit 3 no epilogue stores
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -113,12 +126,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   // piece (kt, region): two DMA instructions per wave
   auto issue_a = [&](int kt, int region) {
     unsigned char* dst = my + (kt & 1) * KTB + region * PIECE;
+    if ((VAR & 2) && kt > 1) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(p.a + offs[region][i] + kt * 64, dst + i * 1024);
   };
   auto issue_b = [&](int kt, int region) {
     unsigned char* dst = my + (kt & 1) * KTB + region * PIECE;
     const int h = region == R_B1;
+    if ((VAR & 2) && kt > 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(bok[h][i] ? p.b + offs[region][i] + kt * 64 : zsrc, dst + i * 1024);
   };
@@ -136,7 +151,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   const int b_row = (wc * 32 + n) * 128;                   // + (j & 1) * 16 * 128
 
   bf16x8 af[4][2], bfr[2][2];
+  if (VAR & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i][0] = af[i][1] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { bfr[j][0] = bfr[j][1] = bf16x8{}; }
+  }
   auto load_a = [&](const unsigned char* piece) {
+    if (VAR & 4) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i][0] = *reinterpret_cast<const bf16x8*>(piece + a_row + i * 2048 + so0);
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
     }
   };
   auto load_b = [&](const unsigned char* piece) {
+    if (VAR & 4) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       bfr[j][0] = *reinterpret_cast<const bf16x8*>(piece + b_row + j * 2048 + so0);
@@ -168,7 +191,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
     READS;                                              \
     ISSUE;                                              \
     __builtin_amdgcn_s_setprio(1);                      \
-    mma_quadrant<QA, QB>(acc, af, bfr);                 \
+    if (!(VAR & 1)) mma_quadrant<QA, QB>(acc, af, bfr); \
+    else keep_frags(af, bfr);                           \
     __builtin_amdgcn_s_setprio(0);                      \
     asm volatile("" ::: "memory");                      \
   }
@@ -195,23 +219,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   }
 #undef PHASE
 
-  // ---- epilogue: lane holds channels g*4..g*4+3 (rows) of token n (column) of each 16 x 16 tile ----
+  if ((VAR & 8) && p.M > 0) {
+    if (acc[0][0][0] == 12345.678f) p.out[0] = 1;    // data-dependent, never true: the accumulators stay live
+    return;
+  }
+  // ---- epilogue.  A lane holds channels g*4..g*4+3 of token n of each 16 x 16 tile: stored from there, every store
+  //      instruction would write 16 rows x 32 bytes, and the 100 MB of a [32768, 1536] output took longer than the whole
+  //      reduction (measured: 114 us with, 49 us without the stores).  So the wave's 64 x 128 tile goes through LDS once
+  //      (rows padded to 272 bytes: conflict-free 8-byte writes) and leaves as 16 bytes per lane, 256 contiguous bytes
+  //      per row; bias / relu / dropout are applied in fp32 on the way in, gate / add with 16-byte loads on the way out.
   unsigned key = 0;
   if (p.thr) key = mix32((p.seed_dev ? *p.seed_dev : 0u) * 0x9E3779B1u + p.site * 0x85EBCA77u + 0x165667B1u);
+  __syncthreads();                                         // every wave is done with the operand buffers
+  unsigned char* ep = smem + wave * EP_WAVE;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int row = pb * 256 + wc * 64 + j * 16 + n;
-    if (row >= p.M) continue;
-    const long rbase = (long)row * p.NO;
+    const long rbase = (long)(pb * 256 + wc * 64 + j * 16 + n) * p.NO;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int co = yi * 256 + wr * 128 + i * 16 + g * 4;
-      const long off = rbase + co;
-      uint2 gv = make_uint2(0, 0), av = make_uint2(0, 0);
-      if (p.gate) gv = *reinterpret_cast<const uint2*>(p.gate + off);
-      if (p.add) av = *reinterpret_cast<const uint2*>(p.add + off);
-      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
-      const bf16_t* ap = reinterpret_cast<const bf16_t*>(&av);
       bf16_t outv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -219,18 +245,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
         if (p.bias) v += p.bias[co + r];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.thr) {
-          const unsigned long idx = (unsigned long)(off + r);
+          const unsigned long idx = (unsigned long)(rbase + co + r);
           const unsigned hsh = mix32((unsigned)idx ^ key ^ (unsigned)(idx >> 32) * 0xC2B2AE35u);
           v = hsh >= p.thr ? v * p.keep : 0.f;
         }
-        if (p.gate) v = bf2f(gp[r]) > 0.f ? v * p.gate_pos : 0.f;
-        if (p.add) v += bf2f(ap[r]);
         outv[r] = f2bf(v);
       }
-      *reinterpret_cast<uint2*>(p.out + off) = *reinterpret_cast<uint2*>(outv);
+      *reinterpret_cast<uint2*>(ep + (j * 16 + n) * EP_PITCH + (i * 16 + g * 4) * 2) = *reinterpret_cast<uint2*>(outv);
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave reads back what its own lanes wrote
+  __builtin_amdgcn_wave_barrier();
+  const int rrow = lane >> 4, c16 = lane & 15;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int trow = r * 4 + rrow;
+    const int row = pb * 256 + wc * 64 + trow;
+    if (row >= p.M) continue;
+    const long off = (long)row * p.NO + yi * 256 + wr * 128 + c16 * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(ep + trow * EP_PITCH + c16 * 16);
+    if (p.gate || p.add) {
+      uint4 gv = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
+      if (p.gate) gv = *reinterpret_cast<const uint4*>(p.gate + off);
+      if (p.add) av = *reinterpret_cast<const uint4*>(p.add + off);
+      bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
+      const bf16_t* ap = reinterpret_cast<const bf16_t*>(&av);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = bf2f(vp[e]);
+        if (p.gate) f = bf2f(gp[e]) > 0.f ? f * p.gate_pos : 0.f;
+        if (p.add) f += bf2f(ap[e]);
+        vp[e] = f2bf(f);
+      }
+    }
+    *reinterpret_cast<uint4*>(p.out + off) = v;
+  }
 }
+
+int g_variant = 0;     // measurement switch (evt_debug_gemm256_variant); 0 = the product kernel
 
 bool eligible(const evt_gemm_params* g, int kred, int nout) {
   if (g->dtype != EVT_DT_BF16) return false;
@@ -258,22 +311,40 @@ int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int
   }
   p.Y = nout / 256;
   p.P = (g->M + 255) / 256;
-  static bool attr = false;
-  const size_t lds = 2 * KTB;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return EVT_ELAUNCH;
-    attr = true;
-  }
+  const size_t lds = 8 * EP_WAVE > 2 * KTB ? 8 * EP_WAVE : 2 * KTB;
+  const dim3 grid(8 * ((p.P + 7) / 8) * p.Y);
   evt_set_last_tag("gemm256_nt<bf16, 256, 256, 64>");
-  hipLaunchKernelGGL(gemm256_nt, dim3(8 * ((p.P + 7) / 8) * p.Y), dim3(512), lds, st, p);
+#define G256_LAUNCH(V)                                                                                                  \
+  {                                                                                                                     \
+    static bool attr = false;                                                                                           \
+    if (!attr) {                                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_nt<V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess)                                                                  \
+        return EVT_ELAUNCH;                                                                                             \
+      attr = true;                                                                                                      \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(gemm256_nt<V>, grid, dim3(512), lds, st, p);                                                     \
+  }
+  switch (g_variant) {
+    case 0: G256_LAUNCH(0) break;
+    case 1: G256_LAUNCH(1) break;
+    case 2: G256_LAUNCH(2) break;
+    case 4: G256_LAUNCH(4) break;
+    case 5: G256_LAUNCH(5) break;
+    case 6: G256_LAUNCH(6) break;
+    case 8: G256_LAUNCH(8) break;
+    case 9: G256_LAUNCH(9) break;
+    default: return EVT_EINVAL;
+  }
+#undef G256_LAUNCH
   return evt_check_launch();
 }
 
 }  // namespace
 
 extern "C" {
+
+void evt_debug_gemm256_variant(int32_t v) { g_variant = v; }
 
 int32_t evt_gemm_bf16_fused_supported(const evt_gemm_params* g, int32_t backward_data) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return 0;

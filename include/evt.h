@@ -313,6 +313,10 @@ typedef struct evt_gemm_epilogue {
   const void* add;          /* [M][out columns] in the GEMM's dtype, or NULL; added last */
 } evt_gemm_epilogue;
 int32_t evt_gemm_bf16_fused_supported(const evt_gemm_params* g, int32_t backward_data);
+/* measurement switch of csrc/gemm256.hip (tools/bench_gemm256.py): ablation variants of the kernel, bit 0 no MFMAs, bit 1
+ * no DMA after the prologue, bit 2 no fragment reads, bit 3 no stores; 0 = the product kernel.  Results are only
+ * meaningful for 0. */
+void evt_debug_gemm256_variant(int32_t variant);
 int evt_gemm_bf16_fwd_ex(const evt_gemm_params* g, const void* x, const void* w_reg, const void* w_alt, const float* bias,
                          const evt_gemm_epilogue* epi, void* y, void* stream);
 int evt_gemm_bf16_bwd_data_ex(const evt_gemm_params* g, const void* dy, const void* w_reg, const void* w_alt,

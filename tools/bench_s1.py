@@ -89,7 +89,7 @@ def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2, x_len=256):
     # the Linear layers run on the k = 1 members of the conv family (csrc/gemm.hip); anything named Cijk_* would be a
     # vendor GEMM
     is_gemm = lambda k: any(t in short_name(k) for t in ("conv_deep", "conv_ring", "wgrad_gemm", "wgrad_ring", "wgrad_deep",
-                                                          "gemm_bf16", "conv_igemm", "rows16_gemm"))
+                                                          "gemm_bf16", "conv_igemm", "rows16_gemm", "gemm256"))
     gemm = sorted(((k, c) for k, c in kernels.items() if k.startswith("Cijk_") or is_gemm(k)), key=lambda kv: -kv[1][1])
     out["also"] = also
     out["attention_ms_per_micro_step"] = round(att_us / 1e3 / n_micro, 3)
