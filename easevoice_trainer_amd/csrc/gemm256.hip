@@ -93,12 +93,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   const int n = lane & 15, g = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
 
-  // XCD-aware decode (as conv_deep): all channel tiles of a token tile on one XCD, so the token rows are fetched once per L2
-  const int lin = blockIdx.x;
+  // Persistent blocks: one per CU, walking the tile list with stride gridDim.x (a multiple of 8: a block stays on its XCD).
+  // XCD-aware decode (as conv_deep): all channel tiles of a token tile on one XCD, so the token rows are fetched once per
+  // L2.  Being persistent is what hides the output: the stores of tile t drain under the DMA and MFMAs of tile t + 1 (one
+  // block per CU could not overlap them with anything: 91 us instead of 48 us without stores at [32768, 1536, 512]).
+  const int nvirt = 8 * ((p.P + 7) / 8) * p.Y;
+  for (int lin = blockIdx.x; lin < nvirt; lin += gridDim.x) {
   const int xcd = lin & 7, slot = lin >> 3;
   const int yi = slot % p.Y;
   const int pb = xcd + 8 * (slot / p.Y);
-  if (pb >= p.P) return;
+  if (pb >= p.P) continue;
 
   // ---- per-lane DMA sources.  A wave fills local rows [16 w, 16 w + 16) of every piece, 8 rows per instruction.
   //      piece-local row lr -> tile row:  a-piece h: (lr >> 6) * 128 + h * 64 + (lr & 63)   (wave row-half, M-tile half)
@@ -221,7 +225,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
 
   if ((VAR & 8) && p.M > 0) {
     if (acc[0][0][0] == 12345.678f) p.out[0] = 1;    // data-dependent, never true: the accumulators stay live
-    return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    continue;
   }
   // ---- epilogue.  A lane holds channels g*4..g*4+3 of token n of each 16 x 16 tile: stored from there, every store
   //      instruction would write 16 rows x 32 bytes, and the 100 MB of a [32768, 1536] output took longer than the whole
@@ -230,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   //      per row; bias / relu / dropout are applied in fp32 on the way in, gate / add with 16-byte loads on the way out.
   unsigned key = 0;
   if (p.thr) key = mix32((p.seed_dev ? *p.seed_dev : 0u) * 0x9E3779B1u + p.site * 0x85EBCA77u + 0x165667B1u);
-  __syncthreads();                                         // every wave is done with the operand buffers
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // every wave is done with the operand buffers
+  asm volatile("" ::: "memory");
   unsigned char* ep = smem + wave * EP_WAVE;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -281,6 +289,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
     }
     *reinterpret_cast<uint4*>(p.out + off) = v;
   }
+  // the staging rows are read: the next tile's prologue may overwrite them.  Raw barrier, no vmcnt wait -- the stores
+  // stay in flight (the first counted wait of the next tile retires them, under its own DMA)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  }   // tile loop
 }
 
 int g_variant = 0;     // measurement switch (evt_debug_gemm256_variant); 0 = the product kernel
@@ -312,7 +326,16 @@ int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int
   p.Y = nout / 256;
   p.P = (g->M + 255) / 256;
   const size_t lds = 8 * EP_WAVE > 2 * KTB ? 8 * EP_WAVE : 2 * KTB;
-  const dim3 grid(8 * ((p.P + 7) / 8) * p.Y);
+  const int nvirt = 8 * ((p.P + 7) / 8) * p.Y;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EVT_ELAUNCH;
+    ncu = prop.multiProcessorCount / 8 * 8;
+    if (ncu <= 0) ncu = 8;
+  }
+  const dim3 grid(nvirt < ncu ? nvirt : ncu);
   evt_set_last_tag("gemm256_nt<bf16, 256, 256, 64>");
 #define G256_LAUNCH(V)                                                                                                  \
   {                                                                                                                     \
