@@ -56,6 +56,8 @@ constexpr int KTB = 4 * PIECE;         // one K tile: regions a0 | b0 | b1 | a1
 constexpr int R_A0 = 0, R_B0 = 1, R_B1 = 2, R_A1 = 3;
 constexpr int EP_PITCH = 272;            // epilogue staging: a wave's 64 token rows x 128 channels (256 B) + 16 B pad
 constexpr int EP_WAVE = 64 * EP_PITCH;   // 17 KiB per wave, 136 KiB per block
+constexpr int LDS_MAIN = 8 * EP_WAVE > 2 * KTB ? 8 * EP_WAVE : 2 * KTB;
+constexpr int LDS_TOTAL = LDS_MAIN + 256 * 4;     // + the tile's bias values
 
 __device__ __forceinline__ unsigned mix32(unsigned x) {   // lowbias32 finaliser (enc_ops.hip)
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -123,6 +125,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
       offs[h ? R_B1 : R_B0][i] = (unsigned)(bok[h][i] ? br : 0) * (unsigned)p.K + c * 8;
     }
   }
+  // the tile's 256 bias values wait in LDS behind the staging area (read in the epilogue: per-lane global loads of them
+  // there were serialised round trips, ~40 % of the kernel's time)
+  float* bias_l = reinterpret_cast<float*>(smem + LDS_MAIN);
+  if (p.bias && wave < 4)      // LDS-DMA like the operands (a register load + ds_write would stall the tile's start)
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + yi * 256 + wave * 64 + lane), (lptr_t)(bias_l + wave * 64), 4, 0, 0);
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g256_zero_page) + pslot * 8;
   unsigned char* my = smem + wave * 2048;                  // + buf * KTB + region * PIECE + i * 1024
   const int nt = p.K >> 6;
@@ -246,11 +253,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int co = yi * 256 + wr * 128 + i * 16 + g * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(bias_l + wr * 128 + i * 16 + g * 4);
       bf16_t outv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co + r];
+        float v = acc[i][j][r] + bv[r];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.thr) {
           const unsigned long idx = (unsigned long)(rbase + co + r);
@@ -325,7 +333,7 @@ int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int
   }
   p.Y = nout / 256;
   p.P = (g->M + 255) / 256;
-  const size_t lds = 8 * EP_WAVE > 2 * KTB ? 8 * EP_WAVE : 2 * KTB;
+  const size_t lds = LDS_TOTAL;
   const int nvirt = 8 * ((p.P + 7) / 8) * p.Y;
   static int ncu = 0;
   if (!ncu) {
