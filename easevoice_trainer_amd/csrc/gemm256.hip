@@ -312,8 +312,7 @@ bool eligible(const evt_gemm_params* g, int kred, int nout) {
   if (nout % 256 || kred % 64 || kred < 128) return false;
   if ((long)g->M * kred >= (1L << 31) || (long)nout * kred >= (1L << 31)) return false;
   if (g->M < 2048) return false;                             // few token tiles: the 128 / 64 tiles fill the chip better
-  static const bool off = getenv("EVT_NO_GEMM256") != nullptr;   // A/B switch for measurements
-  return !off;
+  return getenv("EVT_NO_GEMM256") == nullptr;                // A/B switch (measurements, fused-vs-composed tests)
 }
 
 int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int nout, const float* bias, int relu,

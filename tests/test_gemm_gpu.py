@@ -140,18 +140,14 @@ def test_gemm256_fused_epilogues(gpu, shape):
     assert rel(got, want) < 2e-2
 
 
-@pytest.mark.parametrize("dtype,B", [(torch.bfloat16, 3), (torch.float32, 1)], ids=["bf16-gemm256", "f32-fallback"])
-def test_s1_blocks_match_composition(gpu, dtype, B):
-    """auto_reg/blocks.py (attention block / FFN block as one autograd node each, fused epilogues) against the same
-    arithmetic composed from torch ops in fp32 on the CPU (transformer.py:311-334 with dropout off), with every
-    parameter gradient; bf16 at 3072 rows runs the 256 x 256 kernel, fp32 the fallback composition"""
+def _run_layer_blocks(gpu, dtype, B, seed=5):
+    """one post-LN layer through auto_reg/blocks.py; returns (layer, x, lens, out, dx, {param: grad})"""
     from easevoice_trainer_amd.auto_reg.blocks import attn_block, ffn_block
     from easevoice_trainer_amd.auto_reg.t2s_model import TransformerEncoderLayer
     from easevoice_trainer_amd.hip.linear import LinearBank
-    from oracle import s1_step as OS
 
     Lq, E, x_len = 1024, 512, 256
-    torch.manual_seed(5)
+    torch.manual_seed(seed)
     layer = TransformerEncoderLayer(E, 16, 2048, 0.0).to(gpu)
     with torch.no_grad():
         for p_ in layer.parameters():
@@ -170,7 +166,33 @@ def test_s1_blocks_match_composition(gpu, dtype, B):
     out = ffn_block(h, layer.linear1, layer.linear2, layer.norm2, 0.0, 2, 3)
     (out.float() * wgt).sum().backward()
     torch.cuda.synchronize()
+    return layer, x, (x_lens, y_lens, x_len, Lq, E), wgt, out.detach(), xg.grad, {k: p_.grad.clone() for k, p_ in layer.named_parameters()}
 
+
+def test_s1_blocks_fused_equals_composed(gpu, monkeypatch):
+    """the fused epilogues (gate / add in the backward GEMMs' stores, 256 x 256 kernel) against the SAME blocks on the
+    128 x 128 kernels + separate element-wise launches (EVT_NO_GEMM256): same bf16 operands, same roundings up to the
+    staging of the gated value, so everything agrees closely -- this is the check of the fusion logic itself"""
+    _l, _x, _lens, _w, out_f, dx_f, g_f = _run_layer_blocks(gpu, torch.bfloat16, 3)
+    monkeypatch.setenv("EVT_NO_GEMM256", "1")
+    _l, _x, _lens, _w, out_c, dx_c, g_c = _run_layer_blocks(gpu, torch.bfloat16, 3)
+    monkeypatch.delenv("EVT_NO_GEMM256")
+    assert rel(out_f, out_c) < 1e-2
+    assert rel(dx_f, dx_c) < 2e-2
+    for k in g_f:
+        assert rel(g_f[k], g_c[k]) < 2e-2, k
+
+
+@pytest.mark.parametrize("dtype,B", [(torch.bfloat16, 3), (torch.float32, 1)], ids=["bf16-gemm256", "f32-fallback"])
+def test_s1_blocks_match_composition(gpu, dtype, B):
+    """auto_reg/blocks.py (attention block / FFN block as one autograd node each, fused epilogues) against the same
+    arithmetic composed from torch ops in fp32 on the CPU (transformer.py:311-334 with dropout off), with every
+    parameter gradient; bf16 at 3072 rows runs the 256 x 256 kernel, fp32 the fallback composition.  The bf16 bounds on
+    the FFN weights are loose: a pre-activation within bf16 rounding of zero takes the other branch of relu' than in the
+    fp32 reference, a full-size (not a rounding-size) difference in a few of the 3072 summed rows."""
+    from oracle import s1_step as OS
+
+    layer, x, (x_lens, y_lens, x_len, Lq, E), wgt, out, dx, grads = _run_layer_blocks(gpu, dtype, B)
     F_ = torch.nn.functional
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
     xr = x.float().cpu().requires_grad_(True)
@@ -181,9 +203,9 @@ def test_s1_blocks_match_composition(gpu, dtype, B):
     ff = F_.linear(torch.relu(F_.linear(h1, P["linear1.weight"], P["linear1.bias"])), P["linear2.weight"], P["linear2.bias"])
     ref = F_.layer_norm(h1 + ff, (E,), P["norm2.weight"], P["norm2.bias"], layer.norm2.eps)
     (ref * wgt.cpu()).sum().backward()
-    tol = 3e-2 if dtype == torch.bfloat16 else 1e-3
+    bf = dtype == torch.bfloat16
+    tol = 3e-2 if bf else 1e-3
     assert rel(out, ref) < tol
-    # padded query rows of the reference still attend; their keys are masked for everybody: compare all rows
-    assert rel(xg.grad, xr.grad) < (5e-2 if dtype == torch.bfloat16 else tol)     # through 8 bf16 GEMMs, attention, 2 LN
-    for k, p_ in layer.named_parameters():
-        assert rel(p_.grad, P[k].grad) < tol, k
+    assert rel(dx, xr.grad) < (6e-2 if bf else tol)            # through 8 bf16 GEMMs, the attention and two LayerNorms
+    for k, g_ in grads.items():
+        assert rel(g_, P[k].grad) < ((1e-1 if "linear" in k else 5e-2) if bf else tol), k
