@@ -30,6 +30,82 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 
 constexpr int BM = 128, BN = 128, BK = 64;
+
+// -----------------------------------------------------------------------------------------------------------------
+// Epilogue of the LDS-DMA conv kernels.  An MFMA lane holds 4 consecutive output channels of ONE position: stored from
+// there, an instruction writes 16 rows x 32 bytes (measured on the 256 x 256 GEMM: 100 MB of output took 65 us that way,
+// 19 us as whole rows).  So the block's [TN positions][TM channels] tile is staged in LDS once -- rows padded by 16 bytes:
+// conflict-free 8-byte writes -- and leaves as 16 bytes per lane, whole rows of 2*TM contiguous bytes.  bias / output
+// activation are applied in fp32 on the way in; gate / residual with 16-byte loads on the way out.  The operand stages
+// are dead by then (every wave passed the last stage's MFMAs before the barrier).
+// -----------------------------------------------------------------------------------------------------------------
+template <int TM, int TN, int MI, int NJ>
+__device__ __forceinline__ void store_tile_staged(const ConvP& p, unsigned char* smem, const f32x4 (&acc)[MI][NJ], int wr,
+                                                  int wc, int n, int g, int yi, int pb, int phase, int total_units) {
+  constexpr int PITCH = TM * 2 + 16;
+  constexpr int CPR = TM / 8;                              // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;                           // rows per pass of the block
+  f32x4 bv[MI];                                            // this lane's bias values: one 16-byte load per channel tile
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+    bv[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + yi * TM + wr * 16 * MI + i * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pl = wc * 16 * NJ + j * 16 + n;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int cl = wr * 16 * MI + i * 16 + g * 4;
+      bf16_t outv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[i][r];
+        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
+        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
+        outv[r] = f2bf(v);
+      }
+      *reinterpret_cast<uint2*>(smem + pl * PITCH + cl * 2) = *reinterpret_cast<uint2*>(outv);
+    }
+  }
+  __syncthreads();
+  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
+  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.gate);
+  const int tid = threadIdx.x;
+  const int c16 = tid % CPR, r0 = tid / CPR;
+#pragma unroll
+  for (int pass = 0; pass < TN / RPP; ++pass) {
+    const int pl = pass * RPP + r0;
+    const int u = pb * TN + pl;
+    if (u >= total_units) continue;
+    const int seq = u / p.Q;
+    const int q = u - seq * p.Q;
+    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
+    if (orow < 0 || orow >= p.Lout) continue;
+    const long off = ((long)seq * p.Lout + orow) * p.Cout + yi * TM + c16 * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(smem + pl * PITCH + c16 * 16);
+    if (G || R) {
+      uint4 gv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
+      if (G) gv = *reinterpret_cast<const uint4*>(G + off);
+      if (R) rv = *reinterpret_cast<const uint4*>(R + off);
+      bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
+      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
+      const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = bf2f(vp[e]);
+        if (G) f *= (bf2f(gp[e]) > 0.f ? 1.f : p.gate_slope);
+        if (R) f += bf2f(rp[e]);
+        vp[e] = f2bf(f);
+      }
+    }
+    *reinterpret_cast<uint4*>(Y + off) = v;
+  }
+}
+
+
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
 
 __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
@@ -125,37 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
     }
   }
 
-  // ---- epilogue: lane holds channels g*4..g*4+3 (rows) of position n (column) of each 16 x 16 tile ----
-  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.gate);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int u = pb * BN + wc * 64 + j * 16 + n;
-    if (u >= total_units) continue;
-    const int seq = u / p.Q;
-    const int q = u - seq * p.Q;
-    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
-    if (orow < 0 || orow >= p.Lout) continue;
-    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = yi * BM + wr * 64 + i * 16 + g * 4;
-      const long off = rbase + co;
-      bf16_t outv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co + r];
-        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
-        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
-        if (G) v *= (bf2f(G[off + r]) > 0.f ? 1.f : p.gate_slope);
-        if (R) v += bf2f(R[off + r]);
-        outv[r] = f2bf(v);
-      }
-      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
-    }
-  }
+  // ---- epilogue: through LDS, whole rows (store_tile_staged) ----
+  store_tile_staged<BM, BN, 4, 4>(p, smem, acc, wr, wc, n, g, yi, pb, phase, total_units);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -244,36 +291,7 @@ __global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 
-  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* Gt = reinterpret_cast<const bf16_t*>(p.gate);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int u = pb * BN + wc * 64 + j * 16 + n;
-    if (u >= total_units) continue;
-    const int seq = u / p.Q;
-    const int q = u - seq * p.Q;
-    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
-    if (orow < 0 || orow >= p.Lout) continue;
-    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = yi * BM + wr * 64 + i * 16 + g * 4;
-      const long off = rbase + co;
-      bf16_t outv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co + r];
-        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
-        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
-        if (Gt) v *= (bf2f(Gt[off + r]) > 0.f ? 1.f : p.gate_slope);
-        if (R) v += bf2f(R[off + r]);
-        outv[r] = f2bf(v);
-      }
-      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
-    }
-  }
+  store_tile_staged<BM, BN, 4, 4>(p, smem, acc, wr, wc, n, g, yi, pb, phase, total_units);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -398,36 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
     asm volatile("" ::: "memory");
   }
 
-  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* Gt = reinterpret_cast<const bf16_t*>(p.gate);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int u = pb * RN + wc * 16 * NT + j * 16 + n;
-    if (u >= total_units) continue;
-    const int seq = u / p.Q;
-    const int q = u - seq * p.Q;
-    const int orow = q * p.s_out + p.off_out + phase * p.off_out_phase;
-    if (orow < 0 || orow >= p.Lout) continue;
-    const long rbase = ((long)seq * p.Lout + orow) * p.Cout;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int co = yi * RM + wr * 16 * MT + i * 16 + g * 4;
-      const long off = rbase + co;
-      bf16_t outv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[co + r];
-        if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
-        else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
-        if (Gt) v *= (bf2f(Gt[off + r]) > 0.f ? 1.f : p.gate_slope);
-        if (R) v += bf2f(R[off + r]);
-        outv[r] = f2bf(v);
-      }
-      *reinterpret_cast<uint2*>(Y + off) = *reinterpret_cast<uint2*>(outv);
-    }
-  }
+  store_tile_staged<RM, RN, MT, NT>(p, smem, acc, wr, wc, n, g, yi, pb, phase, total_units);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1312,7 +1301,7 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
   const bool short_k = (k_ch / 64) * p.KHp <= 12;
   if (deep32 == 1 || k_ch % 64 || (deep32 != 0 && short_k)) {
     static bool attr32 = false;
-    const size_t lds32 = 2 * STAGE32;
+    const size_t lds32 = 2 * STAGE32 > 128 * 272 ? 2 * STAGE32 : 128 * 272;   // operand stages, then the staged output tile
     if (!attr32) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_deep32), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds32) != hipSuccess)
