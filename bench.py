@@ -26,16 +26,27 @@ sys.path.insert(0, ROOT)
 
 
 def init_dist(n_gpus):
+    """one rank per GPU over RCCL.  EVT_BENCH_BACKEND=gloo is the dry-run switch of the test tiers (a box with fewer
+    GPUs than ranks: the ranks share device LOCAL_RANK % device_count, which RCCL refuses; no GPU at all: the s1 leg on
+    the CPU with emulated launches, tests/bench_dryrun_worker.py) -- same spawn / rendezvous / broadcast / step / JSON
+    path, different transport."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    backend = os.environ.get("EVT_BENCH_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return world, rank, local
 
 

@@ -28,12 +28,33 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None, rsag=None):
+        """rsag (default: EVT_DP_RSAG=1): every bucket as reduce-scatter + all-gather, in place, instead of one
+        all-reduce.  On xGMI every GPU has a direct link to each of the other seven: a ring all-reduce is bound by ONE
+        link per hop, while the two halves of reduce-scatter / all-gather move 1/world of the bucket to / from every peer
+        at once.  The results are the same sums (per element: one reduction over the ranks either way); the variant is
+        equality-tested against all_reduce on gloo (tests/test_host_cpu.py) and stays opt-in until it has met RCCL."""
         self.world = world_size
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.rsag = (os.environ.get("EVT_DP_RSAG", "0") == "1") if rsag is None else bool(rsag)
         self._pending = []
         self._stream = None
+
+    def _sum_bucket(self, t):
+        """sum the 1-D contiguous bucket `t` over the group, in place"""
+        if not self.rsag or t.numel() < self.world:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        w = self.world
+        rank = dist.get_rank(self.group)
+        chunk = t.numel() // w
+        body = t[: chunk * w]
+        mine = body[rank * chunk: (rank + 1) * chunk]       # in place: shard r of the input is rank r's output
+        dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_gather_into_tensor(body, mine, group=self.group)
+        if chunk * w < t.numel():                           # fewer than `world` leftover elements
+            dist.all_reduce(t[chunk * w:], op=dist.ReduceOp.SUM, group=self.group)
 
     def _side_stream(self, device):
         if self._stream is None and device.type == "cuda":
@@ -55,13 +76,13 @@ class GradReducer:
             side.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(side):
                 for b, e in self.buckets(flat.numel()):
-                    dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+                    self._sum_bucket(flat[b:e])
                 if average:
                     flat.mul_(1.0 / self.world)
             self._pending.append(flat)
             return
         for b, e in self.buckets(flat.numel()):
-            dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+            self._sum_bucket(flat[b:e])
         if average:
             flat.mul_(1.0 / self.world)
 
@@ -97,6 +118,17 @@ def init_process_group_from_env(backend=None, gpu_ids=None):
         else:
             ids = parse_gpu_ids(gpu_ids) if gpu_ids is not None else []
             local = ids[0] if ids else 0
+            if len(ids) > 1:
+                import warnings
+
+                warnings.warn(f"gpu_ids={gpu_ids!r} names {len(ids)} GPUs but this is a single process (no launcher: "
+                              f"WORLD_SIZE=1): training on GPU {local} only -- start it through cmd/train_*.py, which "
+                              "spawns one rank per listed GPU")
+            # a scheduler (or the reference's own CUDA_VISIBLE_DEVICES=gpu_ids export, src/train/sovits.py:168) may have
+            # narrowed the visible devices already: id 2 with one visible device is that device
+            nvis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if nvis and local >= nvis:
+                local = local % nvis
         return world, int(os.environ.get("RANK", "0")), local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")

@@ -113,15 +113,27 @@ class _MaskedKLFn(torch.autograd.Function):
 
 
 def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
-    """losses.py:46-61.  The four tensors share one layout, either [B, C, T] views of channels-last storage (what
-    SynthesizerTrn returns), contiguous [B, T, C], or contiguous [B, C, T]; z_mask [B, 1, T] is the sequence mask of
-    `lens` (passed directly by the engine; recovered as the per-row mask sums otherwise)."""
+    """losses.py:46-61.  The four tensors are [B, C, T] like the reference's (z_mask [B, 1, T]); their storage is either
+    channels-last (what SynthesizerTrn returns: [B, C, T] views of contiguous [B, T, C], read in place) or the
+    reference's own contiguous [B, C, T].  The layout is read off the strides -- never guessed from sizes (a batch with
+    T == C would be ambiguous by size): anything else, or tensors that disagree, raises.  `lens` [B] (the sequence mask
+    as lengths; recovered as the per-row mask sums otherwise)."""
     ts = [z_p, logs_q, m_p, logs_p]
+    if z_mask.dim() != 3 or z_mask.size(1) != 1 or any(t.dim() != 3 or t.shape != z_p.shape for t in ts) \
+            or z_mask.size(-1) != z_p.size(-1) or z_mask.size(0) != z_p.size(0):
+        raise L.EvtError(f"kl_loss: [B, C, T] tensors and a [B, 1, T] mask expected, got {[tuple(t.shape) for t in ts]} "
+                         f"/ {tuple(z_mask.shape)}")
     if lens is None:
         lens = z_mask.reshape(z_mask.size(0), -1).sum(1)
     lens = lens.to(torch.int32).contiguous()
-    if all((not t.is_contiguous()) and t.transpose(1, 2).is_contiguous() for t in ts):
-        return _MaskedKLFn.apply(*[t.transpose(1, 2) for t in ts], lens, False)
-    if z_mask.size(-1) == z_p.size(-1) and z_mask.size(1) == 1:
-        return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, True)
-    return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, False)
+    B, Cc, T = z_p.shape
+    cl = lambda t: t.stride() == (T * Cc, 1, Cc)           # [B, C, T] view of contiguous [B, T, C]
+    if T > 1 and Cc > 1:
+        if all(cl(t) for t in ts):
+            return _MaskedKLFn.apply(*[t.transpose(1, 2) for t in ts], lens, False)
+        if all(t.is_contiguous() for t in ts):
+            return _MaskedKLFn.apply(*ts, lens, True)
+        raise L.EvtError("kl_loss: the four tensors must share one layout: all channels-last views or all contiguous "
+                         f"[B, C, T]; strides {[t.stride() for t in ts]}")
+    # a singleton axis: both layouts describe the same memory; take the reference's
+    return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, True)

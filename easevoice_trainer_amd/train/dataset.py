@@ -12,7 +12,8 @@ the copy instead of in DataLoader workers -- the 5-wav32k files are 16-bit PCM a
 ffmpeg subprocess (src/utils/audio/__init__.py:13-32) reduces to a RIFF parse and a scale by 1/32768.
 
 The phoneme table is data of the reference's text front-end (src/easevoice/text/symbols.py) and is not restated here:
-it is read from `symbols.json` (see tools/dump_symbols.py) or imported from a reference checkout on sys.path."""
+it is read from `symbols.json` (`<exp_dir>/symbols.json` or `$EVT_SYMBOLS_JSON`, written by tools/dump_symbols.py); the
+product never imports the reference."""
 import json
 import math
 import os

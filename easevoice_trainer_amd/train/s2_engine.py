@@ -61,10 +61,21 @@ class S2Engine:
             nd = len(self.net_d.discriminators)
             self._d_ranges = [self.rt_d.arena.range_of_prefix(f"discriminators.{i}.") for i in range(nd)]
             self._d_convs = [[m for m in d.modules() if hasattr(m, "_slot")] for d in self.net_d.discriminators]
-            # the vocoder's convolutions (conv_pre .. conv_post; its 1x1 conditioning layer is an autograd parameter and
-            # goes with the rest): ~58 MB of the generator's 205 MB, reduced under the flow / encoder backward
+            # the vocoder's convolutions (conv_pre .. conv_post): ~58 MB of the generator's 205 MB, reduced under the flow /
+            # encoder backward.  Its 1x1 conditioning layer (dec.cond, a conv of the bank too, registered last) is left
+            # out of the early range: its input gradient continues into the style encoder, it is reduced with the rest.
             self._dec_convs = [m for n, m in self.net_g.dec.named_modules() if hasattr(m, "_slot")]
             self._dec_range = self.rt_g.arena.range_of_prefix("dec.", stop_before="dec.cond.")
+            # a range is reduced as soon as its convolutions' gradients are finished; a parameter whose gradient only
+            # arrives with the final gather (an autograd-owned one) must not sit inside such a range -- it would be
+            # reduced before it was written: silent gradient loss under data parallelism
+            early = [(self._dec_range, self.rt_g)] + [(r, self.rt_d) for r in self._d_ranges]
+            for (lo, hi), rt in early:
+                for p_, view in rt._free:
+                    off = (view.data_ptr() - rt.arena.grad.data_ptr()) // 4
+                    if lo <= off < hi:
+                        raise L.EvtError("data-parallel overlap: an autograd-gathered parameter lies inside an early-"
+                                         f"reduced gradient range [{lo}, {hi}) at offset {off}")
 
     # -- optimisers: 4 groups for G exactly as sovits.py:286-319 (text_embedding / encoder_text / mrte at a
     #    lower lr), everything that receives no gradient (ssl_proj) left out

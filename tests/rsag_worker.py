@@ -1,0 +1,33 @@
+"""Worker of tests/test_host_cpu.py::test_reduce_scatter_all_gather_equals_all_reduce (gloo, CPU): the same ragged buffer
+summed with GradReducer's all-reduce buckets and with its reduce-scatter + all-gather variant."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from easevoice_trainer_amd.dist import GradReducer
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g = torch.Generator().manual_seed(7 + rank)
+    for n in (1, world - 1, world, 1000, 4099, 10007):          # below / at / above the world size, ragged tails
+        x = torch.randn(n, generator=g)
+        a, b = x.clone(), x.clone()
+        GradReducer(world, bucket_bytes=4 * 1024, rsag=False).all_reduce(a)
+        GradReducer(world, bucket_bytes=4 * 1024, rsag=True).all_reduce(b)
+        # one reduction over the ranks per element either way; gloo's ring adds in a rank-rotated order per chunk, so
+        # the two sums may differ in the last bit
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), (n, float((a - b).abs().max()))
+        ref = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(ref, x)
+        assert torch.allclose(b, torch.stack(ref).sum(0), rtol=1e-6, atol=1e-6), n
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

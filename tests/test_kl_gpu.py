@@ -15,13 +15,15 @@ def _ref(z_p, logs_q, m_p, logs_p, z_mask):
 
 
 @pytest.mark.parametrize("layout", ["channels_last_views", "bct_contiguous"])
-@pytest.mark.parametrize("zdt", [torch.float32, torch.bfloat16])
-def test_masked_kl_matches_reference(gpu, layout, zdt):
+@pytest.mark.parametrize("zdt,T", [(torch.float32, 173), (torch.bfloat16, 173), (torch.float32, 192)],
+                         ids=["f32", "bf16", "f32-T_equals_C"])
+def test_masked_kl_matches_reference(gpu, layout, zdt, T):
+    """T == C (192 frames x 192 channels): the layout must come from the strides, not from the sizes"""
     from easevoice_trainer_amd.module.losses import kl_loss
 
-    B, C, T = 5, 192, 173
+    B, C = 5, 192
     g = torch.Generator().manual_seed(3)
-    lens = torch.tensor([173, 1, 100, 64, 172])
+    lens = torch.tensor([T, 1, 100, 64, T - 1])
     mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1)            # [B, 1, T]
     base = [torch.randn(B, C, T, generator=g) * s for s in (1.0, 0.3, 1.0, 0.3)]
     base[0] = base[0].to(zdt).float()           # z_p in the compute dtype, exactly representable
@@ -48,3 +50,17 @@ def test_masked_kl_matches_reference(gpu, layout, zdt):
     # without `lens` the mask sums recover the lengths
     out2 = kl_loss(*[a.detach() for a in args], mask.to(gpu))
     assert abs(float(out2) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+def test_kl_loss_rejects_mixed_layouts(gpu):
+    from easevoice_trainer_amd.hip.lib import EvtError
+    from easevoice_trainer_amd.module.losses import kl_loss
+
+    B, C, T = 2, 8, 8
+    a = torch.randn(B, C, T, device=gpu)
+    cl = torch.randn(B, T, C, device=gpu).transpose(1, 2)
+    mask = torch.ones(B, 1, T, device=gpu)
+    with pytest.raises(EvtError):
+        kl_loss(a, a, cl, a, mask)
+    with pytest.raises(EvtError):
+        kl_loss(a, a, a, a, torch.ones(B, T, device=gpu))

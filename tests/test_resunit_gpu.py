@@ -68,6 +68,11 @@ def test_fused_resblock_step(gpu, case):
     # to bf16 on either side of an fp32 rounding difference, so a pre-activation within 1e-3 of zero may take the other
     # branch -- one such position moves a bias gradient by 0.9 |d| while leaving every forward value where it was
     gate = torch.where(mid_f.float().cpu().transpose(1, 2) > 0, 1.0, LRELU_SLOPE)
+    # ... which must be the oracle's own decisions almost everywhere: a wrong sign pattern in the kernel's intermediate
+    # would otherwise pass unnoticed (the positions that differ sit within rounding distance of zero)
+    agree = ((h.detach() > 0) == (mid_f.float().cpu().transpose(1, 2) > 0))
+    assert agree.float().mean().item() >= 0.999, agree.float().mean().item()
+    assert float(h.detach()[~agree].abs().max() if (~agree).any() else 0.0) < 2e-2 * float(h.detach().abs().max())
     h = h * gate
     h = h + (h.detach().bfloat16().float() - h.detach())                  # the intermediate is stored as bf16
     yo = xo + F.conv1d(h, ws[1], po[1]["bias"], padding=get_padding(k, 1))

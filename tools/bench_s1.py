@@ -113,8 +113,12 @@ def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2, x_len=256):
 def run(args, world, rank, local, extras=True):
     from easevoice_trainer_amd.train.s1_engine import S1Engine
 
-    dev = torch.device("cuda", local)
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")     # cpu: the emulated dry run of the test tier
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    if os.environ.get("EVT_BENCH_TINY") == "1":                              # dry runs only: a 2-layer toy of the model
+        cfg["model"].update(hidden_dim=64, embedding_dim=64, head=4, n_layer=2, linear_units=256)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(cfg["train"]["seed"])
     reducer = None
@@ -126,7 +130,7 @@ def run(args, world, rank, local, extras=True):
     if world > 1:
         reducer.broadcast_params(eng.arena.param)
     B = args.s1_batch
-    x_len, y_len = 256, 768
+    x_len, y_len = (256, 768) if os.environ.get("EVT_BENCH_TINY") != "1" else (8, 24)
     batch = _batch(B, x_len, y_len, dev, 1234 + rank)
     idx = 0
     for _ in range(max(args.warmup, 1)):
@@ -134,14 +138,14 @@ def run(args, world, rank, local, extras=True):
         idx += 1
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, acc, _ = eng.micro_step(batch, idx)
         idx += 1
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -173,5 +177,6 @@ def run(args, world, rank, local, extras=True):
 
             res["cpu_baseline"] = cpu_baseline_s1()
     del eng
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     return res
