@@ -115,9 +115,10 @@ class _MaskedKLFn(torch.autograd.Function):
 def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
     """losses.py:46-61.  The four tensors are [B, C, T] like the reference's (z_mask [B, 1, T]); their storage is either
     channels-last (what SynthesizerTrn returns: [B, C, T] views of contiguous [B, T, C], read in place) or the
-    reference's own contiguous [B, C, T].  The layout is read off the strides -- never guessed from sizes (a batch with
-    T == C would be ambiguous by size): anything else, or tensors that disagree, raises.  `lens` [B] (the sequence mask
-    as lengths; recovered as the per-row mask sums otherwise)."""
+    reference's own contiguous [B, C, T] (or any other strides: copied).  The logical layout is fixed -- [B, C, T] with
+    a [B, 1, T] mask, anything else raises -- and the storage layout is read off the strides, never guessed from sizes
+    (a batch with T == C is ambiguous by size).  `lens` [B] (the sequence mask as lengths; recovered as the per-row mask
+    sums otherwise)."""
     ts = [z_p, logs_q, m_p, logs_p]
     if z_mask.dim() != 3 or z_mask.size(1) != 1 or any(t.dim() != 3 or t.shape != z_p.shape for t in ts) \
             or z_mask.size(-1) != z_p.size(-1) or z_mask.size(0) != z_p.size(0):
@@ -127,13 +128,9 @@ def kl_loss(z_p, logs_q, m_p, logs_p, z_mask, lens=None):
         lens = z_mask.reshape(z_mask.size(0), -1).sum(1)
     lens = lens.to(torch.int32).contiguous()
     B, Cc, T = z_p.shape
-    cl = lambda t: t.stride() == (T * Cc, 1, Cc)           # [B, C, T] view of contiguous [B, T, C]
-    if T > 1 and Cc > 1:
-        if all(cl(t) for t in ts):
-            return _MaskedKLFn.apply(*[t.transpose(1, 2) for t in ts], lens, False)
-        if all(t.is_contiguous() for t in ts):
-            return _MaskedKLFn.apply(*ts, lens, True)
-        raise L.EvtError("kl_loss: the four tensors must share one layout: all channels-last views or all contiguous "
-                         f"[B, C, T]; strides {[t.stride() for t in ts]}")
-    # a singleton axis: both layouts describe the same memory; take the reference's
+    # [B, C, T] views of contiguous [B, T, C] storage are read in place; anything else (the reference's own contiguous
+    # [B, C, T], slices of a wider statistics tensor, a mix) is copied into contiguous [B, C, T] first -- the LOGICAL
+    # layout is fixed by the mask's shape above, so no choice depends on sizes
+    if T > 1 and Cc > 1 and all(t.stride() == (T * Cc, 1, Cc) for t in ts):
+        return _MaskedKLFn.apply(*[t.transpose(1, 2) for t in ts], lens, False)
     return _MaskedKLFn.apply(*[t.contiguous() for t in ts], lens, True)

@@ -52,15 +52,22 @@ def test_masked_kl_matches_reference(gpu, layout, zdt, T):
     assert abs(float(out2) - float(ref)) <= 1e-5 * abs(float(ref))
 
 
-def test_kl_loss_rejects_mixed_layouts(gpu):
+def test_kl_loss_layouts_and_shape_errors(gpu):
+    """mixed storage layouts (a channels-last view next to contiguous [B, C, T] tensors, slices of a wider tensor) give
+    the value of the all-contiguous call; a mask that is not [B, 1, T] raises instead of being guessed at"""
     from easevoice_trainer_amd.hip.lib import EvtError
     from easevoice_trainer_amd.module.losses import kl_loss
 
     B, C, T = 2, 8, 8
-    a = torch.randn(B, C, T, device=gpu)
-    cl = torch.randn(B, T, C, device=gpu).transpose(1, 2)
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(B, C, T, generator=g).to(gpu) * s for s in (1.0, 0.3, 1.0, 0.3)]
     mask = torch.ones(B, 1, T, device=gpu)
+    want = float(kl_loss(*base, mask))
+    cl = base[2].transpose(1, 2).contiguous().transpose(1, 2)                   # same values, channels-last storage
+    wide = torch.cat([base[3], base[3]], dim=1)[:, :C]                          # a slice of a [B, 2C, T] tensor
+    assert abs(float(kl_loss(base[0], base[1], cl, wide, mask)) - want) <= 1e-5 * abs(want)
+    assert abs(float(kl_loss(*base, mask)) - float(_ref(*[t.cpu() for t in base], mask.cpu()))) <= 1e-5 * abs(want)
     with pytest.raises(EvtError):
-        kl_loss(a, a, cl, a, mask)
+        kl_loss(*base, torch.ones(B, T, device=gpu))
     with pytest.raises(EvtError):
-        kl_loss(a, a, a, a, torch.ones(B, T, device=gpu))
+        kl_loss(base[0], base[1][:, :, :4], base[2], base[3], mask)
