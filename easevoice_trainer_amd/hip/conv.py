@@ -145,6 +145,12 @@ class WeightBank:
         # the operands are held until then.  Measured on MI355X: -1.6 ms/step with eager launches, +7 ms/step under
         # HIP-graph replay (fork/join edges per conv), so it is off by default.
         self.async_wgrad = self.device.type == "cuda" and os.environ.get("EVT_ASYNC_WGRAD", "0") == "1"
+        # EVT_WGRAD_DEFER=N (default 0 = off): weight-gradient launches are queued and handed to a side HIP stream N at a
+        # time -- ONE fork per batch instead of one per convolution -- so the backward-data chain (the critical path:
+        # every launch waits for the one before it) shares the chip with the weight gradients, which depend on nothing
+        # but their two operands.  grads() joins.  The operands are held until the join.
+        self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "0")) if self.device.type == "cuda" else 0
+        self._deferred = []
         self._side = None
         self._held = []
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -232,7 +238,20 @@ class WeightBank:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def flush_deferred(self):
+        """hand the queued weight-gradient launches to the side stream (one fork)"""
+        if not self._deferred:
+            return
+        side = self.side_stream()
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for args in self._deferred:
+                _bwd_weight_now(*args)
+        self._held.extend((a[1], a[2], a[3]) for a in self._deferred)
+        self._deferred.clear()
+
     def join_side(self):
+        self.flush_deferred()
         if self._side is not None and self._held:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._held.clear()
@@ -417,6 +436,11 @@ def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
     if slot.packed_member:
         raise L.EvtError("weight gradient of a packed projection member requested on its own: inside a bf16 runtime the "
                          "q / k / v projections of a windowed attention layer run (and are differentiated) as one pack")
+    if bank.defer_n > 0 and TRACE is None:
+        bank._deferred.append((slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope))
+        if len(bank._deferred) >= bank.defer_n:
+            bank.flush_deferred()
+        return
     if bank.async_wgrad and TRACE is None:
         side = bank.side_stream()
         side.wait_stream(torch.cuda.current_stream(bank.device))
