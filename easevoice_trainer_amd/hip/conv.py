@@ -145,11 +145,13 @@ class WeightBank:
         # the operands are held until then.  Measured on MI355X: -1.6 ms/step with eager launches, +7 ms/step under
         # HIP-graph replay (fork/join edges per conv), so it is off by default.
         self.async_wgrad = self.device.type == "cuda" and os.environ.get("EVT_ASYNC_WGRAD", "0") == "1"
-        # EVT_WGRAD_DEFER=N (default 0 = off): weight-gradient launches are queued and handed to a side HIP stream N at a
-        # time -- ONE fork per batch instead of one per convolution -- so the backward-data chain (the critical path:
+        # EVT_WGRAD_DEFER=N (default 64; 0 = off): weight-gradient launches are queued and handed to a side HIP stream N at
+        # a time -- ONE fork per batch instead of one per convolution -- so the backward-data chain (the critical path:
         # every launch waits for the one before it) shares the chip with the weight gradients, which depend on nothing
-        # but their two operands.  grads() joins.  The operands are held until the join.
-        self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "0")) if self.device.type == "cuda" else 0
+        # but their two operands.  grads() joins.  The operands are held until the join.  Measured on MI355X, s2 step
+        # under HIP-graph replay, three interleaved rounds: 27.85-27.95 ms without, 27.14-27.18 ms with N = 64; small N
+        # (a fork every few convolutions) is what made EVT_ASYNC_WGRAD slower under replay.
+        self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "64")) if self.device.type == "cuda" else 0
         self._deferred = []
         self._side = None
         self._held = []
