@@ -421,125 +421,6 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
 
 
 // -----------------------------------------------------------------------------------------------------------------
-// conv_burst<MTW, NTW>: the same implicit GEMM for problems that are ONE round of blocks with a SHORT reduction -- the WN
-// in / res-skip layers, the 1x1 projections and the first FFN convolution at 3200 positions (B = 16 x T = 200): 340
-// launches per s2 step that conv_ring ran in 12-20 us each, of which the MFMAs are well under a microsecond.  A ring
-// pays one L2 round trip per K stage (hidden three deep) plus its fill; here the block's WHOLE operand set -- its
-// 32*MTW weight rows over the full (tap, channel) reduction and its 32*NTW + halo input rows -- is requested in one
-// LDS-DMA burst (<= 150 KiB, every request in flight at once), one wait, one barrier, then every MFMA of the tile back
-// to back, then the staged epilogue.  Grid: at most one block per CU (the launcher picks the tile so that the whole
-// problem is one round, and only takes this kernel then).
-//   Input rows are staged as the contiguous run of FLAT rows [u0 + off_in, u0 + TN - 1 + off_in + (KH-1) dil] of the
-// channels-last activation: for a stride-1 "same" convolution output position u reads flat row u + t*dil + off_in, which
-// is only wrong where that row lies in the neighbouring sequence -- those (position, tap) pairs get a zeroed B fragment
-// (a per-lane bit mask, the conv's zero padding).  Both LDS images are linear copies of global rows with the 16-byte
-// slot swizzle (slot ^= row & 7 inside every 128-byte segment) applied on the DMA source and undone on the fragment
-// read, as in conv_deep.
-// -----------------------------------------------------------------------------------------------------------------
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256) void conv_burst(ConvP p, int nr_b) {
-  constexpr int TM = 32 * MTW, TN = 32 * NTW;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7, slot = lin >> 3;
-  const int yi = slot % p.Y;
-  const int pb = xcd + 8 * (slot / p.Y);
-  if (pb >= p.P) return;
-
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w);
-  const int total_units = p.nseq * p.Q;
-  const int ktot = p.nchunk * p.KHp * 32;                 // reduction length (elements) = one weight row
-  const int spr_a = ktot >> 3, spr_b = p.Cin >> 3;        // 16-byte slots per row
-  const int a_bytes = TM * ktot * 2;
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + a_bytes;
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
-  const long u0 = (long)pb * TN;
-  const long fr0 = u0 + p.off_in;                         // flat input row of staged row 0
-  const long nrows_x = (long)p.nseq * p.Lin;
-
-  // ---- the burst: instruction i of the block (1 KiB each) is issued by wave i % 4 ----
-  {
-    const int nia = (TM * spr_a + 63) >> 6;               // TM * spr_a is a multiple of 64 (ktot % 64 == 0, TM % 32 == 0)
-    for (int i = wave; i < nia; i += 4) {
-      const int P = i * 64 + lane;
-      const int row = P / spr_a, sl = P - row * spr_a;
-      const int lg = (sl & ~7) | ((sl & 7) ^ (row & 7));
-      glds16(W + (long)(yi * TM + row) * ktot + lg * 8, As + i * 1024);
-    }
-    const int nsb = nr_b * spr_b;
-    const int nib = (nsb + 63) >> 6;
-    for (int i = wave; i < nib; i += 4) {
-      const int P = i * 64 + lane;
-      const int row = P / spr_b, sl = P - row * spr_b;
-      const int lg = (sl & ~7) | ((sl & 7) ^ (row & 7));
-      const long fr = fr0 + row;
-      const bool ok = P < nsb && fr >= 0 && fr < nrows_x;
-      glds16(ok ? X + fr * p.Cin + lg * 8 : zsrc + (lane & 7) * 8, Bs + i * 1024);
-    }
-  }
-
-  // per-lane validity of (position, tap): bit t of okb[j]
-  unsigned okb[NTW];
-  int brow[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int pl = wc * 16 * NTW + j * 16 + n;
-    const long u = u0 + pl;
-    brow[j] = pl;
-    okb[j] = 0u;
-    if (u < total_units) {
-      const int q = (int)(u % p.Q);
-#pragma unroll 1
-      for (int t = 0; t < p.KHp; ++t) {
-        const int r = q + t * p.dil + p.off_in;
-        if (r >= 0 && r < p.Lin) okb[j] |= 1u << t;
-      }
-    }
-  }
-  f32x4 acc[MTW][NTW];
-#pragma unroll
-  for (int i = 0; i < MTW; ++i)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int pitch_a = ktot * 2, pitch_b = p.Cin * 2;
-  const unsigned char* a_lane = As + (wr * 16 * MTW + n) * pitch_a;
-  const int swa = n & 7;
-
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  for (int c = 0; c < p.nchunk; ++c) {
-    const int bslot = ((c & 1) << 2) | g;
-    const int bseg = (c >> 1) * 128;
-    for (int t = 0; t < p.KHp; ++t) {
-      const int ks = c * p.KHp + t;
-      const int aoff = (ks >> 1) * 128 + (((((ks & 1) << 2) | g) ^ swa) << 4);
-      bf16x8 a[MTW], b[NTW];
-#pragma unroll
-      for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_lane + i * 16 * pitch_a + aoff);
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int rl = brow[j] + t * p.dil;
-        b[j] = *reinterpret_cast<const bf16x8*>(Bs + rl * pitch_b + bseg + ((bslot ^ (rl & 7)) << 4));
-        if (!((okb[j] >> t) & 1u)) b[j] = bf16x8{};
-      }
-#pragma unroll
-      for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  store_tile_staged<TM, TN, MTW, NTW>(p, smem, acc, wr, wc, n, g, yi, pb, 0, total_units);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
 // wgrad_deep: weight gradient of the same layers on the same LDS-DMA structure.
 //   dW[a][chunk][tap][cc] += sum over flat positions u = (seq, q) of A[u][a] * B[seq][q*s + tap*dil + off][chunk*32+cc]
 // GEMM view: M = A channels (dy), N = (tap, B channel), K = flat positions.  Block tile: 128 A channels x (KT = 5 taps
@@ -1390,71 +1271,10 @@ static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
 }
 
 
-// conv_burst: tile choice.  Candidates (couts x positions per block); the first one whose grid is ONE round (<= CU count)
-// and whose operand set fits the LDS takes the launch; larger weight tiles first (fewer re-reads of the input rows).
-struct BurstCfg { int mtw, ntw; };
-template <int MTW, int NTW>
-static int launch_burst_inst(const ConvP& p, int nr_b, size_t lds, hipStream_t st) {
-  static size_t have = 64 * 1024;
-  if (lds > have) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_burst<MTW, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return EVT_ELAUNCH;
-    have = lds;
-  }
-  evt_set_last_tag("conv_burst<bf16, %d, %d>", 32 * MTW, 32 * NTW);
-  hipLaunchKernelGGL((conv_burst<MTW, NTW>), dim3(8 * ((p.P + 7) / 8) * p.Y), dim3(256), lds, st, p, nr_b);
-  return evt_check_launch();
-}
-
-static int try_burst(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStream_t st) {
-  static const bool off = getenv("EVT_NO_BURST") != nullptr;          // A/B switch for measurements
-  if (off || nphase != 1 || p_in.s_in != 1 || p_in.Lin != p_in.Q || k_ch % 64) return EVT_ENOTSUP;
-  if (p_in.KHp > 16) return EVT_ENOTSUP;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EVT_ENOTSUP;
-    ncu = prop.multiProcessorCount;
-  }
-  const long units = (long)p_in.nseq * p_in.Q;
-  const long ktot = (long)k_ch * p_in.KHp;
-  static const BurstCfg cfgs[] = {{2, 2}, {2, 3}, {2, 4}, {1, 3}, {1, 4}, {1, 5}, {2, 5}};
-  for (const BurstCfg& c : cfgs) {
-    const int TM = 32 * c.mtw, TN = 32 * c.ntw;
-    if (out_ch % TM) continue;
-    const long P = (units + TN - 1) / TN, Y = out_ch / TM;
-    if (P * Y > ncu) continue;       // more than one round: the ring kernel overlaps blocks (grid padding exits at once)
-    const int nr_b = TN + (p_in.KHp - 1) * p_in.dil;
-    const size_t a_bytes = (size_t)TM * ktot * 2, b_bytes = (((size_t)nr_b * k_ch * 2) + 1023) / 1024 * 1024;
-    size_t lds = a_bytes + b_bytes;
-    const size_t stage = (size_t)TN * (TM * 2 + 16);
-    if (lds < stage) lds = stage;
-    if (lds > 150 * 1024) continue;
-    ConvP p = p_in;
-    p.Y = (int)Y; p.P = (int)P; p.U = 0;
-    switch (c.mtw * 10 + c.ntw) {
-      case 22: return launch_burst_inst<2, 2>(p, nr_b, lds, st);
-      case 23: return launch_burst_inst<2, 3>(p, nr_b, lds, st);
-      case 24: return launch_burst_inst<2, 4>(p, nr_b, lds, st);
-      case 25: return launch_burst_inst<2, 5>(p, nr_b, lds, st);
-      case 13: return launch_burst_inst<1, 3>(p, nr_b, lds, st);
-      case 14: return launch_burst_inst<1, 4>(p, nr_b, lds, st);
-      case 15: return launch_burst_inst<1, 5>(p, nr_b, lds, st);
-    }
-  }
-  return EVT_ENOTSUP;
-}
-
 int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStream_t st) {
   ConvP p = p_in;
   const int kind = deep_kind(p, EVT_DT_BF16, out_ch, k_ch, nphase);
   if (kind == 0) return EVT_ENOTSUP;
-  {   // a single round of blocks with a short reduction: everything in one LDS-DMA burst
-    const int rc = try_burst(p, out_ch, k_ch, nphase, st);
-    if (rc != EVT_ENOTSUP) return rc;
-  }
   if (kind == 1) {
     p.Y = out_ch / 64;
     p.P = (int)(((long)p.nseq * p.Q + 63) / 64);
