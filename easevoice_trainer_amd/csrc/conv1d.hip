@@ -1165,9 +1165,10 @@ int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c) {
   }
   // ... or the weight gradient does (A = dy [nseq][lout][cout], B = x)
   WgP w{};
-  w.nseq = c->nseq; w.KHp = c->k; w.Q = w.LA = evt_conv1d_lout(c); w.CA = c->cout; w.CB = c->cin;
+  w.nseq = c->nseq; w.KH = w.KHp = c->k; w.Q = w.LA = evt_conv1d_lout(c); w.CA = c->cout; w.CB = c->cin;
+  w.s = c->stride; w.dil = c->dil; w.LB = c->lin;
   w.a_slope = w.b_slope = 1.f;
-  return evt_conv::wgrad_deep_eligible(w, c->dtype) ? 1 : 0;
+  return (evt_conv::wgrad_deep_eligible(w, c->dtype) || evt_conv::wgrad_halo_eligible(w, c->dtype)) ? 1 : 0;
 }
 
 int evt_conv1d_layout(const evt_conv1d_params* c, evt_wlayout* o) {
@@ -1325,9 +1326,20 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
 
 int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
                           float* dbias, void* stream) {
+  return evt_conv1d_bwd_weight_parts(c, x, dy, y, dw, dbias, nullptr, stream);
+}
+
+int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
+                                float* dbias, evt_wgrad_parts* sp, void* stream) {
   int rc = valid(c);
   if (rc) return rc;
   if (!x || !dy || !dw) return EVT_EINVAL;
+  int used_host = 0;
+  if (sp) {
+    sp->used = 0;
+    if (sp->parts < 1 || !sp->used_dev || sp->prev_used < 0 || sp->prev_used > sp->parts) return EVT_EINVAL;
+    if (sp->parts > 1 && (!sp->dw_extra || sp->part_stride <= 0)) return EVT_EINVAL;
+  }
   if (c->out_act != EVT_ACT_NONE && !y) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int lout = evt_conv1d_lout(c);
@@ -1350,12 +1362,18 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
     p.LA = c->lin; p.CA = c->cin; p.LB = lout; p.CB = c->cout; p.Q = c->lin;
   }
   p.dbias = nullptr;
+  if (sp) {
+    p.dw_extra = sp->dw_extra; p.part_stride = sp->part_stride; p.parts = sp->parts; p.prev_used = sp->prev_used;
+    p.db_part = sp->db_part; p.used = sp->used_dev; p.used_host = &used_host; p.dirty0 = sp->dirty0 || sp->prev_used > 0;
+  }
   // wide layers with plain operands: LDS-DMA GEMM kernel (conv_deep.hip); its dbias comes from the column-sum kernel
   // dense layers (k = 1, long reductions): the 128 x 128 weight-gradient GEMM tile
   const bool gemm_w = igemm_path && c->impl == EVT_IMPL_AUTO && !c->transposed && evt_conv::wgrad_gemm_eligible(p, c->dtype);
-  const bool deep_w = !gemm_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
+  // stride-1 layers with 3..11 taps and long sequences: one staged window of x serves all taps (wgrad_halo.hip)
+  const bool halo_w = !gemm_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_halo_eligible(p, c->dtype);
+  const bool deep_w = !gemm_w && !halo_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_deep_eligible(p, c->dtype);
   // latency-bound mid-size layers: ring-pipelined LDS-DMA kernel (fuses dbias when A is dy)
-  const bool ring_w = !deep_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
+  const bool ring_w = !deep_w && !halo_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
   const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
   const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed) || cin1);
@@ -1414,16 +1432,17 @@ int evt_conv1d_bwd_weight(const evt_conv1d_params* c, const void* x, const void*
   }
   if (gemm_w) {
     p.dbias = fuse_bias ? dbias : nullptr;
+    p.parts = 0;                                     // no slab mode: the s1 dense layers accumulate into the arena
     return evt_conv::launch_wgrad_gemm(p, st);
   }
-  if (deep_w) {
+  if (halo_w || deep_w || ring_w) {
     p.dbias = fuse_bias ? dbias : nullptr;
-    return evt_conv::launch_wgrad_deep(p, st);
+    if (!p.dbias) p.db_part = nullptr;
+    rc = halo_w ? evt_conv::launch_wgrad_halo(p, st) : (deep_w ? evt_conv::launch_wgrad_deep(p, st) : evt_conv::launch_wgrad_ring(p, st));
+    if (sp) sp->used = used_host;
+    return rc;
   }
-  if (ring_w) {
-    p.dbias = fuse_bias ? dbias : nullptr;
-    return evt_conv::launch_wgrad_ring(p, st);
-  }
+  p.parts = 0;
   if (c->dtype == EVT_DT_BF16) {
     p.dbias = fuse_bias ? dbias : nullptr;
     rc = launch_wgrad_tr(p, st);

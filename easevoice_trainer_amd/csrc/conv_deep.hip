@@ -15,6 +15,7 @@
 // zero page.  Two LDS stages (64 KiB): the DMA of stage s+1 is issued right after the barrier that publishes stage s
 // and flies under its 32 MFMAs per wave; one barrier per stage.
 #include "conv_p.h"
+#include "wgrad_epi.h"
 #include <cstdlib>
 
 namespace evt_conv {
@@ -616,21 +617,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
       }
     }
   }
-  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
-
+  if (do_bias) wg_finish_bias(p, a0 + tid, bsum, blockIdx.y);
   // lane holds A channels g8*4..+3 (rows) x B channel j16 (column) of each tile
-#pragma unroll
-  for (int t = 0; t < WKT; ++t) {
-    if (t >= ntap) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = a0 + wr * 64 + i * 16 + g8 * 4 + r;
-        const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * 32 + wc * 16 + j16;
-        atomicAdd(p.dw + off, acc[i][t][r]);
-      }
-  }
+  wg_finish<4, WKT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, blockIdx.y);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1231,20 +1220,8 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
     }
     asm volatile("" ::: "memory");
   }
-  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
-
-#pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    if (t >= ntap) continue;
-#pragma unroll
-    for (int i = 0; i < MA; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = a0 + wr * 16 * MA + i * 16 + g8 * 4 + r;
-        const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * 32 + wc * 16 + j16;
-        atomicAdd(p.dw + off, acc[i][t][r]);
-      }
-  }
+  if (do_bias) wg_finish_bias(p, a0 + tid, bsum, blockIdx.y);
+  wg_finish<MA, KT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, blockIdx.y);
 }
 
 }  // namespace
@@ -1328,6 +1305,15 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
   return evt_check_launch();
 }
 
+void wgrad_pick_split(const WgP& p, long tiles, int nstages, long target, int min_stages, int* nsplit, int* per) {
+  long split = (target + tiles - 1) / tiles;
+  if (split > nstages / min_stages) split = nstages / min_stages;
+  if (p.parts > 0 && split > p.parts) split = p.parts;
+  if (split < 1) split = 1;
+  *per = (int)((nstages + split - 1) / split);
+  *nsplit = (nstages + *per - 1) / *per;          // every split owns at least one stage
+}
+
 bool wgrad_deep_eligible(const WgP& p, int dtype) {
   if (dtype != EVT_DT_BF16) return false;
   if (p.CA % 128 || p.CB % 32) return false;
@@ -1350,13 +1336,13 @@ int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
   p.ntapgrp = (p.KHp + WKT - 1) / WKT;
   const long tiles = (long)(p.CA / 128) * p.nchunk * p.ntapgrp;
   const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
-  // ~2 blocks per CU in flight, >= 8 K stages per block so the pipeline amortises its fill and the atomics
-  long split = (1024 + tiles - 1) / tiles;
-  if (split > nstages / 8) split = nstages / 8;
-  if (split < 1) split = 1;
-  const int per = (int)((nstages + split - 1) / split);
-  split = (nstages + per - 1) / per;
-  p.nsplit = (int)split;
+  // ~2 blocks per CU in flight, >= 8 K stages per block so the pipeline amortises its fill and the atomics; slab mode:
+  // one resident wave of blocks is enough once the tile leaves as plain stores
+  int nsplit, per;
+  wgrad_pick_split(p, tiles, nstages, p.parts > 0 ? 512 : 1024, 8, &nsplit, &per);
+  p.nsplit = nsplit;
+  p.now_used = p.prev_used > nsplit ? p.prev_used : nsplit;
+  if (p.parts > 0 && p.used_host) *p.used_host = p.now_used;
   static bool attr = false;
   const size_t lds = 2 * WSTAGE;
   if (!attr) {
@@ -1451,11 +1437,11 @@ int launch_wgrad_ring(const WgP& p_in, hipStream_t st) {
   const int MA = (tiles128 >= 128 || (tiles128 > 0 && tiles128 * (nstages / 4) >= 512)) ? 4 : 2;
   const long tiles = (long)(p.CA / (32 * MA)) * p.nchunk * p.ntapgrp;
   static const long target = getenv("EVT_RING_BLOCKS") ? atol(getenv("EVT_RING_BLOCKS")) : 256;   // tuning knob (measured: 256 best)
-  long split = (target + tiles - 1) / tiles;      // ~1 block per CU: more splits only add fp32 atomics
-  if (split > nstages / 3) split = nstages / 3;   // >= 3 K stages per block
-  if (split < 1) split = 1;
-  const int per = (int)((nstages + split - 1) / split);
-  p.nsplit = (int)((nstages + per - 1) / per);
+  int nsplit, per;                                // ~1 block per CU: more splits only add partial tiles; >= 3 K stages per block
+  wgrad_pick_split(p, tiles, nstages, target, 3, &nsplit, &per);
+  p.nsplit = nsplit;
+  p.now_used = p.prev_used > nsplit ? p.prev_used : nsplit;
+  if (p.parts > 0 && p.used_host) *p.used_host = p.now_used;
 #define RING(MA_, KT_) (MA_ == 4 && KT_ == 5 ? launch_ring_inst<MA_, KT_, 3>(p, per, st) : launch_ring_inst<MA_, KT_, 4>(p, per, st))
   if (MA == 4) return KT == 1 ? RING(4, 1) : (KT == 3 ? RING(4, 3) : RING(4, 5));
   return KT == 1 ? RING(2, 1) : (KT == 3 ? RING(2, 3) : RING(2, 5));

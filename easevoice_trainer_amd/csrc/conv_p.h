@@ -46,6 +46,17 @@ struct WgP {
   int nsplit;
   int ntapgrp;
   float* dbias;       // optional: += column sums of A_eff (only valid when A is dy)
+  // deterministic split-K (evt_conv1d_bwd_weight_parts, wgrad_epi.h); parts == 0: classic fp32 atomics into dw
+  float* dw_extra;    // slabs 1 .. parts-1 of the gradient image, part_stride floats apart (slab 0 is dw)
+  long part_stride;
+  int parts;          // slabs the caller provides = upper bound for nsplit
+  int prev_used;      // slabs already holding partial sums of this step (0: first launch); slabs >= prev_used (and the
+                      // matching rows of db_part) are stored, the others added to
+  int now_used;       // max(prev_used, nsplit): what the kernel writes to used[]
+  int dirty0;         // slab 0 already holds sums of this step (any earlier launch): add to it instead of storing
+  float* db_part;     // [parts][CA] partial bias gradients, or null (dbias then takes atomics)
+  int* used;          // device int32[2]: {slabs of dw in use, slabs of db_part in use}, written by the kernel
+  int* used_host;     // HOST int the launcher sets to now_used (0 stays for kernels without slab support)
 };
 
 // conv_deep.hip: GEMM-grade path for wide bf16 layers (K-side channels % 64 == 0, output channels % 128 == 0, no
@@ -64,6 +75,13 @@ int launch_wgrad_gemm(const WgP& p, hipStream_t st);
 // ring-pipelined variant for the latency-bound mid-size layers (A channels % 64 == 0); fuses dbias
 bool wgrad_ring_eligible(const WgP& p, int dtype);
 int launch_wgrad_ring(const WgP& p, hipStream_t st);
+// wgrad_halo.hip: stride-1 layers with 3..11 taps whose sequences are long enough for sequence-local K stages: all taps
+// of a block read ONE staged window of the shifted operand (vocoder stages, WN layers, encoder FFN); fuses dbias
+bool wgrad_halo_eligible(const WgP& p, int dtype);
+int launch_wgrad_halo(const WgP& p, hipStream_t st);
+// how the launchers split the positions: nsplit and stages per split from the stage count, the tile count and p.parts
+// (classic mode: `target` blocks; slab mode: additionally nsplit <= parts)
+void wgrad_pick_split(const WgP& p, long tiles, int nstages, long target, int min_stages, int* nsplit, int* per);
 
 // rows_gemm.hip: k = 1 layers applied to at most 16 rows in total (one vector per batch item)
 bool rows16_eligible(const struct evt_conv1d_params* c, int rows, int n_out, int k_red, bool fused);

@@ -67,6 +67,33 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* item
   }
 }
 
+// A deterministic split-K weight gradient (evt_conv1d_bwd_weight_parts) leaves its partial sums in slabs: slab 0 is the
+// image itself, slabs 1 .. n-1 are `stride` floats apart in `extra`.  This folds one d0-row of them into slab 0, in
+// index order, in place (the row belongs to this block alone).  Image order, 16 bytes per lane, eight slabs requested
+// before the first is added: the pass is a stream of n x row bytes (2.4 GB per s2 step), not a chain of dependent loads.
+__device__ __forceinline__ void fold_slabs_row(float* dw_row, const float* extra_row, long stride, int n, int row_floats) {
+  const int nv = row_floats >> 2;                  // rows are multiples of 32 floats (ck = 32) or handled by the tail loop
+  for (int v = threadIdx.x; v < nv; v += 256) {
+    f32x4 s = reinterpret_cast<const f32x4*>(dw_row)[v];
+    int k = 1;
+    for (; k + 8 <= n; k += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const f32x4*>(extra_row + (long)(k - 1 + u) * stride)[v];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < n; ++k) s += reinterpret_cast<const f32x4*>(extra_row + (long)(k - 1) * stride)[v];
+    reinterpret_cast<f32x4*>(dw_row)[v] = s;
+  }
+  for (int e = (nv << 2) + threadIdx.x; e < row_floats; e += 256) {
+    float s = dw_row[e];
+    for (int k = 1; k < n; ++k) s += extra_row[(long)(k - 1) * stride + e];
+    dw_row[e] = s;
+  }
+  __syncthreads();                                 // the row is read back below by other threads of the block
+}
+
 __global__ __launch_bounds__(256) void wn_grad_kernel(const evt_wprep_item* items, const int32_t* rows) {
   __shared__ float red[4];
   const evt_wprep_item it = items[rows[2 * blockIdx.x]];
@@ -76,6 +103,19 @@ __global__ __launch_bounds__(256) void wn_grad_kernel(const evt_wprep_item* item
   const int n = (it.src_d1 ? it.src_d1 : L.d1) * L.k;
   const float* v = it.v + (long)d0 * n;
   float* dv = it.dv + (long)d0 * n;
+  if (it.used) {
+    const int nu = it.used[0], nb = it.used[1];
+    if (nu > 1 && it.dw_extra) {
+      const int row_floats = L.reg_nchunk * L.reg_kp * L.reg_ck;
+      const long ro = (long)d0 * row_floats;
+      fold_slabs_row(const_cast<float*>(it.dw) + ro, it.dw_extra + ro, it.dw_part_stride, nu, row_floats);
+    }
+    if (nb > 0 && it.db_part && it.db && threadIdx.x == 0) {
+      float s = 0.f;
+      for (int k = 0; k < nb; ++k) s += it.db_part[(long)k * L.d0 + d0];
+      it.db[d0] += s;
+    }
+  }
   if (!it.g) {
     for (int e = threadIdx.x; e < n; e += 256) {
       const int d1 = e / L.k, kk = e - d1 * L.k;

@@ -20,13 +20,18 @@ from . import lib as L
 class ConvSlot:
     """Per-conv record inside a WeightBank: geometry + views into the prepared-weight arenas."""
 
-    __slots__ = ("module", "layout", "reg", "alt", "dw", "bank", "_pcache", "packed_member")
+    __slots__ = ("module", "layout", "reg", "alt", "dw", "bank", "_pcache", "packed_member", "parts", "dw_extra",
+                 "db_part", "used", "wg_used", "wg_dirty", "_wgp")
 
     def __init__(self, module, layout, bank):
         self.module, self.layout, self.bank = module, layout, bank
         self.reg = self.alt = self.dw = None
         self._pcache = {}
         self.packed_member = False   # True: the weight gradient of this conv is produced by a PackedConv over it
+        # deterministic split-K (evt_conv1d_bwd_weight_parts): slabs of the gradient image beyond `dw`, partial bias
+        # gradients, the device counters the kernels write, and the host's copy of the slab count of this step
+        self.parts, self.dw_extra, self.db_part, self.used, self.wg_used, self._wgp = 1, None, None, None, 0, None
+        self.wg_dirty = False        # a weight-gradient launch of this step has written into `dw` already
 
     def params(self, nseq, lin, in_slope, out_act, out_slope):
         key = (nseq, lin, in_slope, out_act, out_slope, self.bank.impl)
@@ -186,11 +191,38 @@ class WeightBank:
                     mm._slot.packed_member = True
         self.reg_arena = torch.zeros(max(reg_n, 1), dtype=dtype, device=device)
         self.alt_arena = torch.zeros(max(alt_n, 1), dtype=dtype, device=device)
-        self.dw_arena = torch.zeros(max(reg_n, 1), dtype=torch.float32, device=device)
-        for s, (ro, ao) in zip(self.slots, offs):
+        # slab 0 of every gradient image + the kernels' slab counters (two int32 per conv): ONE memset per step clears both
+        ns = len(self.slots)
+        self.dw_arena = torch.zeros(max(reg_n, 1) + 2 * ns, dtype=torch.float32, device=device)
+        self.used_all = self.dw_arena[max(reg_n, 1):].view(torch.int32)
+        # slabs 1.. (EVT_WGRAD_PARTS=0 switches the deterministic split off: fp32 atomics into the one image as before).
+        # A small image can afford many slabs (the reduction of a 128 -> 128 k11 vocoder layer runs over 40960 positions
+        # for 180 K outputs: 32 splits); a 21 MB image (1024 -> 1024 k5) gets 3.  Never zeroed: a slab is stored before it
+        # is read, the counters say how many are valid.
+        self.parts_on = (dtype == torch.bfloat16 and self.device.type == "cuda"
+                         and os.environ.get("EVT_WGRAD_PARTS", "1") != "0")
+        budget = int(os.environ.get("EVT_WGRAD_SLAB_MB", "48")) << 20
+        cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "32"))      # measured (s2 step, ms): 32: 26.2, 64: 26.5, 128: 26.5; off: 27.2
+        ex_n = db_n = 0
+        ex_offs = []
+        for s in self.slots:
+            nb = s.layout.reg_elems * 4
+            s.parts = max(1, min(cap, -(-budget // max(nb, 1)))) if self.parts_on else 1
+            ex_offs.append((ex_n, db_n))
+            ex_n += (s.parts - 1) * ((s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN)
+            db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)
+        self.dw_extra_arena = torch.empty(max(ex_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
+        self.db_part_arena = torch.empty(max(db_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
+        for i, (s, (ro, ao)) in enumerate(zip(self.slots, offs)):
             s.reg = self.reg_arena[ro: ro + s.layout.reg_elems]
             s.alt = self.alt_arena[ao: ao + s.layout.alt_elems]
             s.dw = self.dw_arena[ro: ro + s.layout.reg_elems]
+            s.used = self.used_all[2 * i: 2 * i + 2]
+            if self.parts_on:
+                eo, do = ex_offs[i]
+                stride = (s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN
+                s.dw_extra = self.dw_extra_arena[eo: eo + (s.parts - 1) * stride]
+                s.db_part = self.db_part_arena[do: do + s.parts * s.layout.d0]
         self._items = self._rows = None
         self._nrows = 0
 
@@ -219,6 +251,15 @@ class WeightBank:
             it.lay = s.layout
             it.dtype = self.dt
             it.src_d1 = int(getattr(m, "src_d1", 0))
+            if self.parts_on and not s.packed_member:
+                it.dw_extra = s.dw_extra.data_ptr() if s.parts > 1 else None
+                it.dw_part_stride = (s.layout.reg_elems + 127) // 128 * 128
+                it.used = s.used.data_ptr()
+                bias = getattr(m, "bias", None)
+                if bias is not None and not m.transposed:      # fused bias gradients exist for plain convolutions only
+                    if bias.grad is None:
+                        bias.grad = torch.zeros_like(bias)
+                    it.db_part, it.db = s.db_part.data_ptr(), bias.grad.data_ptr()
             items.append(it)
             rows.extend((i, r) for r in range(s.layout.d0))
         self._items = L.struct_to_device(items, self.device)
@@ -233,7 +274,9 @@ class WeightBank:
                 "evt_wn_fold_multi")
 
     def zero_dw(self):
-        self.dw_arena.zero_()
+        self.dw_arena.zero_()            # slab 0 of every image and the slab counters
+        for s in self.slots:
+            s.wg_used, s.wg_dirty = 0, False
 
     def side_stream(self):
         if self._side is None:
@@ -462,8 +505,25 @@ def _bwd_weight_now(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
             m.bias.grad = torch.zeros_like(m.bias)
         dbias = m.bias.grad
     e0 = _t0()
-    L.check(L.lib().evt_conv1d_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(y if out_act != L.ACT_NONE else None),
-                                          L.ptr(slot.dw), L.ptr(dbias), L.stream_ptr()), "evt_conv1d_bwd_weight")
+    if slot.bank.parts_on:
+        sp = slot._wgp
+        if sp is None:
+            sp = slot._wgp = L.WgradParts()
+            sp.dw_extra = slot.dw_extra.data_ptr() if slot.parts > 1 else None
+            sp.part_stride = (slot.layout.reg_elems + 127) // 128 * 128
+            sp.db_part = slot.db_part.data_ptr() if (dbias is not None and not m.transposed) else None
+            sp.used_dev = slot.used.data_ptr()
+            sp.parts = slot.parts
+        sp.prev_used, sp.dirty0 = slot.wg_used, int(slot.wg_dirty)
+        L.check(L.lib().evt_conv1d_bwd_weight_parts(C.byref(p), L.ptr(x), L.ptr(dy),
+                                                    L.ptr(y if out_act != L.ACT_NONE else None), L.ptr(slot.dw),
+                                                    L.ptr(dbias), C.byref(sp), L.stream_ptr()),
+                "evt_conv1d_bwd_weight_parts")
+        slot.wg_used, slot.wg_dirty = max(slot.wg_used, int(sp.used)), True
+    else:
+        L.check(L.lib().evt_conv1d_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy),
+                                              L.ptr(y if out_act != L.ACT_NONE else None), L.ptr(slot.dw), L.ptr(dbias),
+                                              L.stream_ptr()), "evt_conv1d_bwd_weight")
     if e0 is not None:
         _t1(e0, "bwd_weight", m, nseq, lin, dy.numel() if out_act != L.ACT_NONE else 0)
 

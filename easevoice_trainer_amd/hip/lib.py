@@ -49,7 +49,14 @@ class WPrepItem(C.Structure):
         ("v", C.c_void_p), ("g", C.c_void_p), ("reg", C.c_void_p), ("alt", C.c_void_p),
         ("dw", C.c_void_p), ("dv", C.c_void_p), ("dg", C.c_void_p),
         ("lay", WLayout), ("dtype", C.c_int32), ("src_d1", C.c_int32),
+        ("dw_extra", C.c_void_p), ("dw_part_stride", C.c_int64), ("db_part", C.c_void_p), ("db", C.c_void_p),
+        ("used", C.c_void_p),
     ]
+
+
+class WgradParts(C.Structure):
+    _fields_ = [("dw_extra", C.c_void_p), ("part_stride", C.c_int64), ("db_part", C.c_void_p), ("used_dev", C.c_void_p),
+                ("parts", C.c_int32), ("prev_used", C.c_int32), ("used", C.c_int32), ("dirty0", C.c_int32)]
 
 
 class Seg(C.Structure):

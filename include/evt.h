@@ -123,6 +123,13 @@ typedef struct evt_wprep_item {
   int32_t dtype;
   int32_t src_d1;   /* 0, or the parameter's own d1 when lay.d1 was padded up (enc_q.pre: 1025 spectrogram bins in an image
                      * of 1088 columns); v / dv rows then hold src_d1 * k values, the image's extra columns stay zero */
+  /* slabs of a deterministic split-K weight gradient (evt_conv1d_bwd_weight_parts); all NULL / 0 without them */
+  const float* dw_extra;   /* slabs 1.. of the gradient image, dw_part_stride floats apart (slab 0 is dw) */
+  int64_t dw_part_stride;
+  const float* db_part;    /* [slab][d0] partial bias gradients or NULL */
+  float* db;               /* [d0] fp32 bias gradient, += sum of the db_part slabs in use */
+  const int32_t* used;     /* DEVICE int32[2] = {slabs of dw in use (0 or 1: dw only), slabs of db_part in use}: written
+                            * by the weight-gradient kernels, reset to 0 by the caller together with dw */
 } evt_wprep_item;
 /* items is a DEVICE pointer to n items; row_index is a DEVICE int32 [nrows][2] table of
  * (item, d0-row) pairs, one workgroup each. */
@@ -144,6 +151,30 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* p, const void* dy, const void* 
 /* dW(REG geometry, fp32) += ..., dbias[cout] += sum(dy * act_out'(y)); dbias may be NULL. */
 int evt_conv1d_bwd_weight(const evt_conv1d_params* p, const void* x, const void* dy, const void* y,
                           float* dw, float* dbias, void* stream);
+
+/* The same gradient with a DETERMINISTIC split over the positions.  The MFMA weight-gradient kernels split the
+ * reduction over several blocks per output tile; evt_conv1d_bwd_weight combines their partial tiles with fp32 atomics
+ * (sum order = finishing order of the blocks: last bits differ from run to run, and every partial tile crosses the
+ * fabric as atomic packets).  Here split s owns SLAB s of the gradient image -- slab 0 is `dw` itself, slabs
+ * 1 .. parts-1 are dw_extra + (s-1) * part_stride -- and writes it with plain stores: added to slabs that already hold sums of this
+ * step (slab 0 when dirty0, slabs below prev_used), stored to the others.  The fused bias gradient goes to db_part[s][cout] the same way (when db_part is NULL: atomics into
+ * dbias as before).  evt_wn_grad_multi adds the slabs in index order.  The kernel records the slab counts in
+ * used_dev[0..1]; `used` returns the count on the host for the next launch's prev_used.  used == 0 on return: the
+ * kernel that handled this shape has no slab mode and accumulated into dw / dbias the classic way.
+ * torch.autograd accumulates weight gradients in one fixed order per op; this restores that property. */
+typedef struct evt_wgrad_parts {
+  float* dw_extra;
+  int64_t part_stride;   /* floats */
+  float* db_part;
+  int32_t* used_dev;
+  int32_t parts;         /* slabs provided (>= 1) = upper bound of the split */
+  int32_t prev_used;     /* in: slabs already holding partial sums since the last reset (0: none) */
+  int32_t used;          /* out */
+  int32_t dirty0;        /* in: 1 when slab 0 (dw) may already hold sums of this step -- an earlier launch of any kind since
+                          * the caller zeroed it -- and has to be added to; 0: slab 0 is stored like the others (no read) */
+} evt_wgrad_parts;
+int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* p, const void* x, const void* dy, const void* y,
+                                float* dw, float* dbias, evt_wgrad_parts* sp, void* stream);
 
 /* One HiFi-GAN ResBlock1 step  y = x + c2(lrelu(c1(lrelu(x), dilation d)))  (modules.py:299-308 of the reference; both
  * convolutions C -> C, kernel k, "same" padding, c2 undilated) as ONE launch for the narrow vocoder stages: bf16,

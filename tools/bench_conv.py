@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--wonly", action="store_true", help="time the weight gradient only")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -43,6 +44,8 @@ def main():
     for C_, Lx in [(256, 320), (128, 2560), (64, 5120), (32, 10240), (16, 20480)]:
         for k, d in [(3, 1), (7, 3), (11, 5), (11, 1)]:
             shapes.append((f"res C{C_} L{Lx} k{k} d{d}", B, Lx, C_, C_, k, 1, (k * d - d) // 2, d, 1, False, 0.1, 0))
+            # the same layer as ResUnitFn runs it: operands activated by the neighbouring epilogues, plain here
+            shapes.append((f"plain C{C_} L{Lx} k{k} d{d}", B, Lx, C_, C_, k, 1, (k * d - d) // 2, d, 1, False, 1.0, 0))
     ups = [(512, 256, 16, 10, 3, 32), (256, 128, 16, 8, 4, 320), (128, 64, 8, 2, 3, 2560), (64, 32, 2, 2, 0, 5120),
            (32, 16, 2, 2, 0, 10240)]
     for ci, co, k, u, p, Lx in ups:
@@ -81,6 +84,7 @@ def main():
     bank = HC.WeightBank(mods, dtype, dev, impl=a.impl)
     bank.build_tables()
     bank.async_wgrad = False      # per-call timings below are taken on the current stream
+    bank.defer_n = 0
     bank.fold()
     torch.cuda.synchronize()
     rows = []
@@ -93,12 +97,17 @@ def main():
         lout = y.size(1)
         macs = nseq * (lout if not tr else Lx) * ci * co * k / g
         bytes_act = (x.numel() + y.numel()) * sz
-        t_f = time_fn(lambda: HC._fwd(slot, x, None, slope, oact, 0.1), iters=a.iters)
+        t_f = 1e9 if a.wonly else time_fn(lambda: HC._fwd(slot, x, None, slope, oact, 0.1), iters=a.iters)
         boact, by = oact, y
         if oact and L.lib().evt_conv1d_wants_plain_dy(C.byref(slot.params(nseq, Lx, slope, oact, 0.1))):
             boact, by = 0, None        # the autograd node pre-multiplies dy by the activation derivative (evt_dact_mul)
-        t_d = time_fn(lambda: HC._bwd_data(slot, dy, by, x, None, nseq, Lx, slope, boact, 0.1), iters=a.iters)
-        t_w = time_fn(lambda: HC._bwd_weight(slot, x, dy, by, nseq, Lx, slope, boact, 0.1), iters=a.iters)
+        t_d = 1e9 if a.wonly else time_fn(lambda: HC._bwd_data(slot, dy, by, x, None, nseq, Lx, slope, boact, 0.1), iters=a.iters)
+
+        def wg():
+            slot.wg_used, slot.wg_dirty = 0, False          # as in a step: the first (only) launch into this convolution's slabs
+            HC._bwd_weight(slot, x, dy, by, nseq, Lx, slope, boact, 0.1)
+
+        t_w = time_fn(wg, iters=a.iters)
         row = dict(name=name, gmac=macs / 1e9, fwd_ms=t_f, bwdd_ms=t_d, bwdw_ms=t_w,
                    fwd_tflops=2 * macs / t_f / 1e9, bwdd_tflops=2 * macs / t_d / 1e9, bwdw_tflops=2 * macs / t_w / 1e9,
                    fwd_gbs=bytes_act / t_f / 1e6)
