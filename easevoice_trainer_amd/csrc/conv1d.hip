@@ -33,9 +33,9 @@ extern "C" int evt_small_kind(const evt_conv1d_params* c);
 extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
                              void* stream);
 extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
-                                    void* stream);
+                                    float* ws, long ws_floats, void* stream);
 extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
-                                   float* dbias, void* stream);
+                                   float* dbias, float* ws, long ws_floats, void* stream);
 extern "C" int evt_cin1_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
                             void* stream);
 extern "C" int evt_cin1_bwd_data(const evt_conv1d_params* c, const void* dy, const void* y, const void* w_reg,
@@ -667,7 +667,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 256 / TA; ++r) sum += bred[r * TA + tid];
-      atomicAdd(p.dbias + a0 + tid, sum);
+      if (p.ws) p.ws[(long)p.nsplit * ((long)p.CA * p.nchunk * p.KHp * CK) + (long)blockIdx.y * p.CA + a0 + tid] = sum;
+      else atomicAdd(p.dbias + a0 + tid, sum);
     }
   }
   if (NPS > 1) {
@@ -702,7 +703,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       for (int r = 0; r < 4; ++r) {
         const int a = a0 + ct * 16 + g8 * 4 + r;
         const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * CK + j * 16 + j16;
-        atomicAdd(p.dw + off, acc[t][j][r]);
+        // scratch row of this position split (fold.hip adds the rows in order), or one atomic per split and address
+        if (p.ws) p.ws[(long)blockIdx.y * ((long)p.CA * p.nchunk * p.KHp * CK) + off] = acc[t][j][r];
+        else atomicAdd(p.dw + off, acc[t][j][r]);
       }
     }
   }
@@ -713,11 +716,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
 // channel and block.  Requires C % V == 0 and C / V <= 256.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_act2(const T* dy, const T* ys, float* out, long rows, int C, int kind,
-                                                   float slope, int rows_per_block) {
-  __shared__ float acc[2048];
+                                                   float slope, int rows_per_block, float* ws) {
+  __shared__ float acc[2048];                 // [rows_par][C]: rows_par * C = (256 / ppr) * ppr * V <= 2048
   constexpr int V = 16 / sizeof(T);
-  for (int c = threadIdx.x; c < C; c += 256) acc[c] = 0.f;
-  __syncthreads();
   const int ppr = C / V;
   const int rows_par = 256 / ppr;
   const int piece = threadIdx.x % ppr, rsub = threadIdx.x / ppr;
@@ -742,10 +743,16 @@ __global__ __launch_bounds__(256) void colsum_act2(const T* dy, const T* ys, flo
       }
     }
 #pragma unroll
-    for (int e = 0; e < V; ++e) atomicAdd(&acc[piece * V + e], a[e]);
+    for (int e = 0; e < V; ++e) acc[rsub * C + piece * V + e] = a[e];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(out + c, acc[c]);
+  // the row lanes are added in lane order; the block's sums go to a scratch row (fold.hip) or, without one, to atomics
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = acc[c];
+    for (int l = 1; l < rows_par; ++l) v += acc[l * C + c];
+    if (ws) ws[(long)blockIdx.x * C + c] = v;
+    else atomicAdd(out + c, v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(256) void conv_naive_bwd_weight(NvP p) {
 // dbias[c] += sum over rows of dy * act'(y); [rows][C] channels-last
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_act(const T* dy, const T* ys, float* out, long rows, int C, int kind,
-                                                  float slope, int rows_per_block) {
+                                                  float slope, int rows_per_block, float* ws) {
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -908,7 +915,8 @@ __global__ __launch_bounds__(256) void colsum_act(const T* dy, const T* ys, floa
       if (ys) d *= dact_from_out(kind, to_f<T>(ys[r * C + c]), slope);
       acc += d;
     }
-    atomicAdd(out + c, acc);
+    if (ws) ws[(long)blockIdx.x * C + c] = acc;
+    else atomicAdd(out + c, acc);
   }
 }
 
@@ -1061,7 +1069,12 @@ int launch_wgrad_tr_inst(const WgP& p, hipStream_t st) {
   const int gx = (p.CA / TA) * p.nchunk * p.ntapgrp;
   evt_set_last_tag("conv_wgrad_tr<%d, %d>", CK, TA);
   hipLaunchKernelGGL((conv_wgrad_tr<CK, TA>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
-  return evt_check_launch();
+  int rc = evt_check_launch();
+  if (rc || !p.ws) return rc;
+  const long img = (long)p.CA * p.nchunk * p.KHp * CK;
+  rc = evt_conv::launch_fold_partials(p.ws, img, p.nsplit, p.dw, img, st);
+  if (rc || !p.dbias) return rc;
+  return evt_conv::launch_fold_partials(p.ws + (long)p.nsplit * img, p.CA, p.nsplit, p.dbias, p.CA, st);
 }
 
 // bf16 only; returns ENOTSUP when the tile does not fit so the caller can use the gather kernel
@@ -1079,6 +1092,14 @@ int launch_wgrad_tr(WgP p, hipStream_t st) {
   if (split > 256) split = 256;
   if (split > iters) split = iters;
   if (split < 1) split = 1;
+  if (p.ws) {
+    // every split stores a partial image (+ bias row); rows of one block's tile that it does not own stay unwritten,
+    // so all (tile, split) blocks must exist: split <= iters holds above
+    const long row = (long)p.CA * p.nchunk * p.KHp * CK + p.CA;
+    if (row * split > p.ws_floats) split = p.ws_floats / row;
+    if (split < 2) p.ws = nullptr;                 // nothing to fold: accumulate directly
+    if (split < 1) split = 1;
+  }
   p.nsplit = (int)split;
   if (CK == 32) {
     if (TA == 64) return launch_wgrad_tr_inst<32, 64>(p, st);
@@ -1339,6 +1360,7 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
     sp->used = 0;
     if (sp->parts < 1 || !sp->used_dev || sp->prev_used < 0 || sp->prev_used > sp->parts) return EVT_EINVAL;
     if (sp->parts > 1 && (!sp->dw_extra || sp->part_stride <= 0)) return EVT_EINVAL;
+    if (sp->ws && sp->ws_floats <= 0) return EVT_EINVAL;
   }
   if (c->out_act != EVT_ACT_NONE && !y) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1377,39 +1399,49 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
   const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
   const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed) || cin1);
+  float* ws = sp ? sp->ws : nullptr;
+  const long ws_floats = sp ? (long)sp->ws_floats : 0;
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
     const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+    int blocks;
+    float* wsb = nullptr;
     if (c->cout % V == 0 && c->cout / V <= 256) {
-      long rpb = (rows + 255) / 256;   // <= 256 blocks: every block ends with one global atomic per channel
+      long rpb = (rows + 255) / 256;   // <= 256 blocks: every block ends with one partial sum per channel
       if (rpb < 16) rpb = 16;
-      const int blocks = (int)((rows + rpb - 1) / rpb);
+      blocks = (int)((rows + rpb - 1) / rpb);
+      if (ws && blocks >= 2 && (long)blocks * c->cout <= ws_floats) wsb = ws;
       if (c->dtype == EVT_DT_BF16)
         hipLaunchKernelGGL(colsum_act2<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
-                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb);
+                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb, wsb);
       else
         hipLaunchKernelGGL(colsum_act2<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
-                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb);
+                           dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb, wsb);
     } else {
       const int rpb = 64;
-      const int blocks = (int)((rows + rpb - 1) / rpb);
+      blocks = (int)((rows + rpb - 1) / rpb);
+      if (ws && blocks >= 2 && (long)blocks * c->cout <= ws_floats) wsb = ws;
       if (c->dtype == EVT_DT_BF16)
         hipLaunchKernelGGL(colsum_act<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
-                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
+                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb, wsb);
       else
         hipLaunchKernelGGL(colsum_act<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
-                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb);
+                           dbias, rows, c->cout, c->out_act, c->out_slope, rpb, wsb);
     }
     rc = evt_check_launch();
     if (rc) return rc;
+    if (wsb) {
+      rc = evt_conv::launch_fold_partials(wsb, c->cout, blocks, dbias, c->cout, st);
+      if (rc) return rc;
+    }
   }
   evt_set_last_tag("conv_naive_bwd_weight");
   if (grouped) {
     evt_set_last_tag("grouped_bwd_weight");
     return evt_grouped_bwd_weight(c, x, dy, y, dw, stream);
   }
-  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, stream);
-  if (cin1) return evt_cin1_bwd_weight(c, x, dy, y, dw, dbias, stream);
+  if (c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 1) return evt_cout1_bwd_weight(c, x, dy, y, dw, ws, ws_floats, stream);
+  if (cin1) return evt_cin1_bwd_weight(c, x, dy, y, dw, dbias, ws, ws_floats, stream);
   const bool use_igemm = igemm_path;
   if (c->impl == EVT_IMPL_IGEMM && !use_igemm) return EVT_ENOTSUP;
   if (!use_igemm) {
@@ -1445,12 +1477,13 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
   p.parts = 0;
   if (c->dtype == EVT_DT_BF16) {
     p.dbias = fuse_bias ? dbias : nullptr;
+    p.ws = ws; p.ws_floats = ws_floats;
     rc = launch_wgrad_tr(p, st);
     if (rc != EVT_ENOTSUP) return rc;
     if (fuse_bias) {  // tile did not fit: the gather kernel has no fused bias
       const long rows = (long)c->nseq * lout;
       hipLaunchKernelGGL(colsum_act<bf16_t>, dim3((int)((rows + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,
-                         (const bf16_t*)ysv, dbias, rows, c->cout, c->out_act, c->out_slope, 64);
+                         (const bf16_t*)ysv, dbias, rows, c->cout, c->out_act, c->out_slope, 64, (float*)nullptr);
       rc = evt_check_launch();
       if (rc) return rc;
     }

@@ -57,6 +57,9 @@ struct WgP {
   float* db_part;     // [parts][CA] partial bias gradients, or null (dbias then takes atomics)
   int* used;          // device int32[2]: {slabs of dw in use, slabs of db_part in use}, written by the kernel
   int* used_host;     // HOST int the launcher sets to now_used (0 stays for kernels without slab support)
+  // scratch for the kernels that finish their reduction with a second launch (fold.hip); null: fp32 atomics
+  float* ws;
+  long ws_floats;
 };
 
 // conv_deep.hip: GEMM-grade path for wide bf16 layers (K-side channels % 64 == 0, output channels % 128 == 0, no
@@ -79,6 +82,8 @@ int launch_wgrad_ring(const WgP& p, hipStream_t st);
 // of a block read ONE staged window of the shifted operand (vocoder stages, WN layers, encoder FFN); fuses dbias
 bool wgrad_halo_eligible(const WgP& p, int dtype);
 int launch_wgrad_halo(const WgP& p, hipStream_t st);
+// fold.hip: out[e] += sum over b < nb of part[b * stride + e], e < n, rows added in a fixed order
+int launch_fold_partials(const float* part, long stride, int nb, float* out, long n, hipStream_t st);
 // how the launchers split the positions: nsplit and stages per split from the stage count, the tile count and p.parts
 // (classic mode: `target` blocks; slab mode: additionally nsplit <= parts)
 void wgrad_pick_split(const WgP& p, long tiles, int nstages, long target, int min_stages, int* nsplit, int* per);

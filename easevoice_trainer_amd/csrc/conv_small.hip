@@ -8,6 +8,7 @@
 // HBM-bound byte work: coalesced 16-byte reads, LDS only for the small weight vector / block reduction.
 #include "evt_common.h"
 #include "../../include/evt.h"
+#include "conv_p.h"
 
 namespace {
 
@@ -18,6 +19,8 @@ struct SP {
   float in_slope; int out_act; float out_slope;
   int G;                // lanes per output (power of two <= 64)
   int pos_per_block;
+  float* ws;            // scratch rows for the per-block partial results (fold.hip), or null: fp32 atomics
+  long ws_row;          // floats per scratch row
 };
 
 __device__ __forceinline__ long sreg_index(const SP& p, int d0, int d1, int t) {
@@ -80,15 +83,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
   constexpr int V = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);   // [k*cin]
+  float* red = reinterpret_cast<float*>(smem);   // [npl][k*cin]
   const int ppr = p.cin / V;
   const int pieces = p.k * ppr;
   int pp = 1;
   while (pp < pieces && pp < 256) pp <<= 1;       // pieces padded to a power of two (<= 256)
   const int npl = 256 / pp;                        // positions processed in parallel
   const int pl = threadIdx.x / pp, pc0 = threadIdx.x % pp;
-  for (int i = threadIdx.x; i < p.k * p.cin; i += 256) red[i] = 0.f;
-  __syncthreads();
   constexpr int NA = 4;   // k*cin <= 4096 (evt_small_kind) -> at most 1024 pieces -> 4 per thread
   float acc[NA][V];
 #pragma unroll
@@ -131,19 +132,25 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight(SP p) {
         for (int e = 0; e < V; ++e) acc[a][e] += d[u] * lrelu_f(to_f<T>(pv[e]), p.in_slope);
       }
   }
+  // the npl position lanes of the block meet in LDS and are added in lane order (LDS atomics would add them in arrival
+  // order: last bits that change from run to run)
+  const int kc = p.k * p.cin;
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     const int pc = pc0 + a * pp;
     if (pc < pieces) {
       const int t = pc / ppr, c0 = (pc - t * ppr) * V;
 #pragma unroll
-      for (int e = 0; e < V; ++e) atomicAdd(&red[t * p.cin + c0 + e], acc[a][e]);
+      for (int e = 0; e < V; ++e) red[pl * kc + t * p.cin + c0 + e] = acc[a][e];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < p.k * p.cin; i += 256) {
+  for (int i = threadIdx.x; i < kc; i += 256) {
     const int t = i / p.cin, c = i - t * p.cin;
-    atomicAdd(p.dw + sreg_index(p, 0, c, t), red[i]);
+    float v = red[i];
+    for (int l = 1; l < npl; ++l) v += red[l * kc + i];
+    if (p.ws) p.ws[(long)blockIdx.x * p.ws_row + sreg_index(p, 0, c, t)] = v;
+    else atomicAdd(p.dw + sreg_index(p, 0, c, t), v);
   }
 }
 
@@ -333,8 +340,14 @@ __global__ __launch_bounds__(256) void cin1_bwd_weight(SP p, float* dbias) {
       acc += a0 + a1;
     }
   }
-  if (role == 0) atomicAdd(p.dw + sreg_index(p, co, 0, t), acc);
-  else if (role == 1 && dbias) atomicAdd(dbias + co, acc);
+  if (p.ws) {
+    // scratch row = [the dW image | cout bias sums]
+    if (role == 0) p.ws[(long)blockIdx.x * p.ws_row + sreg_index(p, co, 0, t)] = acc;
+    else if (role == 1) p.ws[(long)blockIdx.x * p.ws_row + (p.ws_row - p.cout) + co] = acc;
+  } else {
+    if (role == 0) atomicAdd(p.dw + sreg_index(p, co, 0, t), acc);
+    else if (role == 1 && dbias) atomicAdd(dbias + co, acc);
+  }
 }
 
 // ---- Cout == 1 backward-data: dx[i][c] = sum_t dy_eff[(i + pad - t*dil)/s] * w[t][c]; thread = 16 bytes of dx ---------
@@ -432,35 +445,75 @@ extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const vo
 }
 
 extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
-                                    void* stream) {
+                                    float* ws, long ws_floats, void* stream) {
   SP p = make_sp(c);
   p.x = x; p.dy = dy; p.y_in = c->out_act != EVT_ACT_NONE ? y : nullptr; p.dw = dw;
   const long total = (long)p.nseq * p.lout;
-  long ppb = (total + 255) / 256;   // ~256 blocks: enough loads in flight, a bounded number of atomics per dW element
+  long ppb = (total + 255) / 256;   // ~256 blocks: enough loads in flight, a bounded number of partial results
   if (ppb < 16) ppb = 16;
+  const long img = (long)p.nchunk * p.kp * p.ck;          // d0 = 1: one row of the image
+  if (ws && img * 2 <= ws_floats) {
+    // partial rows instead of atomics: the block count is no longer bounded by same-address atomics, and the loop is
+    // latency-bound (a trip = 4 positions per lane) -- four times the blocks, a quarter of the trips
+    ppb = (total + 1023) / 1024;
+    if (ppb < 16) ppb = 16;
+    const long maxb = ws_floats / img;
+    if ((total + ppb - 1) / ppb > maxb) ppb = (total + maxb - 1) / maxb;
+    p.ws = ws; p.ws_row = img;
+  }
   p.pos_per_block = (int)ppb;
   const int blocks = (int)((total + ppb - 1) / ppb);
-  const size_t lds = (size_t)c->k * c->cin * sizeof(float);
+  const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+  int pp = 1;
+  while (pp < c->k * (c->cin / V) && pp < 256) pp <<= 1;
+  const size_t lds = (size_t)(256 / pp) * c->k * c->cin * sizeof(float);    // one partial per position lane
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cout1_bwd_weight");
   if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(cout1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p);
-  return evt_check_launch();
+  int rc = evt_check_launch();
+  if (rc || !p.ws) return rc;
+  // the image's padded entries (kp > k, ck > cin) are never written by the blocks: only the k * cin live ones are folded
+  // -- they are contiguous per (chunk, tap) run of ck floats, and for the shapes evt_small_kind admits (cin % 8 == 0) the
+  // image has no padding at all (ck divides cin, kp == k for ck == 32, even-padded for ck == 16)
+  if (img != (long)c->k * c->cin) {
+    // padded taps: fold run by run
+    for (int chk = 0; chk < p.nchunk && !rc; ++chk)
+      rc = evt_conv::launch_fold_partials(p.ws + (long)chk * p.kp * p.ck, img, blocks, dw + (long)chk * p.kp * p.ck,
+                                          (long)c->k * p.ck, st);
+    return rc;
+  }
+  return evt_conv::launch_fold_partials(p.ws, img, blocks, dw, img, st);
 }
 
 extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, const void* dy, const void* y, float* dw,
-                                   float* dbias, void* stream) {
+                                   float* dbias, float* ws, long ws_floats, void* stream) {
   SP p = make_sp(c);
   p.x = x; p.dy = dy; p.y_in = c->out_act != EVT_ACT_NONE ? y : nullptr; p.dw = dw;
   const long ntiles = (long)p.nseq * ((p.lout + C1_TQ - 1) / C1_TQ);
-  const int blocks = (int)(ntiles < 512 ? ntiles : 512);   // <= 512 atomics per dW element
+  int blocks = (int)(ntiles < 512 ? ntiles : 512);   // <= 512 partial results per dW element
+  // cin = 1: the image is [cout][1][kp][1]; a scratch row holds it and the bias sums
+  const long img = (long)p.cout * p.nchunk * p.kp * p.ck;
+  const long row = img + p.cout;
+  if (ws && blocks >= 2 && row * 2 <= ws_floats) {
+    if (row * blocks > ws_floats) blocks = (int)(ws_floats / row);
+    p.ws = ws; p.ws_row = row;
+  }
   const int seg = (C1_TQ - 1) * c->stride + (c->k - 1) * c->dil + 1;
   const size_t lds = ((size_t)C1_TQ * c->cout + seg) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cin1_bwd_weight");
   if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cin1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p, dbias);
   else hipLaunchKernelGGL(cin1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p, dbias);
-  return evt_check_launch();
+  int rc = evt_check_launch();
+  if (rc || !p.ws) return rc;
+  // live entries: taps t < k of every output channel (kp may be padded): fold the whole image when it has no padding
+  if (p.kp == c->k) rc = evt_conv::launch_fold_partials(p.ws, row, blocks, dw, img, st);
+  else
+    for (int co = 0; co < p.cout && !rc; ++co)
+      rc = evt_conv::launch_fold_partials(p.ws + (long)co * p.kp, row, blocks, dw + (long)co * p.kp, c->k, st);
+  if (rc || !dbias) return rc;
+  return evt_conv::launch_fold_partials(p.ws + img, row, blocks, dbias, p.cout, st);
 }
 
 extern "C" int evt_cin1_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,

@@ -211,6 +211,8 @@ class WeightBank:
             ex_offs.append((ex_n, db_n))
             ex_n += (s.parts - 1) * ((s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN)
             db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)
+        # scratch of the two-launch reductions (evt_wgrad_parts.ws): one buffer per stream the weight gradients run on
+        self._ws = {}
         self.dw_extra_arena = torch.empty(max(ex_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
         self.db_part_arena = torch.empty(max(db_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
         for i, (s, (ro, ao)) in enumerate(zip(self.slots, offs)):
@@ -277,6 +279,14 @@ class WeightBank:
         self.dw_arena.zero_()            # slab 0 of every image and the slab counters
         for s in self.slots:
             s.wg_used, s.wg_dirty = 0, False
+
+    def scratch(self):
+        """16 MiB of scratch for the current stream (created on first use)"""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.empty(4 << 20, dtype=torch.float32, device=self.device)
+        return ws
 
     def side_stream(self):
         if self._side is None:
@@ -515,6 +525,8 @@ def _bwd_weight_now(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
             sp.used_dev = slot.used.data_ptr()
             sp.parts = slot.parts
         sp.prev_used, sp.dirty0 = slot.wg_used, int(slot.wg_dirty)
+        ws = slot.bank.scratch()
+        sp.ws, sp.ws_floats = ws.data_ptr(), ws.numel()
         L.check(L.lib().evt_conv1d_bwd_weight_parts(C.byref(p), L.ptr(x), L.ptr(dy),
                                                     L.ptr(y if out_act != L.ACT_NONE else None), L.ptr(slot.dw),
                                                     L.ptr(dbias), C.byref(sp), L.stream_ptr()),

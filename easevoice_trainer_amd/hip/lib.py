@@ -56,7 +56,8 @@ class WPrepItem(C.Structure):
 
 class WgradParts(C.Structure):
     _fields_ = [("dw_extra", C.c_void_p), ("part_stride", C.c_int64), ("db_part", C.c_void_p), ("used_dev", C.c_void_p),
-                ("parts", C.c_int32), ("prev_used", C.c_int32), ("used", C.c_int32), ("dirty0", C.c_int32)]
+                ("parts", C.c_int32), ("prev_used", C.c_int32), ("used", C.c_int32), ("dirty0", C.c_int32),
+                ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
 
 
 class Seg(C.Structure):

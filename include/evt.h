@@ -172,6 +172,12 @@ typedef struct evt_wgrad_parts {
   int32_t used;          /* out */
   int32_t dirty0;        /* in: 1 when slab 0 (dw) may already hold sums of this step -- an earlier launch of any kind since
                           * the caller zeroed it -- and has to be added to; 0: slab 0 is stored like the others (no read) */
+  float* ws;             /* scratch (or NULL) for the kernels whose result is tiny -- the Cout = 1 / Cin = 1 layers, the 16-
+                          * and 32-channel vocoder stages: their blocks store partial results here and a second launch adds
+                          * them into dw / dbias in a fixed order, instead of one fp32 atomic per block and address.  Any
+                          * size >= 1 MiB helps (the kernels bound their block count by it); contents need not survive
+                          * the call; one buffer per stream. */
+  int64_t ws_floats;
 } evt_wgrad_parts;
 int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* p, const void* x, const void* dy, const void* y,
                                 float* dw, float* dbias, evt_wgrad_parts* sp, void* stream);

@@ -333,8 +333,13 @@ def test_wgrad_slabs_are_deterministic(gpu, ci):
 
 
 @pytest.mark.parametrize("case", [(512, 1024, 5, 3, 2, 1, 1, False, True, 225, 40), (1024, 1024, 5, 1, 2, 1, 1, False, True, 37, 90),
-                                  (192, 384, 1, 1, 0, 1, 1, False, True, 200, 16), (128, 64, 5, 3, 2, 1, 1, False, True, 310, 24)],
-                         ids=["deep_s3", "deep_short", "ring_k1", "ring_s3"])
+                                  (192, 384, 1, 1, 0, 1, 1, False, True, 200, 16), (128, 64, 5, 3, 2, 1, 1, False, True, 310, 24),
+                                  # the two-launch reductions (scratch rows + fold.hip)
+                                  (16, 16, 11, 1, 25, 5, 1, False, True, 2100, 8), (32, 32, 7, 1, 9, 3, 1, False, True, 1500, 8),
+                                  (16, 1, 7, 1, 3, 1, 1, False, True, 3000, 4), (1024, 1, 3, 1, 1, 1, 1, False, True, 127, 24),
+                                  (1, 32, 5, 3, 2, 1, 1, False, True, 3000, 12), (1, 16, 15, 1, 7, 1, 1, False, True, 2000, 6)],
+                         ids=["deep_s3", "deep_short", "ring_k1", "ring_s3", "narrow16", "narrow32", "cout1_16", "cout1_1024",
+                              "cin1_32", "cin1_16"])
 def test_wgrad_deep_ring_slabs_are_deterministic(gpu, case):
     a, b, twice = _wgrad_twice(gpu, case, {"EVT_WGRAD_PARTS": "1"})
     c = _wgrad_twice(gpu, case, {"EVT_WGRAD_PARTS": "0"})[0]
