@@ -20,6 +20,7 @@
 #include "evt_common.h"
 #include "../../include/evt.h"
 #include "conv_p.h"
+#include "wgrad_epi.h"
 
 extern "C" int evt_grouped_supported(const evt_conv1d_params* c);
 extern "C" int evt_grouped_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg, const float* bias, void* y,
@@ -667,10 +668,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 256 / TA; ++r) sum += bred[r * TA + tid];
-      if (p.ws) p.ws[(long)p.nsplit * ((long)p.CA * p.nchunk * p.KHp * CK) + (long)blockIdx.y * p.CA + a0 + tid] = sum;
+      if (p.parts > 0) evt_conv::wg_finish_bias(p, a0 + tid, sum, blockIdx.y);
+      else if (p.ws) p.ws[(long)p.nsplit * ((long)p.CA * p.nchunk * p.KHp * CK) + (long)blockIdx.y * p.CA + a0 + tid] = sum;
       else atomicAdd(p.dbias + a0 + tid, sum);
     }
   }
+  if (p.parts > 0 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.used[0] = p.now_used;
   if (NPS > 1) {
     // sum the position-slice waves inside the block first: 1/NPS of the global atomics
     float* red = reinterpret_cast<float*>(smem);
@@ -703,8 +706,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
       for (int r = 0; r < 4; ++r) {
         const int a = a0 + ct * 16 + g8 * 4 + r;
         const long off = (((long)a * p.nchunk + ch) * p.KHp + t0 + t) * CK + j * 16 + j16;
-        // scratch row of this position split (fold.hip adds the rows in order), or one atomic per split and address
-        if (p.ws) p.ws[(long)blockIdx.y * ((long)p.CA * p.nchunk * p.KHp * CK) + off] = acc[t][j][r];
+        // slab of this position split (evt_wn_grad_multi adds the slabs in order), or a scratch row (fold.hip does), or
+        // one atomic per split and address
+        if (p.parts > 0) {
+          float* d = evt_conv::wg_slab(p, blockIdx.y) + off;
+          const bool add = blockIdx.y == 0 ? p.dirty0 != 0 : (int)blockIdx.y < p.prev_used;
+          *d = add ? *d + acc[t][j][r] : acc[t][j][r];
+        } else if (p.ws) p.ws[(long)blockIdx.y * ((long)p.CA * p.nchunk * p.KHp * CK) + off] = acc[t][j][r];
         else atomicAdd(p.dw + off, acc[t][j][r]);
       }
     }
@@ -1070,7 +1078,7 @@ int launch_wgrad_tr_inst(const WgP& p, hipStream_t st) {
   evt_set_last_tag("conv_wgrad_tr<%d, %d>", CK, TA);
   hipLaunchKernelGGL((conv_wgrad_tr<CK, TA>), dim3(gx, p.nsplit), dim3(256), lds, st, p);
   int rc = evt_check_launch();
-  if (rc || !p.ws) return rc;
+  if (rc || !p.ws || p.parts > 0) return rc;
   const long img = (long)p.CA * p.nchunk * p.KHp * CK;
   rc = evt_conv::launch_fold_partials(p.ws, img, p.nsplit, p.dw, img, st);
   if (rc || !p.dbias) return rc;
@@ -1092,7 +1100,18 @@ int launch_wgrad_tr(WgP p, hipStream_t st) {
   if (split > 256) split = 256;
   if (split > iters) split = iters;
   if (split < 1) split = 1;
-  if (p.ws) {
+  // slab mode only when the caller's slabs cover the split this kernel wants (it is latency-bound: fewer, longer blocks
+  // cost more than the second launch of the scratch-row mode saves -- measured: 28 -> 64 us on the 32 -> 128 k5 s3 layer
+  // with 32 slabs instead of 192 splits)
+  if (p.parts > 0 && split > p.parts) p.parts = 0;
+  if (p.parts > 0) {
+    // one slab per split (the caller sizes them by image: up to 256 for the 11 - 45 KB images of the narrow vocoder
+    // stages); no second launch
+    p.nsplit = (int)split;
+    p.now_used = p.prev_used > p.nsplit ? p.prev_used : p.nsplit;
+    if (p.used_host) *p.used_host = p.now_used;
+    if (!p.dbias) p.db_part = nullptr;
+  } else if (p.ws) {
     // every split stores a partial image (+ bias row); rows of one block's tile that it does not own stay unwritten,
     // so all (tile, split) blocks must exist: split <= iters holds above
     const long row = (long)p.CA * p.nchunk * p.KHp * CK + p.CA;
@@ -1474,12 +1493,14 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
     if (sp) sp->used = used_host;
     return rc;
   }
-  p.parts = 0;
   if (c->dtype == EVT_DT_BF16) {
     p.dbias = fuse_bias ? dbias : nullptr;
     p.ws = ws; p.ws_floats = ws_floats;
+    if (p.parts < 2) p.parts = 0;                  // one slab = no split possible: scratch rows (or atomics) instead
     rc = launch_wgrad_tr(p, st);
+    if (sp && rc != EVT_ENOTSUP) sp->used = used_host;
     if (rc != EVT_ENOTSUP) return rc;
+    p.parts = 0;
     if (fuse_bias) {  // tile did not fit: the gather kernel has no fused bias
       const long rows = (long)c->nseq * lout;
       hipLaunchKernelGGL(colsum_act<bf16_t>, dim3((int)((rows + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,

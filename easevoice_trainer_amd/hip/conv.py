@@ -207,7 +207,9 @@ class WeightBank:
         ex_offs = []
         for s in self.slots:
             nb = s.layout.reg_elems * 4
-            s.parts = max(1, min(cap, -(-budget // max(nb, 1)))) if self.parts_on else 1
+            # images of a few KB (the 16- / 32-channel vocoder stages: 11 - 45 KB for 160 K - 330 K positions) take as many
+            # slabs as their kernel has position splits
+            s.parts = max(1, min(cap if nb > (64 << 10) else 256, -(-budget // max(nb, 1)))) if self.parts_on else 1
             ex_offs.append((ex_n, db_n))
             ex_n += (s.parts - 1) * ((s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN)
             db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)
