@@ -676,6 +676,7 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         self.freeze_quantizer = freeze_quantizer
         self.split_backward = False      # set by a data-parallel S2Engine (see forward)
         self._cut = None
+        self._cut2 = None
 
     def _rvq(self):
         """the fp32 images + launches of the frozen quantizer path (hip/frontend.py::RvqEncoder), built on first use"""
@@ -759,16 +760,27 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
             eps_cl = eps.transpose(1, 2) if eps is not None else None
             ym = y_mask.to(self.cd)      # 0/1 mask in the compute dtype: the WN stacks stay in one dtype (no cast kernels)
-            z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge, eps=eps_cl, lens=lens32)
-            z_p = self.flow(z, ym, g=ge, lens=lens32)
+            split = self.split_backward and torch.is_grad_enabled()
+            ge_fq = ge
+            if split:
+                # second cut of the data-parallel step (see below): posterior encoder and flow hang on their own copy of
+                # the style vector and on detached prior statistics, so their backward ends at these leaves -- their
+                # gradient ranges are complete, and can be reduced, before the prior encoder's backward has started
+                ge_fq = ge.detach().requires_grad_(True)
+                m_p_cut, logs_p_cut = m_p.detach().requires_grad_(True), logs_p.detach().requires_grad_(True)
+                self._cut2 = ((ge, ge_fq), (m_p, m_p_cut), (logs_p, logs_p_cut))
+                m_p, logs_p = m_p_cut, logs_p_cut
+            z, m_q, logs_q = self.enc_q(y_cl, ym, g=ge_fq, eps=eps_cl, lens=lens32)
+            z_p = self.flow(z, ym, g=ge_fq, lens=lens32)
             if ids_slice is None:
                 z_slice, ids_slice = commons.rand_slice_segments(z, y_lengths, self.segment_size)
             else:
                 z_slice = commons.slice_segments(z, ids_slice, self.segment_size)
-            if self.split_backward and torch.is_grad_enabled():
+            if split:
                 # data-parallel step: the autograd graph is cut at the vocoder's inputs, so that the engine can run the
                 # backward of `dec` (and of the discriminators above it) first, start reducing those gradients, and
-                # continue into flow / encoders from the saved cut gradients (train/s2_engine.py)
+                # continue into flow / posterior encoder, then prior / style encoder, from the saved cut gradients
+                # (train/s2_engine.py)
                 z_cut, ge_cut = z_slice.detach().requires_grad_(True), ge.detach().requires_grad_(True)
                 self._cut = ((z_slice, z_cut), (ge, ge_cut))
                 o = self.dec(z_cut, g=ge_cut)

@@ -66,10 +66,18 @@ class S2Engine:
             # out of the early range: its input gradient continues into the style encoder, it is reduced with the rest.
             self._dec_convs = [m for n, m in self.net_g.dec.named_modules() if hasattr(m, "_slot")]
             self._dec_range = self.rt_g.arena.range_of_prefix("dec.", stop_before="dec.cond.")
+            # flow + posterior encoder (adjacent in the arena, convolutions only): complete after the first part of the
+            # generator's remaining backward, reduced under the prior / style encoders' backward
+            self._fq_convs = [m for sub in (self.net_g.flow, self.net_g.enc_q) for m in sub.modules() if hasattr(m, "_slot")]
+            flo, fhi = self.rt_g.arena.range_of_prefix("flow.")
+            qlo, qhi = self.rt_g.arena.range_of_prefix("enc_q.")
+            if fhi != qlo and qhi != flo:
+                raise L.EvtError("data-parallel overlap: flow and enc_q are expected to be adjacent in the gradient arena")
+            self._fq_range = (min(flo, qlo), max(fhi, qhi))
             # a range is reduced as soon as its convolutions' gradients are finished; a parameter whose gradient only
             # arrives with the final gather (an autograd-owned one) must not sit inside such a range -- it would be
             # reduced before it was written: silent gradient loss under data parallelism
-            early = [(self._dec_range, self.rt_g)] + [(r, self.rt_d) for r in self._d_ranges]
+            early = [(self._dec_range, self.rt_g), (self._fq_range, self.rt_g)] + [(r, self.rt_d) for r in self._d_ranges]
             for (lo, hi), rt in early:
                 for p_, view in rt._free:
                     off = (view.data_ptr() - rt.arena.grad.data_ptr()) // 4
@@ -202,14 +210,37 @@ class S2Engine:
         st.g_done = [self.rt_g.finish_conv_grads(self._dec_convs)]
 
     def _phase_b1(self, st):
-        """the rest of the generator's backward: KL term + the gradients saved at the cut -> flow, encoders"""
+        """the generator's backward below the vocoder, first part: KL term + the gradient saved at the vocoder's input
+        -> flow, posterior encoder (both end at the second cut: their own copy of the style vector, detached prior
+        statistics)"""
+        z_full, z_cut = self.net_g._cut[0]
         roots, grads = [st.loss_kl + st.kl_ssl * 1], [None]
-        for full, cut in self.net_g._cut:
-            if cut.grad is not None:
-                roots.append(full)
-                grads.append(cut.grad)
+        if z_cut.grad is not None:
+            roots.append(z_full)
+            grads.append(z_cut.grad)
         torch.autograd.backward(roots, grads)
-        self.net_g._cut = None
+        st.g_done.append(self.rt_g.finish_conv_grads(self._fq_convs))
+
+    def _phase_b2(self, st):
+        """second part: the gradients that arrived at the cuts -> prior encoder (m_p, logs_p) and style encoder (the style
+        vector as the vocoder, the flow and the posterior encoder used it)"""
+        (ge, ge_dec), = self.net_g._cut[1:]
+        (ge2, ge_fq), (m_p, m_p_cut), (logs_p, logs_p_cut) = self.net_g._cut2
+        roots, grads = [], []
+        gsum = None
+        for leaf in (ge_dec, ge_fq):
+            if leaf.grad is not None:
+                gsum = leaf.grad if gsum is None else gsum + leaf.grad
+        if gsum is not None:
+            roots.append(ge)
+            grads.append(gsum)
+        for full, leaf in ((m_p, m_p_cut), (logs_p, logs_p_cut)):
+            if leaf.grad is not None:
+                roots.append(full)
+                grads.append(leaf.grad)
+        if roots:
+            torch.autograd.backward(roots, grads)
+        self.net_g._cut = self.net_g._cut2 = None
         self.rt_g.finish_grads(done=st.g_done)
 
     def _reduce_async(self, flat, lo, hi):
@@ -235,13 +266,20 @@ class S2Engine:
         dlo, dhi = self._dec_range
         prog.append((self._phase_b0, lambda: self._reduce_async(gg, dlo, dhi)))
 
-        def after_b1():
-            if dlo > 0:
-                self._reduce_async(gg, 0, dlo)
-            if dhi < gg.numel():
-                self._reduce_async(gg, dhi, gg.numel())
+        flo, fhi = self._fq_range
+        prog.append((self._phase_b1, lambda: self._reduce_async(gg, flo, fhi)))
+
+        def after_b2():
+            # what is left: everything outside the two early ranges (prior / style encoders, dec.cond)
+            at = 0
+            for lo, hi in sorted([(dlo, dhi), (flo, fhi)]):
+                if lo > at:
+                    self._reduce_async(gg, at, lo)
+                at = hi
+            if at < gg.numel():
+                self._reduce_async(gg, at, gg.numel())
             red.wait()
-        prog.append((self._phase_b1, after_b1))
+        prog.append((self._phase_b2, after_b2))
         prog.append((self._phase_c, None))
         return prog
 

@@ -375,8 +375,9 @@ def test_weight_bank_row_ranges_cpu():
 
 
 def test_s2_data_parallel_program_plumbing_cpu():
-    """The data-parallel s2 step's bookkeeping without launching anything (train/s2_engine.py::_program): ten pieces
-    (D forward, six per-sub-discriminator backward pieces, two generator backward pieces, the G optimiser); the
+    """The data-parallel s2 step's bookkeeping without launching anything (train/s2_engine.py::_program): eleven pieces
+    (D forward, six per-sub-discriminator backward pieces, three generator backward pieces -- through D and the vocoder,
+    flow + posterior encoder, prior + style encoder --, the G optimiser); the
     sub-discriminators' arena ranges tile the discriminator arena and their weight-gradient row ranges tile the bank's row
     table; the vocoder's range and rows are contiguous, exclude its conditioning layer's parameters and leave two rest
     ranges; the generator is switched to the cut backward.  (The arithmetic of the overlapped step is checked on the GPU:
@@ -391,7 +392,7 @@ def test_s2_data_parallel_program_plumbing_cpu():
     eng = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
     assert eng.overlap and eng.net_g.split_backward
     prog = eng._program()
-    assert len(prog) == 10 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
+    assert len(prog) == 11 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
     # discriminator: ranges tile the arena in order, row ranges tile the row table
     d = eng.rt_d.arena
     at = 0
@@ -410,6 +411,17 @@ def test_s2_data_parallel_program_plumbing_cpu():
     assert 0 < lo < hi < g.numel
     rlo, rhi = eng.rt_g.bank.rows_of(eng._dec_convs)
     assert 0 < rlo < rhi <= eng.rt_g.bank._nrows
+    # flow + posterior encoder: one range holding exactly their parameters, disjoint from the vocoder's, one contiguous
+    # run of weight-gradient rows; what is left for the last reduction are the prior / style encoders and dec.cond
+    flo, fhi = eng._fq_range
+    fq = [n for n in g.names if flo <= g.offsets[n] < fhi]
+    assert fq and all(n.startswith(("flow.", "enc_q.")) for n in fq)
+    assert len(fq) == sum(1 for n in g.names if n.startswith(("flow.", "enc_q.")))
+    assert fhi <= lo or flo >= hi
+    qlo, qhi = eng.rt_g.bank.rows_of(eng._fq_convs)
+    assert qhi > qlo and (qhi <= rlo or qlo >= rhi)
+    rest = [n for n in g.names if not (lo <= g.offsets[n] < hi or flo <= g.offsets[n] < fhi)]
+    assert rest and all(n.startswith(("enc_p.", "ref_enc.", "dec.cond.", "ssl_proj.", "quantizer.")) for n in rest), rest[:5]
     # the attention layers' projections are adjacent in the generator's arena (what the packed projection needs)
     o = g.offsets
     pre = "enc_p.encoder_ssl.attn_layers.0."
