@@ -66,8 +66,11 @@ __device__ __forceinline__ bf16x8 tr_join(const TrPair& p) {
 // and the MFMAs depend on its outputs
 __device__ __forceinline__ void tr_tie(TrPair& p) { asm volatile("" : "+v"(p.lo), "+v"(p.hi)); }
 
+// A-tile swizzle by row width: 256-byte rows (MA = 4), 128-byte rows (MA = 2) as in wgrad_ring; 64-byte rows (MA = 1: a
+// 32-channel dy tile has the geometry of the window) as the window
 template <int MA> __device__ __forceinline__ int a_swz(int row) {
-  return MA == 4 ? 2 * ((row & 3) | (((row >> 3) & 1) << 2)) : 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+  return MA == 4 ? 2 * ((row & 3) | (((row >> 3) & 1) << 2))
+                 : (MA == 2 ? 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) : 2 * ((row >> 3) & 1));
 }
 
 constexpr int HPOS = 64;                       // positions per K stage
@@ -247,7 +250,7 @@ bool wgrad_halo_eligible(const WgP& p, int dtype) {
   if (off || dtype != EVT_DT_BF16) return false;
   if (p.s != 1 || p.KHp != p.KH) return false;
   if (p.KH != 3 && p.KH != 5 && p.KH != 7 && p.KH != 11) return false;
-  if (p.CA % 64 || p.CB % 32) return false;
+  if ((p.CA % 64 && p.CA != 32) || p.CB % 32) return false;
   if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
   if (p.LA != p.Q) return false;
   if (HPOS + (p.KH - 1) * p.dil > HROWS) return false;
@@ -258,7 +261,8 @@ bool wgrad_halo_eligible(const WgP& p, int dtype) {
   // 64-channel tile here is bound by its LDS reads (52 transpose reads per 44 MFMAs).  So: 64 dy channels only
   // (EVT_HALO_ALL=1 lifts that for measurements).
   static const bool all = getenv("EVT_HALO_ALL") != nullptr;
-  if (!all && p.CA != 64) return false;
+  static const bool no32 = getenv("EVT_HALO_NO32") != nullptr;
+  if (!all && p.CA != 64 && !(p.CA == 32 && !no32)) return false;
   if (p.CA % 128 == 0 && (long)(p.CA / 128) * (p.CB / 32) >= 128) return false;
   // sequence-local stages: the tail stage of a sequence is partly zero rows; DiscriminatorP's 23..127-long sequences
   // stay on the flat-position kernels
@@ -280,6 +284,7 @@ int launch_wgrad_halo(const WgP& p_in, hipStream_t st) {
   static const int force_ma = getenv("EVT_HALO_MA") ? atoi(getenv("EVT_HALO_MA")) : 0;
   int MA = tiles128 >= 64 ? 4 : 2;
   if (force_ma == 2 || (force_ma == 4 && tiles128 > 0)) MA = force_ma;
+  if (p.CA == 32) MA = 1;                        // the 32-channel vocoder stage: one tile, all the parallelism from the split
   const long tiles = (long)(p.CA / (32 * MA)) * p.nchunk;
   static const long target = getenv("EVT_HALO_BLOCKS") ? atol(getenv("EVT_HALO_BLOCKS")) : 256;
   int nsplit, per;
@@ -291,7 +296,7 @@ int launch_wgrad_halo(const WgP& p_in, hipStream_t st) {
   (p.KH == 3 ? launch_inst<MA_, 3, NS_>(p, spq, per, st)                                                 \
              : p.KH == 5 ? launch_inst<MA_, 5, NS_>(p, spq, per, st)                                     \
                          : p.KH == 7 ? launch_inst<MA_, 7, NS_>(p, spq, per, st) : launch_inst<MA_, 11, NS_>(p, spq, per, st))
-  return MA == 4 ? HALO(4, 3) : HALO(2, 4);
+  return MA == 4 ? HALO(4, 3) : (MA == 2 ? HALO(2, 4) : HALO(1, 4));
 #undef HALO
 }
 
