@@ -2,7 +2,7 @@
 # The round's closing GPU visit: whole -m gpu suite, the driver's bench line, rocprofv3 kernel stats of both steps,
 # HBM traffic counters (two PMC passes), per-shape conv table, attention kernel timings + MFMA/VALU counters.
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r02z}
+O=gpurun_out/${1:-r03z}
 mkdir -p $O
 t0=$(date +%s)
 timeout 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$? $(( $(date +%s)-t0 ))s" > $O/times.txt
@@ -20,11 +20,10 @@ F=$(find $O/p3 -name '*counter_collection.csv' | head -1); W=$(find $O/p4 -name 
 if [ -n "$F" ] && [ -n "$W" ]; then timeout 60 python tools/pmc_traffic.py $F $W > $O/pmc_traffic.json 2> $O/pmc_traffic.err; fi
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/p5 -- python tools/bench_attn.py --iters 2 > $O/p5.log 2>&1
 A=$(find $O/p5 -name '*counter_collection.csv' | head -1)
-if [ -n "$A" ]; then timeout 60 python tools/pmc_summary.py $A attn_ > $O/attn_pmc.txt 2>&1; fi
+if [ -n "$A" ]; then timeout 60 python tools/pmc_summary.py $A attn_ --json $O/attn_pmc.json > $O/attn_pmc.txt 2>&1; fi
 rm -rf $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
 timeout 200 python tools/trace_shapes.py --top 400 > $O/conv_time_by_shape.txt 2>&1
 timeout 100 python tools/bench_attn.py > $O/bench_attn_b32.json 2>/dev/null
-timeout 100 python tools/bench_attn.py --batch 16 > $O/bench_attn_b16.json 2>/dev/null
-timeout 100 python tools/bench_resunit.py > $O/bench_resunit.txt 2>&1
+timeout 100 python tools/bench_conv.py --wonly --only "plain C,dP,dS 1024,WN in,FFN 192->768 k3 T200" --iters 20 > $O/bench_wgrad.txt 2>&1
 echo "all $(( $(date +%s)-t0 ))s" >> $O/times.txt
 cat $O/times.txt; head -c 600 $O/bench_line.json; echo; cat $O/pmc_traffic.json | head -20
