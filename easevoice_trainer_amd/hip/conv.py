@@ -209,7 +209,11 @@ class WeightBank:
             nb = s.layout.reg_elems * 4
             # images of a few KB (the 16- / 32-channel vocoder stages: 11 - 45 KB for 160 K - 330 K positions) take as many
             # slabs as their kernel has position splits
-            s.parts = max(1, min(cap if nb > (64 << 10) else 256, -(-budget // max(nb, 1)))) if self.parts_on else 1
+            # ... and so do the layers with at most 64 output channels: one or two output tiles, every block beyond that is a
+            # position split (64 -> 64 k11 over 81920 positions, in the step: 66 us with 32 slabs, 29 us with 128)
+            few_tiles = s.layout.d0 <= 64
+            s.parts = max(1, min(256 if nb <= (64 << 10) else (128 if few_tiles else cap),
+                                 -(-budget // max(nb, 1)))) if self.parts_on else 1
             ex_offs.append((ex_n, db_n))
             ex_n += (s.parts - 1) * ((s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN)
             db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)
