@@ -54,7 +54,7 @@ def main():
             gui = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
             if not gui:
                 continue
-            m = re.search(r"(attn_\w+|mha_\w+|gemm256_\w+|\w+)", k.split("(")[0].split("::")[-1])
+            m = re.search(r"((?:attn|mha|gemm256|conv|wgrad)_\w+(?:<[^>]*>)?)", k)
             name = m.group(1) if m else k
             res[name] = dict(dispatches=len(disp[k]),
                              mfma_util=v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024),
