@@ -138,6 +138,19 @@ class PackedConv:
         return lin
 
 
+def slab_count(image_bytes, d0, budget=48 << 20, cap=32):
+    """slabs of one convolution's gradient image for the deterministic split-K weight gradient (= the most position splits
+    its kernel may use).  A small image can afford many (the reduction of a 128 -> 128 k11 vocoder layer runs over 40960
+    positions for 180 K outputs); a 21 MB image (1024 -> 1024 k5) gets 3.  `cap` (32; measured on the s2 step: 26.2 ms,
+    64: 26.5, 8: 30.9, 2: 52) bounds what evt_wn_grad_multi has to fold per image; two kinds of layer go beyond it, because
+    all their parallelism comes from the split: images of a few KB (the 16- / 32-channel vocoder stages: 11 - 45 KB for
+    160 K - 330 K positions) and layers with at most 64 output channels (one or two output tiles: 64 -> 64 k11 over 81920
+    positions, in the step: 66 us with 32 slabs, 23 us with 128).  The s2 generator's slabs come to 5.2 GB, the
+    discriminators' to 0.7 GB, of the 288 GB."""
+    limit = 256 if image_bytes <= (64 << 10) else (128 if d0 <= 64 else cap)
+    return max(1, min(limit, -(-budget // max(image_bytes, 1))))
+
+
 class WeightBank:
     """All prepared conv weights of one model: REG/ALT images in the compute dtype, fp32 dW images,
     and the device tables for the two multi-tensor launches (fold before forward, grad after backward)."""
@@ -195,25 +208,17 @@ class WeightBank:
         ns = len(self.slots)
         self.dw_arena = torch.zeros(max(reg_n, 1) + 2 * ns, dtype=torch.float32, device=device)
         self.used_all = self.dw_arena[max(reg_n, 1):].view(torch.int32)
-        # slabs 1.. (EVT_WGRAD_PARTS=0 switches the deterministic split off: fp32 atomics into the one image as before).
-        # A small image can afford many slabs (the reduction of a 128 -> 128 k11 vocoder layer runs over 40960 positions
-        # for 180 K outputs: 32 splits); a 21 MB image (1024 -> 1024 k5) gets 3.  Never zeroed: a slab is stored before it
-        # is read, the counters say how many are valid.
+        # slabs 1.. (EVT_WGRAD_PARTS=0 switches the deterministic split off: fp32 atomics into the one image as before);
+        # how many per image: slab_count().  Never zeroed: a slab is stored before it is read, the counters say how many
+        # are valid.
         self.parts_on = (dtype == torch.bfloat16 and self.device.type == "cuda"
                          and os.environ.get("EVT_WGRAD_PARTS", "1") != "0")
         budget = int(os.environ.get("EVT_WGRAD_SLAB_MB", "48")) << 20
-        cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "32"))      # measured (s2 step, ms): 32: 26.2, 64: 26.5, 128: 26.5; off: 27.2
+        cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "32"))
         ex_n = db_n = 0
         ex_offs = []
         for s in self.slots:
-            nb = s.layout.reg_elems * 4
-            # images of a few KB (the 16- / 32-channel vocoder stages: 11 - 45 KB for 160 K - 330 K positions) take as many
-            # slabs as their kernel has position splits
-            # ... and so do the layers with at most 64 output channels: one or two output tiles, every block beyond that is a
-            # position split (64 -> 64 k11 over 81920 positions, in the step: 66 us with 32 slabs, 29 us with 128)
-            few_tiles = s.layout.d0 <= 64
-            s.parts = max(1, min(256 if nb <= (64 << 10) else (128 if few_tiles else cap),
-                                 -(-budget // max(nb, 1)))) if self.parts_on else 1
+            s.parts = slab_count(s.layout.reg_elems * 4, s.layout.d0, budget, cap) if self.parts_on else 1
             ex_offs.append((ex_n, db_n))
             ex_n += (s.parts - 1) * ((s.layout.reg_elems + ALIGN - 1) // ALIGN * ALIGN)
             db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)

@@ -533,3 +533,17 @@ def test_reduce_scatter_all_gather_equals_all_reduce():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root,
                        env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_slab_count_policy():
+    """slabs per gradient image (hip/conv.py::slab_count): bounded by the memory budget, by the fold cap for ordinary
+    layers, lifted for the layers whose parallelism is all position split"""
+    from easevoice_trainer_amd.hip.conv import slab_count
+
+    assert slab_count(1024 * 1024 * 5 * 4, 1024) == 3            # 21 MB image: budget-bound
+    assert slab_count(128 * 128 * 11 * 4, 128) == 32             # vocoder C = 128: the cap
+    assert slab_count(64 * 64 * 11 * 4, 64) == 128               # at most 64 output channels: one or two output tiles
+    assert slab_count(16 * 16 * 12 * 4, 16) == 256               # a few KB: as many slabs as the kernel has splits
+    assert slab_count(32 * 32 * 11 * 4, 32) == 256
+    assert slab_count(0, 1) == 256 and slab_count(1 << 30, 512) == 1
+    assert slab_count(128 * 128 * 11 * 4, 128, cap=8) == 8 and slab_count(4 << 20, 512, budget=8 << 20) == 2
