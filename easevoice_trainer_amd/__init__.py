@@ -6,7 +6,7 @@ DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- ROCm 7.2's graph executor pre-records the AQ
 capture").  In graphs of a few thousand nodes that optimisation loses the ordering between a memset node and the kernel
 node behind it on replays after the first: ATen's multi-block reductions (which zero their semaphores with a
 hipMemsetAsync node) then return stale results -- the cause of round 1's NaN losses under graph replay of the s2 step.
-Measured with a torch-only reproducer (tools/debug_graph_reduce2.py, 600 reductions in one graph: 134 wrong results per
+Measured with a torch-only reproducer (tools/repro_graph_packet_capture.py, 600 reductions in one graph: 134 wrong results per
 replay with the default, 0 with the switch off).  `hip_graphs_safe()` tells the engines whether the switch took effect;
 they refuse to capture otherwise and keep launching eagerly.
 """
