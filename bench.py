@@ -85,7 +85,7 @@ def run_s2(args, world, rank, local):
     use_graphs = bool(getattr(args, "graphs", 0))
     if use_graphs:
         # fixed-shape batches: after two eager steps the step is captured once and replayed as HIP graphs (three on one GPU;
-        # ten smaller ones with the collectives between them when data-parallel)
+        # eleven smaller ones with the collectives between them when data-parallel)
         eng.enable_graphs(warmup_steps=2)
     B, T, t_text = args.batch, args.clip_seconds * 50, 60
     wav, ssl, text, lengths, tl = synth_s2_batch(B, T, t_text, dev, 1234 + rank)
@@ -155,7 +155,12 @@ def main():
     res = None
     if args.workload in ("both", "s2"):
         res, eng, step_fn = run_s2(args, world, rank, local)
-        if not args.no_extras:
+        if world > 1:
+            # the roofline / cpu_baseline legs are single-GPU properties and run extra, individually timed steps; with
+            # several ranks a leg that fails on ONE rank would leave the others waiting in a collective -- they are
+            # reported by the N = 1 run only
+            res["roofline_note"] = "kernel roofline and cpu_baseline are reported by the N = 1 run"
+        elif not args.no_extras:
             try:
                 from tools import bench_extras
 
@@ -168,7 +173,7 @@ def main():
         from tools import bench_s1
 
         try:
-            s1 = bench_s1.run(args, world, rank, local, extras=not args.no_extras)
+            s1 = bench_s1.run(args, world, rank, local, extras=not args.no_extras and world == 1)
         except Exception as e:
             if res is None:
                 raise
