@@ -33,7 +33,8 @@ class LayerNorm(nn.Module):
 class PointwiseEvtConv(EvtConv1d):
     """the same nn.Conv1d(cin, cout, 1) parameters (`weight` [cout, cin, 1], `bias`) on the fused HIP conv path: a
     3200-row x 192..768-column GEMM is launch/latency-bound, the ring-pipelined k = 1 conv does it in ~10 us and its
-    weight-gradient launch also produces the bias gradient (a dense-layer call through torch takes three launches for that: data gradient, weight gradient, column sum)."""
+    weight-gradient launch also produces the bias gradient (a dense-layer call through torch takes three launches for
+    that: data gradient, weight gradient, column sum)."""
 
     def __init__(self, cin, cout, kdims=1, weight_norm=False):
         super().__init__(cin, cout, 1, kdims=kdims, weight_norm=weight_norm)
