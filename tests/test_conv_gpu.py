@@ -240,6 +240,8 @@ HALO_CASES = [
     (192, 768, 3, 1, 1, 1, 1, False, False, 200, 16),      # FFN
     (768, 192, 3, 1, 1, 1, 1, False, False, 200, 16),
     (512, 256, 7, 1, 3, 1, 1, False, True, 128, 12),       # 128-channel tiles (EVT_HALO_MA=4 forces them elsewhere)
+    (32, 32, 11, 1, 25, 5, 1, False, True, 1536, 6),       # 32 dy channels: the A tile has the window's geometry
+    (64, 32, 7, 1, 3, 1, 1, False, True, 1000, 4),
 ]
 
 
@@ -259,15 +261,20 @@ def test_wgrad_halo_all_shapes_in_child_process(gpu):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("ci", range(len(HALO_CASES)))
-def test_wgrad_halo_parity(gpu, ci):
+def _halo_case_ids():
+    """the cases the dispatcher sends to wgrad_halo in this process: 64 (and 32) dy channels, all of them under
+    EVT_HALO_ALL=1 (the child process of the test above)"""
     import os
 
+    every = os.environ.get("EVT_HALO_ALL") is not None
+    return [i for i, c in enumerate(HALO_CASES) if every or c[1] in (32, 64)]
+
+
+@pytest.mark.parametrize("ci", _halo_case_ids())
+def test_wgrad_halo_parity(gpu, ci):
     from easevoice_trainer_amd.hip import conv as HC
 
     case = HALO_CASES[ci]
-    if case[1] != 64 and os.environ.get("EVT_HALO_ALL") is None:
-        pytest.skip("dispatched to wgrad_deep / wgrad_ring (covered in the EVT_HALO_ALL child process)")
     for fusion in (FUSIONS[0], FUSIONS[2]):
         HC.set_trace([])
         try:
