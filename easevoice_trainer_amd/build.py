@@ -1,8 +1,12 @@
 """Builds libevt_hip.so (all csrc/*.hip, gfx950 only) in-tree with hipcc.
 
-Incremental: an object is rebuilt only when its source (or a header) is newer.  hipcc cross-compiles
-without a GPU, so this runs in the build container; the .so travels to the GPU box with the tree.
+Incremental by CONTENT: an object is rebuilt when the hash of its source, the headers and the flags differs from the one
+recorded next to it (mtimes say nothing after a checkout).  hipcc cross-compiles without a GPU, so this runs in the build
+container; the .so travels to the GPU box with the tree.  The hash of all sources is compiled into evt_version(), and
+hip/lib.py compares it with the sources it finds at load time: a stale library is an error, not a silent old kernel.
+Only the entry points declared in include/evt.h are exported (-fvisibility=hidden + the header's visibility pragma).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,35 +17,61 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libevt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
 EXTRA_FLAGS = {}   # per-file flags (none at present)
+VERSION_SRC = "elementwise.hip"   # defines evt_version(): compiled with -DEVT_SRC_HASH=<hash of all sources>
 
 
-def _newer(a, b):
-    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdrs.append(os.path.join(HERE, "..", "include", "evt.h"))
+    return hdrs
+
+
+def source_hash() -> str:
+    """12 hex digits over every csrc/*.hip, csrc/*.h and include/evt.h: what evt_version() of a fresh build reports"""
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return _sha(srcs + _headers())[:12]
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(HERE, "..", "include", "evt.h"))
+    hdrs = _headers()
+    shash = source_hash()
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s[:-4] + ".o")
-        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
-            jobs.append((src, obj))
+        flags = [*FLAGS, *EXTRA_FLAGS.get(s, [])]
+        if s == VERSION_SRC:
+            flags.append(f'-DEVT_SRC_HASH="{shash}"')
+        stamp = _sha([src] + hdrs, " ".join(flags))
+        rec = obj + ".hash"
+        old = open(rec).read().strip() if os.path.exists(rec) else ""
+        if force or not os.path.exists(obj) or old != stamp:
+            jobs.append((src, obj, flags, stamp))
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        src, obj, flags, stamp = job
+        cmd = [HIPCC, *flags, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(obj + ".hash", "w") as f:
+            f.write(stamp)
         return obj
 
     if jobs:

@@ -394,7 +394,10 @@ extern "C" {
 const char* evt_last_kernel_tag(void) { return g_last_tag; }
 void evt_debug_kernel_tags(int32_t enable) { g_tags_on = enable != 0; }
 
-const char* evt_version(void) { return "evt-hip 0.1 (gfx950)"; }
+#ifndef EVT_SRC_HASH
+#define EVT_SRC_HASH "unknown"
+#endif
+const char* evt_version(void) { return "evt-hip 0.2 (gfx950) src=" EVT_SRC_HASH; }
 
 int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream) {
   if (!items || !row_index || nrows <= 0) return EVT_EINVAL;

@@ -658,6 +658,10 @@ class ResUnitFn(torch.autograd.Function):
         s1, s2, slope = ctx.s1, ctx.s2, ctx.slope
         dy = dy.contiguous()
         nseq, lin = xa.size(0), xa.size(1)
+        if ctx.needs_input_grad[0]:
+            dx = resunit_bwd(s1, s2, dy, xa, mid_a, slope, 1.0)
+            if dx is not None:
+                return dx, None, None, None, None
         if s2.bank.weight_grads:
             _bwd_weight(s2, mid_a, dy, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
         # d(c1 output before its activation) = (W2^T dy) * lrelu'(mid): gate epilogue on mid_a
@@ -670,8 +674,231 @@ class ResUnitFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+def _t1_unit_bwd(e0, m1, m2, xa, wg):
+    """trace record of one fused backward: both backward-data convolutions (+ both weight gradients); bytes = dy, xa,
+    mid_a in, dx out, both weight images (+ both fp32 gradient images)"""
+    e0, rf = e0
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
+    n, ln, c = xa.shape
+    macs = n * ln * c * c * (m1.k + m2.k) * (2 if wg else 1)
+    wb = (m1.v.numel() + m2.v.numel()) * (2 + (4 if wg else 0))
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), "bwd_unit", 2 * macs, 4 * xa.numel() * 2 + wb, e0, e1,
+                  f"unit {c}>{c} k{m1.k} d{m1.dil} n{n} L{ln}", m1))
+
+
+def resunit_bwd(s1, s2, dy, xa, mid_a, slope, dy_scale=1.0):
+    """The whole backward of one ResBlock1 step in one launch (csrc/resunit_bwd.hip) when the shape is covered: returns
+    dx (and leaves the weight / bias gradients of both convolutions in their gradient images / .grad), else None.
+    Where the kernel takes the data gradients but not the weight gradients (C = 32 with 11 taps: the accumulators do
+    not fit the register file) it also writes dmid and the two weight gradients run as their own launches."""
+    fused = _resunit_params(s1, s2, xa, slope)
+    if fused is None:
+        return None
+    lib = L.lib()
+    bank = s1.bank
+    wg = bool(bank.weight_grads)
+    wg_in = wg and bool(lib.evt_resunit_bwd_supported(C.byref(fused), 1))
+    if not lib.evt_resunit_bwd_supported(C.byref(fused), 0):
+        return None
+    if wg and not wg_in and dy_scale != 1.0:
+        return None
+    m1, m2 = s1.module, s2.module
+    dx = torch.empty_like(dy)
+    dmid = torch.empty_like(dy) if (wg and not wg_in) else None
+    dw1 = dw2 = db1 = db2 = ws = None
+    if wg_in:
+        for m in (m1, m2):
+            if m.bias is not None and m.bias.grad is None:
+                m.bias.grad = torch.zeros_like(m.bias)
+        dw1, dw2 = s1.dw, s2.dw
+        db1 = m1.bias.grad if m1.bias is not None else None
+        db2 = m2.bias.grad if m2.bias is not None else None
+        ws = bank.scratch()
+    e0 = _t0()
+    L.check(lib.evt_resunit_bwd(C.byref(fused), L.ptr(dy), C.c_float(dy_scale), L.ptr(xa), L.ptr(mid_a), L.ptr(s1.alt),
+                                L.ptr(s2.alt), L.ptr(dx), L.ptr(dmid), L.ptr(dw1), L.ptr(dw2), L.ptr(db1), L.ptr(db2),
+                                L.ptr(ws), C.c_int64(ws.numel() if ws is not None else 0), L.stream_ptr()),
+            "evt_resunit_bwd")
+    if e0 is not None:
+        _t1_unit_bwd(e0, m1, m2, xa, wg_in)
+    if wg_in:
+        s1.wg_dirty = s2.wg_dirty = True
+    elif wg:
+        nseq, lin = xa.size(0), xa.size(1)
+        _bwd_weight(s2, mid_a, dy, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+        _bwd_weight(s1, xa, dmid, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+    return dx
+
+
 def res_unit(x, c1: EvtConv1d, c2: EvtConv1d, slope: float):
     return ResUnitFn.apply(x, c1._slot.bank.anchor, c1._slot, c2._slot, float(slope))
+
+
+def _dptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _t1_multi(e0, kind, pairs, x, wg):
+    """trace record of one grouped launch: the sums over its jobs of what _t1_unit / _t1_unit_bwd record"""
+    e0, rf = e0
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
+    n, ln, c = x.shape
+    macs = sum(n * ln * c * c * (s1.module.k + s2.module.k) for s1, s2 in pairs)
+    wel = sum(s1.module.v.numel() + s2.module.v.numel() for s1, s2 in pairs)
+    if kind == "bwd_unit":
+        macs *= 2 if wg else 1
+        wb = wel * (2 + (4 if wg else 0))
+    else:
+        wb = wel * 2
+    m1 = pairs[0][0].module
+    TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, len(pairs) * 4 * x.numel() * 2 + wb, e0, e1,
+                  f"units x{len(pairs)} {c}>{c} k" + "/".join(str(s1.module.k) for s1, _ in pairs) + f" d{m1.dil} n{n} L{ln}", m1))
+
+
+def _stage_plan(x, blocks, slope):
+    """[(slot pairs of unit j over the blocks)] when every step of the stage is covered by the grouped kernels: the blocks
+    have kernel sizes 3 / 7 / 11 (one each), equally many steps, and every step passes _resunit_params"""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or len(blocks) != 3:
+        return None
+    nunits = len(blocks[0].convs1)
+    if any(len(b.convs1) != nunits or len(b.convs2) != nunits for b in blocks):
+        return None
+    if sorted(b.convs1[0].k for b in blocks) != [3, 7, 11]:
+        return None
+    plan = []
+    for j in range(nunits):
+        pairs = [(b.convs1[j]._slot, b.convs2[j]._slot) for b in blocks]
+        if any(s1 is None or s2 is None for s1, s2 in pairs):
+            return None
+        ps = [_resunit_params(s1, s2, x, slope) for s1, s2 in pairs]
+        if any(p is None for p in ps):
+            return None
+        plan.append((pairs, ps))
+    return plan
+
+
+class ResStageFn(torch.autograd.Function):
+    """One HiFi-GAN stage after its up-sampling convolution (models.py:457-466): the three ResBlock1 of kernel sizes
+    3 / 7 / 11 applied to the same input and averaged.  Step j of all three blocks is ONE grouped launch each way
+    (csrc/resunit.hip, resunit_bwd.hip), so a stage is 3 + 1 launches forward and 3 + 1 (+ 1 fold each) backward instead
+    of 9 + 1 and 36 + 2.  The 1 / 3 of the mean is folded into the first backward launch's load of dy."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, plan, slope, scale):
+        lib = L.lib()
+        cur = [x] * len(plan[0][0])
+        saved = []
+        for pairs, ps in plan:
+            jobs = (L.ResUnitFwdJob * len(pairs))()
+            outs = []
+            for i, ((s1, s2), p) in enumerate(zip(pairs, ps)):
+                m1, m2 = s1.module, s2.module
+                xa, mid_a, y = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+                jb = jobs[i]
+                jb.p = p
+                jb.x, jb.w1_reg, jb.w2_reg = cur[i].data_ptr(), s1.reg.data_ptr(), s2.reg.data_ptr()
+                jb.b1 = _dptr(m1.bias.data if m1.bias is not None else None)
+                jb.b2 = _dptr(m2.bias.data if m2.bias is not None else None)
+                jb.xa, jb.mid_a, jb.y = xa.data_ptr(), mid_a.data_ptr(), y.data_ptr()
+                outs.append(y)
+                saved += [xa, mid_a]
+            e0 = _t0()
+            L.check(lib.evt_resunit_fwd_multi(jobs, len(pairs), L.stream_ptr()), "evt_resunit_fwd_multi")
+            if e0 is not None:
+                _t1_multi(e0, "fwd", pairs, x, False)
+            cur = outs
+        out = torch.empty_like(x)
+        L.check(lib.evt_add3_scale(L.dt_of(x), L.ptr(cur[0]), L.ptr(cur[1]), L.ptr(cur[2]), C.c_float(scale), L.ptr(out),
+                                   C.c_int64(x.numel()), L.stream_ptr()), "evt_add3_scale")
+        ctx.plan, ctx.slope, ctx.scale = plan, slope, scale
+        ctx.save_for_backward(*saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        plan, slope, scale = ctx.plan, ctx.slope, ctx.scale
+        saved = ctx.saved_tensors
+        dy = dy.contiguous()
+        nb = len(plan[0][0])
+        bank = plan[0][0][0][0].bank
+        wg = bool(bank.weight_grads)
+        # which jobs accumulate their weight gradients in the launch (all but C = 32 with 11 taps)
+        in_k = [[wg and bool(lib.evt_resunit_bwd_supported(C.byref(p), 1)) for p in ps] for _, ps in plan]
+        fold_scale = all(all(r) for r in in_k) or not wg
+        if not fold_scale:
+            g = torch.empty_like(dy)
+            L.check(lib.evt_add3_scale(L.dt_of(dy), L.ptr(dy), None, None, C.c_float(scale), L.ptr(g),
+                                       C.c_int64(dy.numel()), L.stream_ptr()), "evt_add3_scale")
+            dy = g
+        d = [dy] * nb
+        ws = bank.scratch() if wg else None
+        for j in range(len(plan) - 1, -1, -1):
+            pairs, ps = plan[j]
+            jobs = (L.ResUnitBwdJob * nb)()
+            outs, later = [], []
+            for i, ((s1, s2), p) in enumerate(zip(pairs, ps)):
+                m1, m2 = s1.module, s2.module
+                xa, mid_a = saved[2 * (j * nb + i)], saved[2 * (j * nb + i) + 1]
+                dx = torch.empty_like(dy)
+                jb = jobs[i]
+                jb.p = p
+                jb.dy_scale = scale if (fold_scale and j == len(plan) - 1) else 1.0
+                jb.dy, jb.xa, jb.mid_a = d[i].data_ptr(), xa.data_ptr(), mid_a.data_ptr()
+                jb.w1_alt, jb.w2_alt, jb.dx = s1.alt.data_ptr(), s2.alt.data_ptr(), dx.data_ptr()
+                if in_k[j][i]:
+                    for m in (m1, m2):
+                        if m.bias is not None and m.bias.grad is None:
+                            m.bias.grad = torch.zeros_like(m.bias)
+                    jb.dw1, jb.dw2 = s1.dw.data_ptr(), s2.dw.data_ptr()
+                    jb.db1 = _dptr(m1.bias.grad if m1.bias is not None else None)
+                    jb.db2 = _dptr(m2.bias.grad if m2.bias is not None else None)
+                    s1.wg_dirty = s2.wg_dirty = True
+                elif wg:
+                    dmid = torch.empty_like(dy)
+                    jb.dmid = dmid.data_ptr()
+                    later.append((s1, s2, xa, mid_a, d[i], dmid))
+                outs.append(dx)
+            e0 = _t0()
+            L.check(lib.evt_resunit_bwd_multi(jobs, nb, L.ptr(ws), C.c_int64(ws.numel() if ws is not None else 0),
+                                              L.stream_ptr()), "evt_resunit_bwd_multi")
+            if e0 is not None:
+                _t1_multi(e0, "bwd_unit", pairs, dy, wg)
+            nseq, lin = dy.size(0), dy.size(1)
+            for s1, s2, xa, mid_a, dyi, dmid in later:
+                _bwd_weight(s2, mid_a, dyi, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+                _bwd_weight(s1, xa, dmid, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+            d = outs
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            L.check(lib.evt_add3_scale(L.dt_of(dy), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), C.c_float(1.0), L.ptr(dx),
+                                       C.c_int64(dy.numel()), L.stream_ptr()), "evt_add3_scale")
+        return dx, None, None, None, None
+
+
+def res_stage(x, blocks, slope: float, scale: float):
+    """mean over `blocks` (ResBlock1 modules) of block(x), through the grouped kernels; None when the stage is not covered
+    (the caller then runs the blocks one by one)"""
+    if os.environ.get("EVT_NO_RESSTAGE") == "1":
+        return None
+    plan = _stage_plan(x, blocks, slope)
+    if plan is None:
+        return None
+    lib = L.lib()
+    # the grouped backward exists for every job shape the forward takes (data gradients at least)
+    if not all(lib.evt_resunit_bwd_supported(C.byref(p), 0) for _, ps in plan for p in ps):
+        return None
+    # jobs are handed over in kernel-size order 3 / 7 / 11
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i].convs1[0].k)
+    plan = [([pairs[i] for i in order], [ps[i] for i in order]) for pairs, ps in plan]
+    return ResStageFn.apply(x, plan[0][0][0][0].bank.anchor, plan, float(slope), float(scale))
 
 
 class Add3ScaleFn(torch.autograd.Function):

@@ -35,6 +35,17 @@ class ResUnitParams(C.Structure):
                 ("dil", C.c_int32), ("slope", C.c_float)]
 
 
+class ResUnitFwdJob(C.Structure):
+    _fields_ = [("p", ResUnitParams), ("x", C.c_void_p), ("w1_reg", C.c_void_p), ("w2_reg", C.c_void_p),
+                ("b1", C.c_void_p), ("b2", C.c_void_p), ("xa", C.c_void_p), ("mid_a", C.c_void_p), ("y", C.c_void_p)]
+
+
+class ResUnitBwdJob(C.Structure):
+    _fields_ = [("p", ResUnitParams), ("dy_scale", C.c_float), ("dy", C.c_void_p), ("xa", C.c_void_p),
+                ("mid_a", C.c_void_p), ("w1_alt", C.c_void_p), ("w2_alt", C.c_void_p), ("dx", C.c_void_p),
+                ("dmid", C.c_void_p), ("dw1", C.c_void_p), ("dw2", C.c_void_p), ("db1", C.c_void_p), ("db2", C.c_void_p)]
+
+
 class WLayout(C.Structure):
     _fields_ = [
         ("d0", C.c_int32), ("d1", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32),
@@ -112,6 +123,21 @@ class MhaParams(C.Structure):
 _lib = None
 
 
+def _check_fresh(handle):
+    """the library carries the hash of the sources it was built from (evt_version(): "... src=<hash>"); next to a source
+    tree (this repository, the GPU box's copy of it) a different hash means a stale .so -- an error, not an old kernel"""
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    if os.environ.get("EVT_ALLOW_STALE_LIB") == "1" or not os.path.isdir(csrc):
+        return
+    from ..build import source_hash
+
+    have = handle.evt_version().decode()
+    want = source_hash()
+    if f"src={want}" not in have:
+        raise EvtError(f"{LIB_PATH} is stale: built from sources {have.split('src=')[-1]!r}, the tree has {want!r}; "
+                       "rebuild with `python -m easevoice_trainer_amd.build` (EVT_ALLOW_STALE_LIB=1 overrides)")
+
+
 def lib():
     """Load the shared library once; raise loudly if it is missing (no CPU / eager fallback)."""
     global _lib
@@ -122,10 +148,12 @@ def lib():
                 "(or __graft_entry__.build()). There is no fallback path.")
         _lib = C.CDLL(LIB_PATH)
         _lib.evt_version.restype = C.c_char_p
+        _check_fresh(_lib)
         _lib.evt_conv1d_lout.restype = C.c_int32
         _lib.evt_mel_workspace_floats.restype = C.c_int64
         _lib.evt_workspace_bytes.restype = C.c_int64
         _lib.evt_last_kernel_tag.restype = C.c_char_p
+        _lib.evt_resunit_bwd_ws_floats.restype = C.c_int64
         _lib.evt_debug_kernel_tags.restype = None
     return _lib
 

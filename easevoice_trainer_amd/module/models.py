@@ -22,7 +22,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..hip import lib as L
-from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_unit
+from ..hip.conv import Add3ScaleFn, EvtConv1d, GatedActFn, res_stage, res_unit
 from ..hip.enc import new_site, rel_self_attention, unbind_rows, wn_residual, wn_residual_last
 from ..hip.frontend import RvqEncoder, ncl_to_nlc
 from ..hip.wn import wn_stack
@@ -503,7 +503,14 @@ class Generator(nn.Module, _ComputeDtype):
             x = (x + self.cond(g).unsqueeze(1)).to(self.cd)
         for i in range(self.num_upsamples):
             x = self.ups[i](x, in_slope=LRELU_SLOPE)          # leaky_relu(0.1) fused on load
-            rs = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
+            blocks = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
+            if x.is_cuda:
+                # narrow stages: step j of the three blocks is one grouped launch each way (hip/conv.py::ResStageFn)
+                xs = res_stage(x, blocks, LRELU_SLOPE, 1.0 / self.num_kernels)
+                if xs is not None:
+                    x = xs
+                    continue
+            rs = [b(x) for b in blocks]
             while len(rs) < 3:
                 rs.append(None)
             x = Add3ScaleFn.apply(rs[0], rs[1], rs[2], 1.0 / self.num_kernels)

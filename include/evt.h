@@ -24,6 +24,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the declarations of this header are its exported symbols */
+#pragma GCC visibility push(default)
 
 #define EVT_DT_F32 0
 #define EVT_DT_BF16 1
@@ -34,11 +36,15 @@ extern "C" {
 #define EVT_IMPL_NAIVE 1 /* direct-form reference kernels (any shape, groups) */
 #define EVT_IMPL_IGEMM 2 /* LDS-tiled implicit-GEMM on MFMA */
 
+/* "evt-hip <version> (gfx950) src=<12 hex digits>": the digits are a hash of the sources the library was built from
+ * (easevoice_trainer_amd/build.py::source_hash); the Python binding refuses a library whose hash differs from the
+ * sources next to it. */
 const char* evt_version(void);
 /* Profiling aid, OUTSIDE the contract above and off by default: after evt_debug_kernel_tags(1) every dispatcher
  * records the name of the kernel instantiation it launched in a per-thread buffer that evt_last_kernel_tag() returns
  * (bench.py's roofline leg groups its timings by these names, the same names rocprofv3 prints).  With tags off (the
- * product path) nothing is recorded and the library keeps no mutable state. */
+ * product path) nothing is recorded.  evt_debug_* are the library's ONLY process-global mutable state (two flags and a
+ * thread-local name buffer): measurement switches, never read by a computation's arithmetic. */
 void evt_debug_kernel_tags(int32_t enable);
 const char* evt_last_kernel_tag(void);
 /* measurement switch of the bf16 attention kernels: 1 = both query/key tiles of a wave in one instruction stream
@@ -194,6 +200,43 @@ typedef struct evt_resunit_params {
 int32_t evt_resunit_supported(const evt_resunit_params* p);
 int evt_resunit_fwd(const evt_resunit_params* p, const void* x, const void* w1_reg, const void* w2_reg, const float* b1,
                     const float* b2, void* xa, void* mid_a, void* y, void* stream);
+
+/* The same step of up to THREE ResBlocks at once -- the three kernel sizes of a HiFi-GAN stage (models.py:457-466:
+ * resblock_kernel_sizes 3 / 7 / 11 run side by side on the same input and are averaged) -- as ONE launch: one job per
+ * kernel size, all with the same C; each job is what evt_resunit_fwd takes. */
+typedef struct evt_resunit_fwd_job {
+  evt_resunit_params p;
+  const void* x; const void* w1_reg; const void* w2_reg; const float* b1; const float* b2;
+  void* xa; void* mid_a; void* y;
+} evt_resunit_fwd_job;
+int evt_resunit_fwd_multi(const evt_resunit_fwd_job* jobs, int32_t njobs, void* stream);
+
+/* The whole backward of the same step in ONE launch (what torch.autograd runs as two conv backward-data, two conv
+ * backward-weight and two bias reductions for modules.py:299-308):
+ *   dmid = (c2^T dy') * lrelu'(mid_a),  dx = (c1^T dmid) * lrelu'(xa) + dy',  dy' = dy * dy_scale (rounded to bf16: the
+ *   1 / num_kernels of the stage mean, models.py:466, folded into the load; 1.0 = plain dy),
+ *   dw2 += dy' (x) mid_a, dw1 += dmid (x) xa (fp32 gradient images, REG geometry), db2 += sum dy', db1 += sum dmid.
+ * w1_alt / w2_alt: the ALT images of the two convolutions.  dmid (optional, may be NULL): receives dmid [nseq][L][C].
+ * Weight gradients: evt_resunit_bwd_supported(p, 1) says whether the launch can accumulate them (not for C = 32 with
+ * 11 taps: the two images do not fit the register file); then dw1, dw2 != NULL and ws = scratch of at least
+ * evt_resunit_bwd_ws_floats() floats (one buffer per stream, contents need not survive the call): blocks store partial
+ * gradient rows there and a second launch adds them in block order -- the result does not depend on timing.  Otherwise
+ * pass dw1 == dw2 == NULL and dmid != NULL and run evt_conv1d_bwd_weight(xa, dmid) / (mid_a, dy) for the two gradients.
+ * db1 / db2 may be NULL.  evt_resunit_bwd_multi: one to three jobs (one per kernel size 3 / 7 / 11, same C) in one
+ * launch, each job as described. */
+int32_t evt_resunit_bwd_supported(const evt_resunit_params* p, int32_t with_weight_grads);
+int64_t evt_resunit_bwd_ws_floats(const evt_resunit_params* p);
+int evt_resunit_bwd(const evt_resunit_params* p, const void* dy, float dy_scale, const void* xa, const void* mid_a,
+                    const void* w1_alt, const void* w2_alt, void* dx, void* dmid, float* dw1, float* dw2, float* db1,
+                    float* db2, float* ws, int64_t ws_floats, void* stream);
+typedef struct evt_resunit_bwd_job {
+  evt_resunit_params p;
+  float dy_scale;
+  const void* dy; const void* xa; const void* mid_a; const void* w1_alt; const void* w2_alt;
+  void* dx; void* dmid;
+  float* dw1; float* dw2; float* db1; float* db2;
+} evt_resunit_bwd_job;
+int evt_resunit_bwd_multi(const evt_resunit_bwd_job* jobs, int32_t njobs, float* ws, int64_t ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Element-wise / reduction helpers of the s2 path.
@@ -559,6 +602,7 @@ int evt_scaled_adam_stats(const float* param, const float* grad, const evt_sa_ch
 int evt_scaled_adam_apply(float* param, const float* grad, float* delta, float* exp_avg_sq, const evt_sa_chunk* chunks,
                           int32_t nchunks, const float* coef, const evt_scaled_adam_hp* hp, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,5 @@
-"""Times one ResBlock step forward at the B=16 vocoder shapes, fused (csrc/resunit.hip) vs the three launches it replaces.
+"""Times one ResBlock step at the B=16 vocoder shapes: forward fused (csrc/resunit.hip) vs the three launches it replaces,
+backward fused (csrc/resunit_bwd.hip: data + weight + bias gradients) vs the four launches it replaces.
 usage: python tools/bench_resunit.py"""
 import os
 import sys
@@ -13,7 +14,7 @@ from easevoice_trainer_amd.hip import lib as L    # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     for C_, Lq in ((16, 20480), (32, 10240)):
-        for k, d in ((3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)):
+        for k, d in ((3, 1), (3, 5), (7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11, 5)):
             pad = lambda kk, dd: (kk * dd - dd) // 2
             m = torch.nn.ModuleList([HC.EvtConv1d(C_, C_, k, dilation=d, padding=pad(k, d), weight_norm=True),
                                      HC.EvtConv1d(C_, C_, k, dilation=1, padding=pad(k, 1), weight_norm=True)]).to(dev)
@@ -32,8 +33,22 @@ def main():
                 with torch.no_grad():
                     return HC.res_unit(x, m[0], m[1], 0.1)
 
+            dy = torch.randn(16, Lq, C_, device=dev).bfloat16()
+            xa = HC._lrelu(x, 0.1)
+            mid_a = HC._fwd(s1, xa, None, 1.0, L.ACT_LRELU, 0.1)
+            bank.defer_n = 0
+
+            def bwd_unfused():
+                HC._bwd_weight(s2, mid_a, dy, None, 16, Lq, 1.0, L.ACT_NONE, 1.0)
+                dmid = HC._bwd_data(s2, dy, None, mid_a, None, 16, Lq, 0.1, L.ACT_NONE, 1.0)
+                HC._bwd_weight(s1, xa, dmid, None, 16, Lq, 1.0, L.ACT_NONE, 1.0)
+                return HC._bwd_data(s1, dmid, None, xa, dy, 16, Lq, 0.1, L.ACT_NONE, 1.0)
+
+            def bwd_fused():
+                return HC.resunit_bwd(s1, s2, dy, xa, mid_a, 0.1, 1.0)
+
             out = {}
-            for name, fn in (("unfused", unfused), ("fused", fused)):
+            for name, fn in (("unfused", unfused), ("fused", fused), ("bwd_unfused", bwd_unfused), ("bwd_fused", bwd_fused)):
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize()
@@ -44,7 +59,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 out[name] = e0.elapsed_time(e1) / 20 * 1e3
-            print(f"C={C_:3d} L={Lq:6d} k={k:2d} d={d}: unfused {out['unfused']:6.1f} us  fused {out['fused']:6.1f} us")
+            print(f"C={C_:3d} L={Lq:6d} k={k:2d} d={d}: fwd unfused {out['unfused']:6.1f} us  fused {out['fused']:6.1f} us | "
+                  f"bwd unfused {out['bwd_unfused']:6.1f} us  fused {out['bwd_fused']:6.1f} us", flush=True)
 
 
 if __name__ == "__main__":
