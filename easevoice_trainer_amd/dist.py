@@ -128,6 +128,13 @@ def init_process_group_from_env(backend=None, gpu_ids=None):
             # narrowed the visible devices already: id 2 with one visible device is that device
             nvis = torch.cuda.device_count() if torch.cuda.is_available() else 0
             if nvis and local >= nvis:
+                narrowed = any(os.environ.get(v) for v in ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                                                           "ROCR_VISIBLE_DEVICES"))
+                if not narrowed:
+                    # nothing narrowed the visible devices: "2" on a 2-GPU box is a mistake, and folding it onto card 0
+                    # would put two independent jobs on one device without a word
+                    raise ValueError(f"gpu_ids={gpu_ids!r} names GPU {local}, this node has {nvis} (and no "
+                                     "*_VISIBLE_DEVICES narrowing that would explain the id)")
                 local = local % nvis
         return world, int(os.environ.get("RANK", "0")), local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

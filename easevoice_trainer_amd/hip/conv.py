@@ -213,8 +213,15 @@ class WeightBank:
         # are valid.
         self.parts_on = (dtype == torch.bfloat16 and self.device.type == "cuda"
                          and os.environ.get("EVT_WGRAD_PARTS", "1") != "0")
-        budget = int(os.environ.get("EVT_WGRAD_SLAB_MB", "48")) << 20
+        # the slab sizes below (48 MiB per image, at most 32 slabs: 5.9 GB for the s2 models) were measured on a 288 GB
+        # MI355X; on a smaller device the budget shrinks with its memory (at 1/4 of the memory: 12 MiB, 1.5 GB)
+        total_mem = torch.cuda.get_device_properties(self.device).total_memory if self.device.type == "cuda" else 0
+        mem_scale = min(1.0, total_mem / float(256 << 30)) if total_mem else 1.0
+        budget = int(os.environ.get("EVT_WGRAD_SLAB_MB", str(max(4, int(48 * mem_scale))))) << 20
         cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "32"))
+        # operands held for the deferred weight-gradient launches: flushed on a byte budget as well as on a count
+        self.defer_bytes = int(os.environ.get("EVT_WGRAD_DEFER_MB", str(max(256, int(4096 * mem_scale))))) << 20
+        self._deferred_bytes = 0
         ex_n = db_n = 0
         ex_offs = []
         for s in self.slots:
@@ -224,8 +231,9 @@ class WeightBank:
             db_n += s.parts * ((s.layout.d0 + 31) // 32 * 32)
         # scratch of the two-launch reductions (evt_wgrad_parts.ws): one buffer per stream the weight gradients run on
         self._ws = {}
-        self.dw_extra_arena = torch.empty(max(ex_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
-        self.db_part_arena = torch.empty(max(db_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
+        # zeros once: the kernels never store the padded taps of an image row, and the fold adds whole rows
+        self.dw_extra_arena = torch.zeros(max(ex_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
+        self.db_part_arena = torch.zeros(max(db_n, 1), dtype=torch.float32, device=device) if self.parts_on else None
         for i, (s, (ro, ao)) in enumerate(zip(self.slots, offs)):
             s.reg = self.reg_arena[ro: ro + s.layout.reg_elems]
             s.alt = self.alt_arena[ao: ao + s.layout.alt_elems]
@@ -278,6 +286,19 @@ class WeightBank:
         self._items = L.struct_to_device(items, self.device)
         self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
         self._nrows = len(rows)
+        self._grad_stamp = self._grad_ptrs()
+
+    def _grad_ptrs(self):
+        """addresses of every .grad the device tables point at (weights, gains, fused bias gradients)"""
+        out = []
+        for s in self.slots:
+            m = s.module
+            g = m.weight_g if m.weight_norm else None
+            b = getattr(m, "bias", None)
+            out.append((m.v.grad.data_ptr() if m.v.grad is not None else 0,
+                        g.grad.data_ptr() if (g is not None and g.grad is not None) else 0,
+                        b.grad.data_ptr() if (b is not None and b.grad is not None) else 0))
+        return out
 
     def fold(self):
         """w = g*v/|v| -> REG/ALT images for every conv of the model: ONE launch."""
@@ -287,6 +308,14 @@ class WeightBank:
                 "evt_wn_fold_multi")
 
     def zero_dw(self):
+        if self._deferred or self._held:
+            # weight-gradient launches of a backward that never reached grads() (a standalone user, an exception in the
+            # middle of a step): they would land in the images zeroed below -- drop them, wait for what already runs
+            self._deferred.clear()
+            self._deferred_bytes = 0
+            if self._side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._held.clear()
         self.dw_arena.zero_()            # slab 0 of every image and the slab counters
         for s in self.slots:
             s.wg_used, s.wg_dirty = 0, False
@@ -315,6 +344,7 @@ class WeightBank:
                 _bwd_weight_now(*args)
         self._held.extend((a[1], a[2], a[3]) for a in self._deferred)
         self._deferred.clear()
+        self._deferred_bytes = 0
 
     def join_side(self):
         self.flush_deferred()
@@ -337,6 +367,10 @@ class WeightBank:
         """dW images -> weight_v.grad / weight_g.grad (or weight.grad), ACCUMULATED (+=): one launch over the whole
         model, or over the row range [lo, hi) of rows_of() -- every row must be visited exactly once per backward."""
         self.join_side()
+        if self._items is None or (not torch.cuda.is_current_stream_capturing() and self._grad_stamp != self._grad_ptrs()):
+            # a .grad was replaced since the tables were built (zero_grad(set_to_none=True), a caller assigning a new
+            # tensor): the fused bias gradients / dv / dg would go to the old storage -- rebuild the tables
+            self.build_tables()
         lo = 0 if lo is None else lo
         hi = self._nrows if hi is None else hi
         if hi <= lo:
@@ -459,6 +493,18 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
     TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs, act * sz + wbytes, e0, e1, shape, m))
 
 
+def _t1_elt(e0, name, nbytes, owner):
+    """trace record of an element-wise launch of this file (leaky-relu copy, stage mean, activation derivative): no flops,
+    bytes = operands in + out; `owner` = a module of the model the launch belongs to (bench.py attributes HiFi-GAN's
+    element-wise launches to `dec` through it)"""
+    e0, rf = e0
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
+    TRACE.append((name, "elt", 0, nbytes, e0, e1, name, owner))
+
+
 def _fwd(slot, x, res, in_slope, out_act, out_slope, out=None):
     """`out`: optional preallocated contiguous [nseq, Lout, Cout] destination (e.g. one plane of a q|k|v buffer)"""
     m = slot.module
@@ -504,7 +550,8 @@ def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
                          "q / k / v projections of a windowed attention layer run (and are differentiated) as one pack")
     if bank.defer_n > 0 and TRACE is None:
         bank._deferred.append((slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope))
-        if len(bank._deferred) >= bank.defer_n:
+        bank._deferred_bytes += x.numel() * x.element_size() + dy.numel() * dy.element_size()
+        if len(bank._deferred) >= bank.defer_n or bank._deferred_bytes >= bank.defer_bytes:
             bank.flush_deferred()
         return
     if bank.async_wgrad and TRACE is None:
@@ -573,8 +620,11 @@ class ConvFn(torch.autograd.Function):
                 C.byref(slot.params(nseq, lin, in_slope, out_act, out_slope))):
             # wide layers: apply the activation derivative once, both backward GEMMs then take plain operands
             dy_eff = torch.empty_like(dy)
+            e0 = _t0()
             L.check(L.lib().evt_dact_mul(L.dt_of(dy), L.ptr(dy), L.ptr(y), int(out_act), C.c_float(out_slope),
                                          L.ptr(dy_eff), C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
+            if e0 is not None:
+                _t1_elt(e0, "dact_mul_kernel", 3 * dy.numel() * dy.element_size(), slot.module)
             dy, y, out_act, out_slope = dy_eff, None, L.ACT_NONE, 1.0
         if slot.bank.weight_grads:
             _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
@@ -600,6 +650,18 @@ def _resunit_params(s1, s2, x, slope):
     return p if L.lib().evt_resunit_supported(C.byref(p)) else None
 
 
+def _resunit_wide_params(s1, s2, x, slope):
+    """evt_resunit_params when the wide fused step (csrc/resunit_wide.hip: C = 64 / 128) covers this pair, else None"""
+    m1, m2 = s1.module, s2.module
+    if (x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
+            or m2.cin != m2.cout or m1.cin != m2.cin or m1.k != m2.k or m2.dil != 1 or m1.stride != 1 or m2.stride != 1
+            or m1.groups != 1 or m2.groups != 1 or m1.transposed or m2.transposed
+            or m1.pad != m1.dil * (m1.k - 1) // 2 or m2.pad != (m2.k - 1) // 2 or s1.bank.impl != L.IMPL_AUTO):
+        return None
+    p = L.ResUnitParams(L.DT_BF16, x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
+    return p if L.lib().evt_resunit_wide_supported(C.byref(p)) else None
+
+
 def _t1_unit(e0, m1, m2, x):
     """trace record of one fused step: flops of both convolutions; bytes = x in, xa / mid_a / y out, both weight images"""
     e0, rf = e0
@@ -613,10 +675,22 @@ def _t1_unit(e0, m1, m2, x):
                   e0, e1, f"unit {c}>{c} k{m1.k} d{m1.dil} n{n} L{ln}", m1))
 
 
-def _lrelu(x, slope):
+def _lrelu(x, slope, owner=None):
     out = torch.empty_like(x)
+    e0 = _t0()
     L.check(L.lib().evt_leaky_relu(L.dt_of(x), L.ptr(x), C.c_float(slope), L.ptr(out), C.c_int64(x.numel()),
                                    L.stream_ptr()), "evt_leaky_relu")
+    if e0 is not None:
+        _t1_elt(e0, "lrelu_kernel", 2 * x.numel() * x.element_size(), owner)
+    return out
+
+
+def _add3(a, b, c, scale, out, owner):
+    e0 = _t0()
+    L.check(L.lib().evt_add3_scale(L.dt_of(a), L.ptr(a), L.ptr(b), L.ptr(c), C.c_float(scale), L.ptr(out),
+                                   C.c_int64(a.numel()), L.stream_ptr()), "evt_add3_scale")
+    if e0 is not None:
+        _t1_elt(e0, "add3_scale_kernel", (2 + (b is not None) + (c is not None)) * a.numel() * a.element_size(), owner)
     return out
 
 
@@ -645,7 +719,22 @@ class ResUnitFn(torch.autograd.Function):
             ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
             ctx.save_for_backward(xa, mid_a)
             return y
-        xa = _lrelu(x, slope)
+        wide = _resunit_wide_params(s1, s2, x, slope)
+        if wide is not None:
+            # wide stages (C = 64 / 128): one launch, the intermediate stays in LDS (csrc/resunit_wide.hip)
+            m1, m2 = s1.module, s2.module
+            xa, mid_a, y = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            e0 = _t0()
+            L.check(L.lib().evt_resunit_wide_fwd(C.byref(wide), L.ptr(x), L.ptr(s1.reg), L.ptr(s2.reg),
+                                                 L.ptr(m1.bias.data if m1.bias is not None else None),
+                                                 L.ptr(m2.bias.data if m2.bias is not None else None), L.ptr(xa),
+                                                 L.ptr(mid_a), L.ptr(y), L.stream_ptr()), "evt_resunit_wide_fwd")
+            if e0 is not None:
+                _t1_unit(e0, m1, m2, x)
+            ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
+            ctx.save_for_backward(xa, mid_a)
+            return y
+        xa = _lrelu(x, slope, s1.module)
         mid_a = _fwd(s1, xa, None, 1.0, L.ACT_LRELU, slope)
         y = _fwd(s2, mid_a, x, 1.0, L.ACT_NONE, 1.0)
         ctx.s1, ctx.s2, ctx.slope = s1, s2, slope
@@ -661,6 +750,20 @@ class ResUnitFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = resunit_bwd(s1, s2, dy, xa, mid_a, slope, 1.0)
             if dx is not None:
+                return dx, None, None, None, None
+            wide = _resunit_wide_params(s1, s2, xa, slope)
+            if wide is not None:
+                m1, m2 = s1.module, s2.module
+                dmid, dx = torch.empty_like(dy), torch.empty_like(dy)
+                e0 = _t0()
+                L.check(L.lib().evt_resunit_wide_bwd_data(C.byref(wide), L.ptr(dy), C.c_float(1.0), L.ptr(xa), L.ptr(mid_a),
+                                                          L.ptr(s1.alt), L.ptr(s2.alt), L.ptr(dmid), L.ptr(dx),
+                                                          L.stream_ptr()), "evt_resunit_wide_bwd_data")
+                if e0 is not None:
+                    _t1_unit_bwd(e0, m1, m2, xa, False)
+                if s2.bank.weight_grads:
+                    _bwd_weight(s2, mid_a, dy, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
+                    _bwd_weight(s1, xa, dmid, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
                 return dx, None, None, None, None
         if s2.bank.weight_grads:
             _bwd_weight(s2, mid_a, dy, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
@@ -724,6 +827,8 @@ def resunit_bwd(s1, s2, dy, xa, mid_a, slope, dy_scale=1.0):
             "evt_resunit_bwd")
     if e0 is not None:
         _t1_unit_bwd(e0, m1, m2, xa, wg_in)
+        if wg_in:
+            _t1_elt(_t0(), "fold_partials_multi", (s1.layout.reg_elems + s2.layout.reg_elems) * 4 * 256, m1)
     if wg_in:
         s1.wg_dirty = s2.wg_dirty = True
     elif wg:
@@ -813,9 +918,8 @@ class ResStageFn(torch.autograd.Function):
             if e0 is not None:
                 _t1_multi(e0, "fwd", pairs, x, False)
             cur = outs
-        out = torch.empty_like(x)
-        L.check(lib.evt_add3_scale(L.dt_of(x), L.ptr(cur[0]), L.ptr(cur[1]), L.ptr(cur[2]), C.c_float(scale), L.ptr(out),
-                                   C.c_int64(x.numel()), L.stream_ptr()), "evt_add3_scale")
+        owner = plan[0][0][0][0].module
+        out = _add3(cur[0], cur[1], cur[2], scale, torch.empty_like(x), owner)
         ctx.plan, ctx.slope, ctx.scale = plan, slope, scale
         ctx.save_for_backward(*saved)
         return out
@@ -832,11 +936,9 @@ class ResStageFn(torch.autograd.Function):
         # which jobs accumulate their weight gradients in the launch (all but C = 32 with 11 taps)
         in_k = [[wg and bool(lib.evt_resunit_bwd_supported(C.byref(p), 1)) for p in ps] for _, ps in plan]
         fold_scale = all(all(r) for r in in_k) or not wg
+        owner = plan[0][0][0][0].module
         if not fold_scale:
-            g = torch.empty_like(dy)
-            L.check(lib.evt_add3_scale(L.dt_of(dy), L.ptr(dy), None, None, C.c_float(scale), L.ptr(g),
-                                       C.c_int64(dy.numel()), L.stream_ptr()), "evt_add3_scale")
-            dy = g
+            dy = _add3(dy, None, None, scale, torch.empty_like(dy), owner)
         d = [dy] * nb
         ws = bank.scratch() if wg else None
         for j in range(len(plan) - 1, -1, -1):
@@ -870,6 +972,9 @@ class ResStageFn(torch.autograd.Function):
                                               L.stream_ptr()), "evt_resunit_bwd_multi")
             if e0 is not None:
                 _t1_multi(e0, "bwd_unit", pairs, dy, wg)
+                if any(in_k[j]):       # the second launch of the call: the partial rows added into the gradient images
+                    rows = sum(s1.layout.reg_elems + s2.layout.reg_elems for (s1, s2), k_ in zip(pairs, in_k[j]) if k_)
+                    _t1_elt(_t0(), "fold_partials_multi", rows * 4 * 256, owner)
             nseq, lin = dy.size(0), dy.size(1)
             for s1, s2, xa, mid_a, dyi, dmid in later:
                 _bwd_weight(s2, mid_a, dyi, None, nseq, lin, 1.0, L.ACT_NONE, 1.0)
@@ -877,9 +982,7 @@ class ResStageFn(torch.autograd.Function):
             d = outs
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(dy)
-            L.check(lib.evt_add3_scale(L.dt_of(dy), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), C.c_float(1.0), L.ptr(dx),
-                                       C.c_int64(dy.numel()), L.stream_ptr()), "evt_add3_scale")
+            dx = _add3(d[0], d[1], d[2], 1.0, torch.empty_like(dy), owner)
         return dx, None, None, None, None
 
 
@@ -905,20 +1008,16 @@ class Add3ScaleFn(torch.autograd.Function):
     """(a + b + c) * scale — HiFi-GAN stage mean (models.py:457-466)."""
 
     @staticmethod
-    def forward(ctx, a, b, c, scale):
-        out = torch.empty_like(a)
-        L.check(L.lib().evt_add3_scale(L.dt_of(a), L.ptr(a), L.ptr(b), L.ptr(c), C.c_float(scale), L.ptr(out),
-                                       C.c_int64(a.numel()), L.stream_ptr()), "evt_add3_scale")
-        ctx.scale = scale
+    def forward(ctx, a, b, c, scale, owner=None):
+        out = _add3(a, b, c, scale, torch.empty_like(a), owner)
+        ctx.scale, ctx.owner = scale, owner
         return out
 
     @staticmethod
     def backward(ctx, d):
         d = d.contiguous()
-        g = torch.empty_like(d)
-        L.check(L.lib().evt_add3_scale(L.dt_of(d), L.ptr(d), None, None, C.c_float(ctx.scale), L.ptr(g),
-                                       C.c_int64(d.numel()), L.stream_ptr()), "evt_add3_scale")
-        return g, g, g, None
+        g = _add3(d, None, None, ctx.scale, torch.empty_like(d), ctx.owner)
+        return g, g, g, None, None
 
 
 class GatedActFn(torch.autograd.Function):

@@ -513,7 +513,7 @@ class Generator(nn.Module, _ComputeDtype):
             rs = [b(x) for b in blocks]
             while len(rs) < 3:
                 rs.append(None)
-            x = Add3ScaleFn.apply(rs[0], rs[1], rs[2], 1.0 / self.num_kernels)
+            x = Add3ScaleFn.apply(rs[0], rs[1], rs[2], 1.0 / self.num_kernels, self)
         # F.leaky_relu(x) at models.py:467 uses the DEFAULT slope 0.01, then conv_post, then tanh
         return self.conv_post(x, in_slope=0.01, out_act=L.ACT_TANH)
 

@@ -238,6 +238,18 @@ typedef struct evt_resunit_bwd_job {
 } evt_resunit_bwd_job;
 int evt_resunit_bwd_multi(const evt_resunit_bwd_job* jobs, int32_t njobs, float* ws, int64_t ws_floats, void* stream);
 
+/* The same step for the WIDE vocoder stages (bf16, C in {64, 128}, k in {3, 7, 11}, d in 1..5) with the activated
+ * intermediate kept in LDS: forward in one launch (instead of leaky-relu + two convolutions), and the DATA half of the
+ * backward in one launch -- dmid = (c2^T dy') * lrelu'(mid_a) and dx = (c1^T dmid) * lrelu'(xa) + dy', dy' = dy * dy_scale
+ * rounded to bf16 -- instead of two.  dmid [nseq][L][C] is written for the two weight-gradient launches
+ * (evt_conv1d_bwd_weight on (mid_a, dy') and (xa, dmid)), which stay separate: at these widths a gradient image does not
+ * fit a wave's registers.  Operands as in evt_resunit_fwd / evt_resunit_bwd. */
+int32_t evt_resunit_wide_supported(const evt_resunit_params* p);
+int evt_resunit_wide_fwd(const evt_resunit_params* p, const void* x, const void* w1_reg, const void* w2_reg, const float* b1,
+                         const float* b2, void* xa, void* mid_a, void* y, void* stream);
+int evt_resunit_wide_bwd_data(const evt_resunit_params* p, const void* dy, float dy_scale, const void* xa, const void* mid_a,
+                              const void* w1_alt, const void* w2_alt, void* dmid, void* dx, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Element-wise / reduction helpers of the s2 path.
  * ------------------------------------------------------------------------------------- */

@@ -130,7 +130,7 @@ def cpu_emulation():
 
     class _Add3:
         @staticmethod
-        def apply(a, b, c, scale):
+        def apply(a, b, c, scale, owner=None):
             s = a
             if b is not None:
                 s = s + b

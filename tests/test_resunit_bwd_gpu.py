@@ -205,3 +205,81 @@ def test_grouped_stage_vs_block_by_block(gpu, case):
     assert torch.equal(y_f, y_2) and torch.equal(dx_f, dx_2)
     for n_ in g_f:
         assert torch.equal(g_f[n_], g_2[n_]), n_
+
+
+WIDE = [(C, k, d, L) for C in (64, 128) for (k, d, L) in
+        [(3, 1, 200), (3, 5, 1000), (7, 3, 640), (7, 5, 129), (11, 1, 130), (11, 3, 2048), (11, 5, 777), (11, 5, 64)]]
+
+
+@pytest.mark.parametrize("case", WIDE)
+def test_wide_fused_step_vs_unfused_launches(gpu, case):
+    """C = 64 / 128 (csrc/resunit_wide.hip through ResUnitFn): forward (xa, mid_a, y) and backward (dx, every parameter
+    gradient) of the one-launch-each-way path against the leaky-relu + convolution launches it replaces"""
+    from easevoice_trainer_amd.hip import lib as L
+    from easevoice_trainer_amd.module.models import LRELU_SLOPE
+
+    C_, k, d, Lq = case
+    HC, m, bank, x, dy = _setup(gpu, C_, k, d, Lq)
+    s1, s2 = m[0]._slot, m[1]._slot
+    assert HC._resunit_wide_params(s1, s2, x, LRELU_SLOPE) is not None, "the wide fused path must cover this case"
+    xa_u = HC._lrelu(x, LRELU_SLOPE)
+    mid_u = HC._fwd(s1, xa_u, None, 1.0, L.ACT_LRELU, LRELU_SLOPE)
+    y_u = HC._fwd(s2, mid_u, x, 1.0, L.ACT_NONE, 1.0)
+    dx_u, dmid_u, g_u = _unfused(HC, L, m, bank, xa_u, mid_u, dy, LRELU_SLOPE)
+
+    bank.zero_dw()
+    for c in m:
+        c.weight_v.grad.zero_()
+        c.weight_g.grad.zero_()
+        c.bias.grad.zero_()
+    xg = x.clone().requires_grad_(True)
+    y = HC.res_unit(xg, m[0], m[1], LRELU_SLOPE)
+    xa_f, mid_f = y.grad_fn.saved_tensors
+    y.backward(dy)
+    bank.grads()
+    torch.cuda.synchronize()
+    assert torch.equal(xa_f, xa_u), "lrelu(x)"
+    assert _rel(mid_f, mid_u) < 1e-2, "mid_a: " + _where(mid_f, mid_u)
+    assert _rel(y, y_u) < 1e-2, "y: " + _where(y, y_u)
+    # the unfused backward used ITS mid_a; leaky-relu branch decisions can differ where the two intermediates round to
+    # opposite sides of zero, so dx / gradients are compared loosely here and exactly-gated against the oracle below
+    assert _rel(xg.grad, dx_u) < 3e-2, "dx: " + _where(xg.grad, dx_u)
+    for n_ in g_u:
+        got = dict((f"{ci}.{n}", p_.grad) for ci, c in enumerate(m) for n, p_ in c.named_parameters())[n_]
+        assert _rel(got, g_u[n_]) < 3e-2, f"{n_}: " + _where(got, g_u[n_])
+
+
+@pytest.mark.parametrize("case", [(64, 11, 5, 777), (64, 3, 1, 200), (128, 7, 3, 640), (128, 11, 5, 333)])
+def test_wide_fused_step_vs_oracle(gpu, case):
+    import torch.nn.functional as F
+
+    from easevoice_trainer_amd.module.models import LRELU_SLOPE, get_padding
+
+    C_, k, d, Lq = case
+    HC, m, bank, x, dy = _setup(gpu, C_, k, d, Lq)
+    bank.zero_dw()
+    xg = x.clone().requires_grad_(True)
+    y = HC.res_unit(xg, m[0], m[1], LRELU_SLOPE)
+    xa_f, mid_f = y.grad_fn.saved_tensors
+    y.backward(dy)
+    bank.grads()
+    torch.cuda.synchronize()
+    xo = x.float().cpu().transpose(1, 2).requires_grad_(True)
+    po = [{n_: p_.detach().cpu().clone().requires_grad_(True) for n_, p_ in c.named_parameters()} for c in m]
+    ws = []
+    for q in po:
+        w = O.weight_norm_fold(q["weight_v"], q["weight_g"])
+        ws.append(w + (w.detach().bfloat16().float() - w.detach()))
+    h = F.conv1d(F.leaky_relu(xo, LRELU_SLOPE), ws[0], po[0]["bias"], padding=get_padding(k, d), dilation=d)
+    gate = torch.where(mid_f.float().cpu().transpose(1, 2) > 0, 1.0, LRELU_SLOPE)
+    agree = ((h.detach() > 0) == (mid_f.float().cpu().transpose(1, 2) > 0))
+    assert agree.float().mean().item() >= 0.999, agree.float().mean().item()
+    h = h * gate
+    h = h + (h.detach().bfloat16().float() - h.detach())
+    yo = xo + F.conv1d(h, ws[1], po[1]["bias"], padding=get_padding(k, 1))
+    yo.backward(dy.float().cpu().transpose(1, 2))
+    assert _rel(y.transpose(1, 2), yo) < 3e-2, "y: " + _where(y.transpose(1, 2), yo)
+    assert _rel(xg.grad.transpose(1, 2), xo.grad) < 3e-2, "dx: " + _where(xg.grad.transpose(1, 2), xo.grad)
+    for ci, (c, q) in enumerate(zip(m, po)):
+        for n_, p_ in c.named_parameters():
+            assert _rel(p_.grad, q[n_].grad) < 3e-2, f"{ci}.{n_}: " + _where(p_.grad, q[n_].grad)

@@ -63,7 +63,8 @@ def kernel_profile(run):
     return kernels, seq
 
 
-_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_|resunit_|rows16_)")
+_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_|resunit_|rows16_|add3_scale_kernel|lrelu_kernel|dact_mul_kernel|"
+                   r"fold_partials_multi)")
 
 
 def align_records(rec, seq):
@@ -71,7 +72,8 @@ def align_records(rec, seq):
     order; one stream, so the same order).  Every traced entry point launches exactly one kernel of the conv family
     (plus, for some weight gradients, a column-sum helper), and the library's tags start with that kernel's function
     name -- so the records are a subsequence of the conv-family kernels of the run; conv-family kernels launched by an
-    untraced entry point are stepped over (greedy two-pointer match on the function name)."""
+    untraced entry point are stepped over (greedy two-pointer match on the function name).  The element-wise launches of
+    hip/conv.py and the fold launch behind a fused ResBlock backward have records of their own (kind "elt")."""
     base = lambda n: n.split("<")[0].strip()
     main = [(base(short_name(n)), us) for _t, n, us in seq if _MAIN.match(base(short_name(n)))]
     out, j = {}, 0
@@ -139,7 +141,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
 
     agg = {}
     dec_mods = {id(m) for m in eng.net_g.dec.modules()}
-    voc = dict(us=0.0, bytes=0.0, flops=0.0, calls=0)
+    voc = dict(us=0.0, bytes=0.0, flops=0.0, calls=0, elt_us=0.0, elt_calls=0)
     for i, r in enumerate(rec):
         tag, kind, flops, nbytes, _e0, _e1, _shape, mod = r
         us = dur_us(i, r)
@@ -148,6 +150,11 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
             voc["bytes"] += nbytes
             voc["flops"] += flops
             voc["calls"] += 1
+            if kind == "elt":
+                voc["elt_us"] += us
+                voc["elt_calls"] += 1
+        if kind == "elt":
+            continue                       # element-wise launches count for `dec`, not for the dominant-kernel pick
         a = agg.setdefault(tag, dict(us=0.0, calls=0, flops=0.0, bytes=0.0))
         a["us"] += us
         a["calls"] += 1
@@ -171,11 +178,15 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         r_voc = dict(bound="hbm", achieved=alg / vsec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=alg / vsec / 1e9 / HBM_PEAK_GBS, ms_per_step=voc["us"] / 1e3 / n_steps,
                      launches_per_step=voc["calls"] / n_steps, algorithmic_gb_per_step=alg / n_steps / 1e9,
+                     elementwise_ms_per_step=voc["elt_us"] / 1e3 / n_steps,
+                     elementwise_launches_per_step=voc["elt_calls"] / n_steps,
                      bytes_with_saved_reads_gb_per_step=voc["bytes"] / n_steps / 1e9,
                      gbs_with_saved_reads=voc["bytes"] / vsec / 1e9, tflops=voc["flops"] / vsec / 1e12,
                      note="algorithmic bytes = SURVEY 8(d): 3 x (52.98 M x B + 14.66 M) elements, every conv's input "
-                          "and output once per direction; conv launches of `dec` only (its element-wise launches are "
-                          "in the step time, not in this sum)")
+                          "and output once per direction; time and launches = EVERY launch of `dec`: convolutions, "
+                          "fused / grouped ResBlock steps, and its element-wise launches (leaky-relu copies, stage "
+                          "means, activation derivatives -- listed separately as elementwise_*); the fold launch "
+                          "behind a fused backward is inside that backward's time")
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

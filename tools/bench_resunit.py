@@ -13,8 +13,11 @@ from easevoice_trainer_amd.hip import lib as L    # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    for C_, Lq in ((16, 20480), (32, 10240)):
-        for k, d in ((3, 1), (3, 5), (7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11, 5)):
+    wide_fwd = "--wide-fwd" in sys.argv       # only the fused forward of the wide shapes (tile-shape experiments)
+    shapes = ((64, 5120), (128, 2560)) if wide_fwd else ((16, 20480), (32, 10240), (64, 5120), (128, 2560))
+    for C_, Lq in shapes:
+        for k, d in (((3, 1), (7, 3), (11, 5)) if wide_fwd else
+                     ((3, 1), (3, 5), (7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11, 5))):
             pad = lambda kk, dd: (kk * dd - dd) // 2
             m = torch.nn.ModuleList([HC.EvtConv1d(C_, C_, k, dilation=d, padding=pad(k, d), weight_norm=True),
                                      HC.EvtConv1d(C_, C_, k, dilation=1, padding=pad(k, 1), weight_norm=True)]).to(dev)
@@ -45,10 +48,16 @@ def main():
                 return HC._bwd_data(s1, dmid, None, xa, dy, 16, Lq, 0.1, L.ACT_NONE, 1.0)
 
             def bwd_fused():
-                return HC.resunit_bwd(s1, s2, dy, xa, mid_a, 0.1, 1.0)
+                if C_ <= 32:
+                    return HC.resunit_bwd(s1, s2, dy, xa, mid_a, 0.1, 1.0)
+                xg = x.clone().requires_grad_(True)
+                y = HC.res_unit(xg, m[0], m[1], 0.1)       # fwd + bwd through the autograd node (wide path)
+                y.backward(dy)
+                return xg.grad
 
-            out = {}
-            for name, fn in (("unfused", unfused), ("fused", fused), ("bwd_unfused", bwd_unfused), ("bwd_fused", bwd_fused)):
+            out = dict(unfused=0.0, bwd_unfused=0.0, bwd_fused=0.0)
+            for name, fn in ((("fused", fused),) if wide_fwd else
+                             (("unfused", unfused), ("fused", fused), ("bwd_unfused", bwd_unfused), ("bwd_fused", bwd_fused))):
                 for _ in range(3):
                     fn()
                 torch.cuda.synchronize()
