@@ -277,6 +277,7 @@ int evt_gated_act_fwd(int32_t dtype, const void* xin, const void* g, void* acts,
 int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void* dacts, void* dxin, float* dg,
                       int32_t nseq, int32_t len, int32_t H, void* stream);
 
+
 /* STFT magnitude + mel + log of the generated waveform, src/easevoice/module/mel_processing.py:93-142:
  * reflect-pad (n_fft-hop)/2, hann window, n_fft-point real DFT per frame (radix-2 in LDS, wavefront
  * shuffles for the short butterflies), sqrt(re^2+im^2+1e-6), mel basis [n_mels][n_fft/2+1] matmul,
