@@ -16,6 +16,7 @@ import torch
 from torch.nn import functional as F
 
 from ..hip import lib as L
+from ..hip.linear import LinearBank, gemm_fwd
 from .ops import AddLayerNormFn, PrefixLMAttentionFn
 
 MAX_STEPS = 1500          # t2s_model.py:822
@@ -126,13 +127,43 @@ class T2SInfer:
 
     def __init__(self, model):
         self.model = model
-        self._w, self._sessions = None, {}
+        self._w, self._sessions, self._dense = None, {}, None
 
     def weights(self, dtype):
         if self._w is None or self._w[0] != dtype or self._w[1].stamp != _Weights.stamp_of(self.model):
             self._w = (dtype, _Weights(self.model, dtype))
             self._sessions.clear()          # captured graphs hold pointers into the old copies
         return self._w[1]
+
+    def dense(self, dtype, device):
+        """x, weight[, relu] -> act(x W^T + b) for the prompt pass (T2SBlock.process_prompt, t2s_model.py:124-185 of the
+        reference: five F.linear per block) on the library's GEMM entry points.  Inside a trainer the model's own
+        LinearBank serves (same images as the training forward); a bare model (inference/t2s.py) gets a bank of its own
+        here, rebuilt when the weights were replaced or written (load_state_dict)."""
+        m = self.model
+        bank = getattr(m, "_bank", None)
+        if bank is None or bank.dtype != dtype or bank.device != torch.device(device):
+            stamp = _Weights.stamp_of(m)
+            if self._dense is None or self._dense[0] != (dtype, str(device)) or self._dense[2] != stamp:
+                keep = {id(w): getattr(w, "_evt_slot", None) for _n, w, _b in m.dense_specs()}
+                own = LinearBank(m.dense_specs(), dtype, device)
+                slots = {id(s.weight): s for s in own.slots}
+                for _n, w, _b in m.dense_specs():       # a training bank of another dtype keeps its slots on the weights
+                    if keep[id(w)] is not None:
+                        w._evt_slot = keep[id(w)]
+                    else:
+                        del w._evt_slot
+                self._dense = ((dtype, str(device)), own, stamp, slots)
+            bank, slots = self._dense[1], self._dense[3]
+        else:
+            slots = None
+        bank.prepare()
+
+        def run(x, weight, relu=False):
+            slot = slots[id(weight)] if slots is not None else weight._evt_slot
+            return gemm_fwd(slot, x, relu=relu)
+
+        return run
 
     def session(self, B, Lneed, yneed, dtype, device):
         Lmax, ymax = -(-Lneed // 512) * 512, -(-yneed // 512) * 512
@@ -158,10 +189,10 @@ class T2SInfer:
         x_lens = [int(x.numel()) for x in xs]
         x_len = max(x_lens)
         rows = []
+        dense = self.dense(cd, dev)           # the library's GEMMs on prepared weight images (hip/linear.py), no vendor BLAS
         for x, bert in zip(xs, berts):
             xe = m.ar_text_embedding(x.unsqueeze(0))
-            xe = xe + F.linear(bert.transpose(0, 1).unsqueeze(0).to(cd), m.bert_proj.weight.to(cd), m.bert_proj.bias.to(cd)
-                               ).to(xe.dtype)
+            xe = xe + dense(bert.transpose(0, 1).unsqueeze(0).to(cd).contiguous(), m.bert_proj.weight).to(xe.dtype)
             xe = m.ar_text_position(xe).squeeze(0)
             rows.append(F.pad(xe, (0, 0, 0, x_len - xe.size(0))))      # padded text positions: masked as keys below
         xe = torch.stack(rows, dim=0)
@@ -184,14 +215,13 @@ class T2SInfer:
         yl = torch.full((B,), y_len, dtype=torch.int32, device=dev)
         for i, lyr in enumerate(m.h.layers):
             w = W.layers[i]
-            qkv = F.linear(xy, lyr.self_attn.in_proj_weight.to(cd), lyr.self_attn.in_proj_bias.to(cd)).contiguous()
+            qkv = dense(xy, lyr.self_attn.in_proj_weight)
             S.kc[i, :, :src_len].copy_(qkv[..., S.E:2 * S.E])
             S.vc[i, :, :src_len].copy_(qkv[..., 2 * S.E:])
             o = PrefixLMAttentionFn.apply(qkv, xl, yl, x_len, S.H, 0.0, 0)
-            sa = F.linear(o, lyr.self_attn.out_proj.weight.to(cd), lyr.self_attn.out_proj.bias.to(cd))
+            sa = dense(o.contiguous(), lyr.self_attn.out_proj.weight)
             xy = AddLayerNormFn.apply(xy, sa, w["g1"], w["be1"], w["eps1"])
-            ff = F.linear(F.relu(F.linear(xy, lyr.linear1.weight.to(cd), lyr.linear1.bias.to(cd))),
-                          lyr.linear2.weight.to(cd), lyr.linear2.bias.to(cd))
+            ff = dense(dense(xy.contiguous(), lyr.linear1.weight, relu=True), lyr.linear2.weight)
             xy = AddLayerNormFn.apply(xy, ff, w["g2"], w["be2"], w["eps2"])
         # ---- state ----
         S.y.zero_()

@@ -377,12 +377,25 @@ def cpu_emulation_decode():
         self.logits.copy_(x @ W.wpred.float().t())
         sample_embed_advance(self, W, sp, noise, pe, 1)
 
+    def dense(self, dtype, device):
+        bias = {id(w): b for _n, w, b in self.model.dense_specs()}
+
+        def run(x, weight, relu=False):
+            b = bias[id(weight)]
+            o = x.float() @ weight.float().t() + (b.float() if b is not None else 0.0)
+            return (o.clamp(min=0) if relu else o).to(x.dtype)
+
+        return run
+
+    saved_dense = TI.T2SInfer.dense
+    TI.T2SInfer.dense = dense
     DS._gemv, DS._sample_embed_advance, DS.step_launches = gemv, sample_embed_advance, step_launches
     TI.PrefixLMAttentionFn, TI.AddLayerNormFn = _Attn, _LN
     os.environ["EVT_DECODE_GRAPH"] = "0"
     try:
         yield
     finally:
+        TI.T2SInfer.dense = saved_dense
         DS._gemv, DS._sample_embed_advance, DS.step_launches, TI.PrefixLMAttentionFn, TI.AddLayerNormFn = saved[:5]
         if saved[5] is None:
             os.environ.pop("EVT_DECODE_GRAPH", None)

@@ -9,6 +9,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime loads: easevoice_trainer_amd/__init__.py
+
 import torch
 import yaml
 
