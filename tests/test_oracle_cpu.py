@@ -163,3 +163,36 @@ def test_oracle_scaled_adam_matches_reference_trajectory():
         opt.lr = 0.002
         for k in params:
             assert torch.allclose(params[k], want[k], rtol=2e-5, atol=1e-6), (step, k)
+
+
+def test_product_mel_filterbank_is_the_oracle_filterbank_bit_for_bit():
+    """the filterbank the product multiplies with (module/mel_processing.py::mel_filterbank) against the oracle's restatement
+    of librosa 0.9.2's `filters.mel` (oracle/melbank.py): every float32 identical, at the s2.json configuration and two
+    others -- the GPU test of spec_to_mel then checks the matmul against THIS matrix, not against itself"""
+    import numpy as np
+
+    from easevoice_trainer_amd.module import mel_processing as PM
+    from oracle.melbank import slaney_mel
+
+    for sr, n_fft, n_mels, fmin, fmax in ((32000, 2048, 128, 0.0, None), (22050, 1024, 80, 0.0, 8000.0),
+                                          (16000, 512, 40, 50.0, 7600.0)):
+        a, b = PM.mel_filterbank(sr, n_fft, n_mels, fmin, fmax), slaney_mel(sr, n_fft, n_mels, fmin, fmax)
+        assert a.dtype == np.float32 and a.shape == b.shape == (n_mels, 1 + n_fft // 2)
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+
+
+def test_mel_filterbank_known_answer_computed_by_hand():
+    """sr = 2000, n_fft = 8 (bins 0, 250, 500, 750, 1000 Hz), two filters up to 1000 Hz: everything sits in the LINEAR part
+    of the slaney scale (mel = f / (200/3)), so the edges are 0, 1000/3, 2000/3, 1000 Hz, the triangles are
+    (0, 333.3, 666.7) and (333.3, 666.7, 1000), and the slaney norm is 2 / 666.67 = 0.003 for both:
+        filter 0: bin 250 -> min(250/333.3, 416.7/333.3) = 0.75,  bin 500 -> min(1.5, 166.7/333.3) = 0.5
+        filter 1: bin 500 -> min(166.7/333.3, 1.5) = 0.5,         bin 750 -> min(1.25, 250/333.3) = 0.75"""
+    import numpy as np
+
+    from easevoice_trainer_amd.module import mel_processing as PM
+    from oracle.melbank import slaney_mel
+
+    want = np.array([[0, 0.75 * 0.003, 0.5 * 0.003, 0, 0], [0, 0, 0.5 * 0.003, 0.75 * 0.003, 0]], np.float64)
+    for fn in (PM.mel_filterbank, slaney_mel):
+        got = fn(2000, 8, 2, 0.0, 1000.0).astype(np.float64)
+        assert got.shape == (2, 5) and np.allclose(got, want, rtol=1e-6, atol=1e-9), got

@@ -87,12 +87,112 @@ def _s2_grads(gpu, dtype):
     return gg, gd
 
 
+# s2 generator tensors allowed below 0.995, each with its reason (measured round 4 on the C1 batch of 2 items; bound =
+# measured - 0.01).  None of them is a small-norm tensor: their per-element RMS is 0.7e-3 .. 5.7e-3, the model's typical.
+S2_G_ALLOW = {
+    # the vocoder's first convolution: its dy has travelled back through 90 bf16 layers and a 640-fold up-sampling, and
+    # the gradient is a sum over only 2 x 32 positions -- nothing averages the rounding noise out.  An INDEPENDENT bf16
+    # implementation (torch's own kernels through the oracle's vocoder) lands on the same figure:
+    # test_vocoder_bf16_noise_floor_of_an_independent_implementation below.
+    "dec.conv_pre.weight": (0.955, 0.9690),
+    # the relative-position attention of the text encoder on 2 x 40 phonemes: 80 rows behind softmax + bf16 P
+    "enc_p.encoder2.attn_layers.0.conv_q.weight": (0.979, 0.9893),
+    "enc_p.encoder2.attn_layers.0.conv_k.weight": (0.979, 0.9898),
+    # first layers of the ssl branch: 2 x 100 frames, the deepest backward path of enc_p (MRTE, two encoders, flow)
+    "enc_p.ssl_proj.weight": (0.984, 0.9938),
+    "enc_p.encoder_ssl.ffn_layers.2.conv_1.weight": (0.984, 0.9946),
+    "enc_p.encoder_ssl.norm_layers_1.0.gamma": (0.984, 0.9948),
+    "enc_p.encoder_ssl.ffn_layers.1.conv_1.weight": (0.984, 0.9949),
+}
+
+
 def test_s2_every_parameter_bf16_vs_fp32(gpu):
     gg32, gd32 = _s2_grads(gpu, torch.float32)
     gg16, gd16 = _s2_grads(gpu, torch.bfloat16)
     for what, a, b in (("G", gg32, gg16), ("D", gd32, gd16)):
         cs = _compare(a, b, 1e-4, what)
         _judge(f"s2 {what}", cs)
+        # every tensor >= 0.995 except the named ones, which must hold their own bound
+        allow = S2_G_ALLOW if what == "G" else {}
+        bad = [(round(c, 4), k) for c, k in cs if c < (allow[k][0] if k in allow else 0.995)]
+        assert not bad, (what, bad)
+
+
+def test_vocoder_bf16_noise_floor_of_an_independent_implementation(gpu):
+    """Is 0.97 for dec.conv_pre.weight this library's error or bfloat16's?  The oracle's vocoder (oracle/s2_step.py::
+    generator: plain torch convolutions, torch's own GPU kernels -- test infrastructure) is run in fp32 and with every
+    tensor in bf16 on the same weights and input; its bf16-vs-fp32 cosine per parameter is the yardstick: the library's
+    bf16 gradient must be as close to the fp32 truth as that independent implementation's, within 0.02."""
+    from easevoice_trainer_amd.hip import conv as HC
+    from easevoice_trainer_amd.module.models import Generator
+    from oracle import ops as O
+    from oracle import s2_step as OS
+
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))["model"]
+    torch.manual_seed(7)
+    B, T = 2, 32
+    z = torch.randn(B, hps["inter_channels"], T, device=gpu).bfloat16().float()
+    ge = torch.randn(B, hps["gin_channels"], 1, device=gpu).bfloat16().float()
+    wgt = torch.randn(B, 1, T * 640, device=gpu)
+
+    def ours(dtype):
+        torch.manual_seed(8)
+        dec = Generator(hps["inter_channels"], hps["resblock"], hps["resblock_kernel_sizes"], hps["resblock_dilation_sizes"],
+                        hps["upsample_rates"], hps["upsample_initial_channel"], hps["upsample_kernel_sizes"],
+                        gin_channels=hps["gin_channels"]).to(gpu)
+        fill_module(dec, 5)
+        for m in dec.modules():
+            if hasattr(m, "cd"):
+                m.cd = dtype
+        bank = HC.WeightBank(dec, dtype, gpu)
+        bank.build_tables()
+        bank.fold()
+        bank.zero_dw()
+        y = dec(z.transpose(1, 2).to(dtype).contiguous(), g=ge.squeeze(-1).to(dtype))
+        (y.float().transpose(1, 2) * wgt).sum().backward()
+        bank.grads()
+        torch.cuda.synchronize()
+        return dec, {n: p.grad.detach().float().clone() for n, p in dec.named_parameters() if p.grad is not None}
+
+    dec, g32 = ours(torch.float32)
+    _dec16, g16 = ours(torch.bfloat16)
+
+    def oracle(dtype):
+        sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in dec.state_dict(keep_vars=True).items()}
+        s = OS.SD(sd)
+        if dtype == torch.bfloat16:
+            # weight_norm folded in fp32, then every operand handed to torch's kernels in bf16 (what autocast would do)
+            bf = torch.bfloat16
+
+            class Cast(OS.SD):
+                def __getitem__(self, k):
+                    return OS.SD.__getitem__(self, k).to(bf)
+
+                def w(self, name):
+                    if self.has(name + ".weight"):
+                        return OS.SD.__getitem__(self, name + ".weight").to(bf)
+                    return O.weight_norm_fold(OS.SD.__getitem__(self, name + ".weight_v"),
+                                              OS.SD.__getitem__(self, name + ".weight_g")).to(bf)
+
+                def sub(self, k):
+                    return Cast(self.sd, self.p + k + ".")
+
+            s = Cast(sd)
+        y = OS.generator(s, z.to(dtype), ge.to(dtype), hps)
+        (y.float() * wgt).sum().backward()
+        return {k: v.grad.detach().float() for k, v in sd.items() if v.grad is not None}
+
+    o32, o16 = oracle(torch.float32), oracle(torch.bfloat16)
+    report = []
+    for k in ("conv_pre.weight", "ups.0.weight_v", "resblocks.0.convs1.0.weight_v", "resblocks.14.convs2.2.weight_v",
+              "conv_post.weight"):
+        ref = o32[k]
+        c_lib, c_torch = _cos(ref, g16[k]), _cos(ref, o16[k])
+        c_fp32 = _cos(ref, g32[k])
+        report.append((k, round(c_fp32, 5), round(c_lib, 4), round(c_torch, 4)))
+        assert c_fp32 > 0.9999, (k, c_fp32)                       # the fp32 library path IS the oracle
+        assert c_lib >= c_torch - 0.02, report
+    print("vocoder bf16 cosine to the fp32 oracle (name, library fp32, library bf16, torch bf16):", report)
 
 
 def _s1_grads(gpu, dtype):
