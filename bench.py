@@ -98,6 +98,8 @@ def run_s2(args, world, rank, local):
         out = step()
     if world > 1:
         torch.distributed.barrier()
+        reducer.reset_stats()
+        reducer.timing = dev.type == "cuda"        # HIP events around every wait for the side stream: the exposed part
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -106,7 +108,9 @@ def run_s2(args, world, rank, local):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm = None
     if world > 1:
+        comm = reducer.comm_report(args.steps)      # this rank's view; the line is rank 0's
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -119,12 +123,16 @@ def run_s2(args, world, rank, local):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"s2 SoVITS generator+discriminator GAN step, batch={B}/GPU, {args.clip_seconds} s 32 kHz "
                                f"clips (T={T} frames), configs/s2.json, random-init weights",
-                   "global_batch": world * B, "parallelism": f"dp{world}",
+                   "global_batch": world * B, "parallelism": reducer.describe() if reducer is not None else "dp1",
                    "launch": (f"hip-graph replay ({len(eng._program())} graphs/step"
                               f"{', gradient reductions between them' if world > 1 else ''})") if eng.graphs_enabled else "eager"},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
+    if comm is not None:
+        # gradient exchange per step on rank 0: collectives issued, MiB moved, and how long the compute stream stood
+        # waiting for them (what the overlap with the backward did not hide)
+        res["comm"] = comm
     return res, eng, step
 
 

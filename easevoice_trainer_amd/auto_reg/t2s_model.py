@@ -140,8 +140,13 @@ class TransformerEncoder(nn.Module):
         self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
                                      for _ in range(num_layers)])
 
+    grad_hook = None          # callable(block index): the gradient has reached the input of that block (train/s1_engine.py
+    grad_hook_blocks = ()     # uses it to start reducing the finished part of the gradient arena); the blocks to watch
+
     def forward(self, x, x_lens, y_lens, x_len, seed):
         for i, layer in enumerate(self.layers):
+            if i in self.grad_hook_blocks and x.requires_grad:
+                x.register_hook(lambda g, i=i: (self.grad_hook(i) if self.grad_hook is not None else None, None)[1])
             x = layer(x, x_lens, y_lens, x_len, seed + 7919 * i)
         return x
 

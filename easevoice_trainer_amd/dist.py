@@ -28,33 +28,67 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None, rsag=None):
-        """rsag (default: EVT_DP_RSAG=1): every bucket as reduce-scatter + all-gather, in place, instead of one
-        all-reduce.  On xGMI every GPU has a direct link to each of the other seven: a ring all-reduce is bound by ONE
-        link per hop, while the two halves of reduce-scatter / all-gather move 1/world of the bucket to / from every peer
-        at once.  The results are the same sums (per element: one reduction over the ranks either way); the variant is
-        equality-tested against all_reduce on gloo (tests/test_host_cpu.py) and stays opt-in until it has met RCCL."""
+    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None, rsag=None, rsag_min_bytes: int = 8 << 20):
+        """rsag (default: EVT_DP_RSAG = 0 | 1 | auto): a bucket as reduce-scatter + all-gather instead of one all-reduce.
+        On xGMI every GPU has a direct link to each of the other seven: a ring all-reduce is bound by ONE link per hop,
+        while the two halves of reduce-scatter / all-gather move 1/world of the bucket to / from every peer at once; below a
+        few MiB the second collective's latency costs more than the links give, so `auto` keeps all-reduce for buckets
+        under rsag_min_bytes (and for worlds of two, where there is one link either way).  The results are the same sums
+        (per element one reduction over the ranks either way); equality-tested against all_reduce on gloo
+        (tests/test_host_cpu.py).  Default 0 until the variant has met RCCL on more than one GPU.
+        The reducer keeps count of what it issued (collectives, bytes, which kind) and -- with timing on -- of how long
+        the compute stream had to wait for the side stream: bench.py prints both."""
         self.world = world_size
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
-        self.rsag = (os.environ.get("EVT_DP_RSAG", "0") == "1") if rsag is None else bool(rsag)
+        mode = os.environ.get("EVT_DP_RSAG", "0") if rsag is None else rsag
+        self.rsag_mode = {True: "1", False: "0"}.get(mode, str(mode))
+        if self.rsag_mode not in ("0", "1", "auto"):
+            raise ValueError(f"EVT_DP_RSAG / rsag must be 0, 1 or auto, got {mode!r}")
+        self.rsag_min_elems = max(1, rsag_min_bytes // 4)
         self._pending = []
         self._stream = None
+        self._shards = {}
+        self.stats = {"all_reduce": 0, "rs_ag": 0, "bytes": 0}
+        self.timing = False
+        self._waits = []
+
+    @property
+    def rsag(self):
+        return self.rsag_mode != "0"
+
+    def _use_rsag(self, n):
+        if self.rsag_mode == "1":
+            return n >= self.world
+        return self.rsag_mode == "auto" and self.world > 2 and n >= max(self.world, self.rsag_min_elems)
 
     def _sum_bucket(self, t):
         """sum the 1-D contiguous bucket `t` over the group, in place"""
-        if not self.rsag or t.numel() < self.world:
+        self.stats["bytes"] += t.numel() * t.element_size()
+        if not self._use_rsag(t.numel()):
+            self.stats["all_reduce"] += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return
+        self.stats["rs_ag"] += 1
         w = self.world
-        rank = dist.get_rank(self.group)
         chunk = t.numel() // w
         body = t[: chunk * w]
-        mine = body[rank * chunk: (rank + 1) * chunk]       # in place: shard r of the input is rank r's output
+        # the reduced shard lands in a buffer of its own (an output aliasing the input is something only gloo has run), the
+        # all-gather then writes every rank's shard back over the bucket
+        key = (chunk, t.dtype, t.device)
+        mine = self._shards.get(key)
+        if mine is None:
+            mine = self._shards[key] = torch.empty(chunk, dtype=t.dtype, device=t.device)
         dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_gather_into_tensor(body, mine, group=self.group)
         if chunk * w < t.numel():                           # fewer than `world` leftover elements
             dist.all_reduce(t[chunk * w:], op=dist.ReduceOp.SUM, group=self.group)
+
+    def describe(self):
+        """how gradients are exchanged, for the bench line's config.parallelism"""
+        kind = {"0": "all-reduce", "1": "reduce-scatter + all-gather",
+                "auto": f"reduce-scatter + all-gather for buckets >= {self.rsag_min_elems * 4 >> 20} MiB, all-reduce below"}
+        return f"dp{self.world}, {kind[self.rsag_mode]}, buckets of {self.bucket_elems * 4 >> 20} MiB"
 
     def _side_stream(self, device):
         if self._stream is None and device.type == "cuda":
@@ -67,7 +101,8 @@ class GradReducer:
 
     def all_reduce(self, flat: torch.Tensor, async_op: bool = False, average: bool = False):
         """sum `flat` (1-D contiguous) over the group, in place.  async_op=True: enqueue on a side stream and return;
-        call wait() before the optimiser reads the buffer."""
+        call wait() before the optimiser reads the buffer.  average=True: the 1/world pass rides on the same stream right
+        behind the collectives (off the compute stream when async)."""
         if self.world == 1:
             return
         assert flat.dim() == 1 and flat.is_contiguous()
@@ -88,8 +123,30 @@ class GradReducer:
 
     def wait(self):
         if self._stream is not None and self._pending:
-            torch.cuda.current_stream().wait_stream(self._stream)
+            cur = torch.cuda.current_stream()
+            if self.timing and not torch.cuda.is_current_stream_capturing():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._stream)
+                e1.record(cur)
+                self._waits.append((e0, e1))
+            else:
+                cur.wait_stream(self._stream)
         self._pending.clear()
+
+    def comm_report(self, steps: int):
+        """{collectives, MiB and exposed wait per step}: the wait is what the compute stream stood still for at wait()
+        (HIP events around it; needs timing = True and a synchronised device)"""
+        ms = sum(a.elapsed_time(b) for a, b in self._waits)
+        n = max(1, steps)
+        out = {"all_reduce_per_step": self.stats["all_reduce"] / n, "rs_ag_per_step": self.stats["rs_ag"] / n,
+               "mib_per_step": self.stats["bytes"] / n / (1 << 20),
+               "exposed_wait_ms_per_step": (ms / n) if self._waits else None, "waits_per_step": len(self._waits) / n}
+        return out
+
+    def reset_stats(self):
+        self.stats = {"all_reduce": 0, "rs_ag": 0, "bytes": 0}
+        self._waits = []
 
     def broadcast_params(self, flat: torch.Tensor, src: int = 0):
         """one-time parameter broadcast from rank `src` (DDP's wrap-time broadcast)"""

@@ -1,8 +1,14 @@
 """The s1 training micro-step (Text2SemanticLightningModule.training_step,
 src/easevoice/soundstorm/auto_reg/models/t2s_lightning_module.py:41-89) without Lightning: manual optimisation,
 gradients accumulated in the flat arena, ScaledAdam + the pinned-LR schedule, optimiser step on
-`batch_idx > 0 and batch_idx % 4 == 0` exactly like the reference.  Data-parallel: ONE all-reduce of the flat gradient
-arena per optimiser step (the reference all-reduces on each of the accumulation micro-batches)."""
+`batch_idx > 0 and batch_idx % 4 == 0` exactly like the reference.  Data-parallel: the flat gradient arena is reduced
+once per optimiser step (the reference all-reduces on each of the accumulation micro-batches), in pieces that start
+while the last micro-batch's backward is still running: the arena is in parameter order (embeddings, blocks 0..23,
+predict layer), the backward walks the blocks from 23 down, so when the gradient reaches the input of block k the
+ranges of blocks k+1.. and of the predict layer are final -- they go to the side stream (sum + the 1/world scale) and
+the rest follows after the backward (EVT_DP_S1_CUTS: comma-separated block indices, default "16,8"; "" = one piece)."""
+import os
+
 import torch
 
 from ..auto_reg.optim import ScaledAdam, WarmupCosineLRSchedule
@@ -33,34 +39,75 @@ class S1Engine:
         self._views = [(p, p.grad) for p in self.model.parameters()]
         for p, v in self._views:       # the GEMM weight-gradient launches accumulate straight into these (hip/linear.py)
             p._evt_grad_view = v
+        # overlapped reduction: cut points (block indices, descending) and where each block's parameters start in the arena
+        cuts = os.environ.get("EVT_DP_S1_CUTS", "16,8")
+        nl = len(self.model.h.layers)
+        self._cuts = sorted({int(c) for c in cuts.split(",") if c.strip() != "" and 0 <= int(c) < nl - 1}, reverse=True)
+        names = [n for n, _ in self.model.named_parameters()]
+        self._block_start = {}
+        for i in range(nl):
+            first = next(n for n in names if n.startswith(f"h.layers.{i}."))
+            self._block_start[i] = self.arena.offsets[first]
+        self._param_off = [self.arena.offsets[n] for n in names]
+        self._reduced_from = None      # arena offset from which the gradients are already with the side stream
 
     def micro_step(self, batch: dict, batch_idx: int):
         """one micro-batch: forward_old (or the DPO `forward` when config train.if_dpo, t2s_lightning_module.py:44) +
         backward (+ optimiser step on the reference's schedule)"""
         fwd = self.model.forward if self.config.get("train", {}).get("if_dpo", False) is True else self.model.forward_old
-        loss, acc = fwd(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
-                        batch["semantic_ids_len"], batch["bert_feature"])
+        stepping = batch_idx > 0 and batch_idx % 4 == 0
+        overlap = stepping and self.reducer is not None and self.reducer.world > 1 and bool(self._cuts)
+        # the forward plants the tensor hooks at the cut blocks' inputs
+        self.model.h.grad_hook_blocks = tuple(self._cuts) if overlap else ()
+        try:
+            loss, acc = fwd(batch["phoneme_ids"], batch["phoneme_ids_len"], batch["semantic_ids"],
+                            batch["semantic_ids_len"], batch["bert_feature"])
+        finally:
+            self.model.h.grad_hook_blocks = ()
         # autograd keeps the produced gradient tensors (no per-parameter `grad += new` launch); they are accumulated
-        # into the flat arena with one multi-tensor add
+        # into the flat arena with one multi-tensor add (per reduced piece when the reduction overlaps the backward)
         for p, _v in self._views:
             p.grad = None
-        loss.backward()
-        dst, src = [], []
+        self._reduced_from = None
+        self.model.h.grad_hook = self._piece_done if overlap else None
+        try:
+            loss.backward()
+        finally:
+            self.model.h.grad_hook = None
+        hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
+        self._gather(0, hi)
         for p, v in self._views:
-            if p.grad is not None:
-                dst.append(v)
-                src.append(p.grad if p.grad.dtype == v.dtype else p.grad.to(v.dtype))
             p.grad = v
-        if dst:
-            torch._foreach_add_(dst, src)
         stepped = False
-        if batch_idx > 0 and batch_idx % 4 == 0:
-            if self.reducer is not None:
-                self.reducer.all_reduce(self.arena.grad)
-                self.arena.grad.mul_(1.0 / self.reducer.world)
+        if stepping:
+            if self.reducer is not None and self.reducer.world > 1:
+                self.reducer.all_reduce(self.arena.grad[:hi], async_op=self.arena.grad.is_cuda, average=True)
+                self.reducer.wait()
             self.optimizer.step()
             self.bank.mark_dirty()        # weights written through raw pointers: refold the GEMM images on next use
             self.optimizer.zero_grad()
             self.scheduler.step()
             stepped = True
         return loss.detach(), acc.detach(), stepped
+
+    def _gather(self, lo, hi):
+        """add the gradient tensors autograd produced for the parameters in arena range [lo, hi) into their arena views"""
+        dst, src = [], []
+        for (p, v), o in zip(self._views, self._param_off):
+            if lo <= o < hi and p.grad is not None and p.grad is not v:
+                dst.append(v)
+                src.append(p.grad if p.grad.dtype == v.dtype else p.grad.to(v.dtype))
+                p.grad = None
+        if dst:
+            torch._foreach_add_(dst, src)
+
+    def _piece_done(self, block):
+        """called (from a tensor hook) when the gradient has reached the input of `block`: everything behind block + 1 in
+        the arena is final -> gather it and hand it to the side stream"""
+        lo = self._block_start[block + 1]
+        hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
+        if lo >= hi:
+            return
+        self._gather(lo, hi)
+        self.reducer.all_reduce(self.arena.grad[lo:hi], async_op=self.arena.grad.is_cuda, average=True)
+        self._reduced_from = lo

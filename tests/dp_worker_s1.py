@@ -16,7 +16,7 @@ from util_fill import fill_module  # noqa: E402
 
 def small_cfg():
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
-    cfg["model"].update(hidden_dim=64, embedding_dim=64, head=4, n_layer=2, linear_units=256)
+    cfg["model"].update(hidden_dim=64, embedding_dim=64, head=4, n_layer=4, linear_units=256)
     return cfg
 
 
@@ -48,6 +48,9 @@ def main():
             eng.reducer.broadcast_params(eng.arena.param)
             stepped = [eng.micro_step(batch(rank, i), i)[2] for i in range(5)]
             assert stepped == [False] * 4 + [True]
+            # one collective per piece (the test model is far below the bucket size): three with two cuts, one without
+            pieces = 1 + len([c for c in os.environ.get("EVT_DP_S1_CUTS", "16,8").split(",") if c.strip() != "" and int(c) < 3])
+            assert eng.reducer.stats["all_reduce"] == pieces, (eng.reducer.stats, pieces)
         else:                                 # the same ten micro-batches in one process, mean of the two ranks' sums
             for r in range(2):
                 for i in range(5):

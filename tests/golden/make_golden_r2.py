@@ -10,7 +10,9 @@ read-only through oracle/refshim.py):
   s1_c3.pt        BASELINE config 3 sequence shape (256 phonemes + 768 semantic tokens) at B = 2 (the CPU reference needs
                   ~6.5 GB per item at L = 1024): loss, top-3 accuracy, gradient sums per block, gradient slices
 
-  python tests/golden/make_golden_r2.py [adamw] [c2] [s1c3]
+  s1_c3_b4.pt     the same at B = 4 with four different (text, semantic) length pairs
+
+  python tests/golden/make_golden_r2.py [adamw] [c2] [s1c3] [s1c3b4]
 """
 import json
 import os
@@ -132,7 +134,7 @@ def make_c2():
     print("wrote", path, {k: round(v, 5) for k, v in out["losses"].items()})
 
 
-def make_s1c3():
+def make_s1c3(B=2, x_lens=(256, 201), y_lens=(768, 645), seed=4321, name="s1_c3.pt"):
     import yaml
     from src.easevoice.soundstorm.auto_reg.models.t2s_model import Text2SemanticDecoder
 
@@ -146,9 +148,9 @@ def make_s1c3():
         if hasattr(m, "dropout") and isinstance(m.dropout, float):
             m.dropout = 0.0
     model.train()
-    B, x_len, y_len = 2, 256, 768
-    b = s1_batch(B, x_len, y_len, seed=4321)
-    x_lens, y_lens = [256, 201], [768, 645]          # one full item, one padded on both sides
+    x_len, y_len = 256, 768
+    b = s1_batch(B, x_len, y_len, seed=seed)
+    x_lens, y_lens = list(x_lens), list(y_lens)      # s1_c3.pt: one full item, one padded on both sides
     b["phoneme_ids_len"], b["semantic_ids_len"] = torch.tensor(x_lens), torch.tensor(y_lens)
     loss, acc = model.forward_old(b["phoneme_ids"], b["phoneme_ids_len"], b["semantic_ids"], b["semantic_ids_len"],
                                   b["bert_feature"])
@@ -165,9 +167,9 @@ def make_s1c3():
     for n, p in params.items():
         top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
         gss[top] = gss.get(top, 0.0) + float(p.grad.double().pow(2).sum())
-    out = dict(config=dict(B=B, x_len=x_len, y_len=y_len, x_lens=x_lens, y_lens=y_lens, seed=4321), loss=float(loss),
+    out = dict(config=dict(B=B, x_len=x_len, y_len=y_len, x_lens=x_lens, y_lens=y_lens, seed=seed), loss=float(loss),
                acc=float(acc), grad_slices=grads, grad_sumsq=gss)
-    path = os.path.join(HERE, "s1_c3.pt")
+    path = os.path.join(HERE, name)
     torch.save(out, path)
     print("wrote", path, "loss", out["loss"], "acc", out["acc"], "per-token nll", out["loss"] / (B * y_len))
 
@@ -180,3 +182,7 @@ if __name__ == "__main__":
         make_c2()
     if "s1c3" in what:
         make_s1c3()
+    if "s1c3b4" in what:
+        # four ragged items (~26 GB of host memory in the reference): multi-block grids per (batch, head) beyond two items,
+        # a text shorter than half the padded length, a semantic sequence shorter than half
+        make_s1c3(B=4, x_lens=(256, 201, 130, 256), y_lens=(768, 645, 768, 300), seed=4322, name="s1_c3_b4.pt")

@@ -26,6 +26,16 @@ def main():
         ref = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(ref, x)
         assert torch.allclose(b, torch.stack(ref).sum(0), rtol=1e-6, atol=1e-6), n
+        # "auto": reduce-scatter + all-gather only for buckets of at least rsag_min_bytes, all-reduce below -- and the
+        # reducer says which it used
+        c = x.clone()
+        r = GradReducer(world, bucket_bytes=4 * 1024, rsag="auto", rsag_min_bytes=2 * 1024)
+        r.all_reduce(c)
+        assert torch.allclose(c, a, rtol=1e-6, atol=1e-6), n
+        full, tail = divmod(n, 1024)
+        want_rsag = full + (1 if tail >= 512 else 0)
+        assert r.stats["rs_ag"] == want_rsag and r.stats["all_reduce"] == (1 if 0 < tail < 512 else 0), (n, r.stats)
+        assert r.stats["bytes"] == 4 * n and "reduce-scatter" in r.describe()
     dist.destroy_process_group()
 
 

@@ -218,15 +218,22 @@ def test_s1_engine_data_parallel_gloo(tmp_path):
     from easevoice_trainer_amd.dist import spawn_ranks
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker_s1.py")
-    codes = spawn_ranks([sys.executable, worker, str(tmp_path / "dp")], [0, 1])
-    assert codes == [0, 0]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     import subprocess
     subprocess.run([sys.executable, worker, str(tmp_path / "single")], check=True, env=env)
-    a, b = torch.load(tmp_path / "dp0"), torch.load(tmp_path / "dp1")
     one = torch.load(tmp_path / "single0")
-    assert torch.equal(a, b)                                   # replicas stay identical
-    assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a))
+    # the reduction in three pieces that start inside the last micro-batch's backward (cuts at blocks 2 and 1 of the
+    # 4-block test model), and as one piece after it: both = the single process
+    for tag, cuts in (("cut", "2,1"), ("plain", "")):
+        os.environ["EVT_DP_S1_CUTS"] = cuts
+        try:
+            codes = spawn_ranks([sys.executable, worker, str(tmp_path / tag)], [0, 1])
+        finally:
+            del os.environ["EVT_DP_S1_CUTS"]
+        assert codes == [0, 0]
+        a, b = torch.load(tmp_path / (tag + "0")), torch.load(tmp_path / (tag + "1"))
+        assert torch.equal(a, b)                                   # replicas stay identical
+        assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a)), tag
 
 
 def test_split_subgroups_gloo(tmp_path):
@@ -489,7 +496,9 @@ def test_bench_multi_rank_dry_run(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("dp2, all-reduce") and d["config"]["global_batch"] == 4 and d["value"] > 0
+    # the line explains its own gradient exchange: one all-reduce of the (toy) arena every fourth micro-step
+    assert d["comm"]["all_reduce_per_step"] > 0 and d["comm"]["mib_per_step"] > 0 and d["comm"]["rs_ag_per_step"] == 0
     # a launch with the wrong world size is refused, not silently run as N independent jobs
     cmd1 = [sys.executable, os.path.join(root, "tests", "bench_dryrun_worker.py"), "--gpus", "2", "--workload", "s1"]
     r1 = subprocess.run(cmd1, capture_output=True, text=True, timeout=120, cwd=root,

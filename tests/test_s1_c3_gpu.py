@@ -19,11 +19,15 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+@pytest.mark.parametrize("fixture", ["s1_c3.pt", "s1_c3_b4.pt"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_s1_c3_shape_matches_reference(gpu, dtype):
+def test_s1_c3_shape_matches_reference(gpu, dtype, fixture):
+    """s1_c3.pt: B = 2 (one full item, one padded on both sides); s1_c3_b4.pt: B = 4 with four different (text, semantic)
+    length pairs -- more than two items per grid, a text shorter than half the padded length, a semantic sequence shorter
+    than half (tests/golden/make_golden_r2.py s1c3b4: the reference's forward_old on ~26 GB of host memory)"""
     from easevoice_trainer_amd.train.s1_engine import S1Engine
 
-    gold = torch.load(os.path.join(HERE, "golden", "s1_c3.pt"), weights_only=False)
+    gold = torch.load(os.path.join(HERE, "golden", fixture), weights_only=False)
     c = gold["config"]
     assert (c["x_len"], c["y_len"]) == (256, 768)
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))

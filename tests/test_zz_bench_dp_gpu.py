@@ -25,8 +25,12 @@ def test_bench_two_ranks_one_device(gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2, all-reduce") and d["config"]["global_batch"] == 4
+    # the line explains its own gradient exchange: collectives and MiB per step, and the wait the overlap did not hide
+    c = d["comm"]
+    assert c["all_reduce_per_step"] >= 2 and c["mib_per_step"] > 300 and c["exposed_wait_ms_per_step"] is not None
     assert d["losses_finite"] and d["value"] > 0
     assert "graph" in d["config"]["launch"] and "reductions between them" in d["config"]["launch"]
     assert "roofline" not in d and "roofline_note" in d and "roofline" not in d["s1"]
-    assert d["s1"]["n_gpus"] == 2 and d["s1"]["value"] > 0 and d["s1"]["config"]["parallelism"] == "dp2"
+    assert d["s1"]["n_gpus"] == 2 and d["s1"]["value"] > 0 and d["s1"]["config"]["parallelism"].startswith("dp2, all-reduce")
+    assert d["s1"]["comm"]["mib_per_step"] > 0

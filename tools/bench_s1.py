@@ -138,6 +138,8 @@ def run(args, world, rank, local, extras=True):
         idx += 1
     if world > 1:
         torch.distributed.barrier()
+        reducer.reset_stats()
+        reducer.timing = on_gpu
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -147,6 +149,7 @@ def run(args, world, rank, local, extras=True):
         torch.distributed.barrier()
     sync()
     dt = time.perf_counter() - t0
+    comm = reducer.comm_report(args.steps) if world > 1 else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -158,9 +161,13 @@ def run(args, world, rank, local, extras=True):
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"s1 AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th "
                                f"micro-batch), batch={B}/GPU, x_len=256 + y_len=768, configs/gpt.yaml, attention dropout 0.1",
-                   "global_batch": world * B, "seq_len": x_len + y_len, "parallelism": f"dp{world}"},
+                   "global_batch": world * B, "seq_len": x_len + y_len,
+                   "parallelism": (reducer.describe() + f", {1 + len(eng._cuts)} pieces per optimiser step, the first "
+                                   "ones under the last micro-batch's backward") if reducer is not None else "dp1"},
         "loss_per_token_last": float(loss) / (B * y_len), "top3_acc_last": float(acc),
     }
+    if comm is not None:
+        res["comm"] = comm       # per MICRO-step on rank 0 (one exchange every fourth): collectives, MiB, exposed wait
     if extras:
         try:
             res["roofline"] = attention_roofline(eng, batch, B, x_len + y_len, args.dtype)
