@@ -152,10 +152,27 @@ def make_s1c3(B=2, x_lens=(256, 201), y_lens=(768, 645), seed=4321, name="s1_c3.
     b = s1_batch(B, x_len, y_len, seed=seed)
     x_lens, y_lens = list(x_lens), list(y_lens)      # s1_c3.pt: one full item, one padded on both sides
     b["phoneme_ids_len"], b["semantic_ids_len"] = torch.tensor(x_lens), torch.tensor(y_lens)
+    # the two position scales are single scalars whose gradient is a sum of +- terms over every (token, channel):
+    # d alpha = sum(grad_out * pe).  The size of the terms, sum(|grad_out * pe|), is recorded next to the sums so that the
+    # comparison can be made the way a dot product's error is bounded -- relative to the magnitudes, not to a result that
+    # cancellation may have made arbitrarily small
+    abs_terms = {}
+
+    def watch(name):
+        mod = getattr(model, name)
+
+        def fwd_hook(m, inp, out):
+            pe = m.pe[:, : inp[0].size(1)].detach()
+            out.register_hook(lambda g, pe=pe: abs_terms.__setitem__(name, float((g.double() * pe.double()).abs().sum())))
+        return mod.register_forward_hook(fwd_hook)
+
+    handles = [watch("ar_text_position"), watch("ar_audio_position")]
     loss, acc = model.forward_old(b["phoneme_ids"], b["phoneme_ids_len"], b["semantic_ids"], b["semantic_ids_len"],
                                   b["bert_feature"])
     model.zero_grad()
     loss.backward()
+    for h in handles:
+        h.remove()
     names = ["bert_proj.weight", "ar_text_embedding.word_embeddings.weight", "ar_text_position.alpha",
              "ar_audio_embedding.word_embeddings.weight", "ar_audio_position.alpha", "h.layers.0.self_attn.in_proj_weight",
              "h.layers.0.self_attn.in_proj_bias", "h.layers.0.self_attn.out_proj.weight", "h.layers.11.linear1.weight",
@@ -168,7 +185,7 @@ def make_s1c3(B=2, x_lens=(256, 201), y_lens=(768, 645), seed=4321, name="s1_c3.
         top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
         gss[top] = gss.get(top, 0.0) + float(p.grad.double().pow(2).sum())
     out = dict(config=dict(B=B, x_len=x_len, y_len=y_len, x_lens=x_lens, y_lens=y_lens, seed=seed), loss=float(loss),
-               acc=float(acc), grad_slices=grads, grad_sumsq=gss)
+               acc=float(acc), grad_slices=grads, grad_sumsq=gss, alpha_abs_terms=abs_terms)
     path = os.path.join(HERE, name)
     torch.save(out, path)
     print("wrote", path, "loss", out["loss"], "acc", out["acc"], "per-token nll", out["loss"] / (B * y_len))

@@ -48,12 +48,24 @@ def test_s1_c3_shape_matches_reference(gpu, dtype, fixture):
         for n, s in gold["grad_slices"].items():
             if float(s.abs().max()) < 1e-4:
                 continue    # h.layers.23 q-projection row 0: |g| ~ 4e-6 against 1e-1 elsewhere in the tensor, pure cancellation
+            if n.endswith("_position.alpha"):
+                continue    # a dot product over every (token, channel): judged against the size of its terms below
             assert rel(params[n].grad.flatten()[:96], s) < 3e-3, n
     tot = {}
     for n, p in params.items():
         top = ".".join(n.split(".")[:3]) if n.startswith("h.layers") else n.split(".")[0]
         tot[top] = tot.get(top, 0.0) + float(p.grad.double().pow(2).sum())
     for k, v in gold["grad_sumsq"].items():
-        # the two position scales (alpha) are single scalars whose gradient sums +-terms over every token: 7 % in bf16
-        tol = 5e-3 if f32 else (2e-1 if k in ("ar_audio_position", "ar_text_position") else 6e-2)
+        if k in ("ar_audio_position", "ar_text_position"):
+            # d alpha = sum over every (token, channel) of grad_out * pe: +- terms that cancel (at B = 4 the audio scale's
+            # gradient is 0.007 out of terms that add up to 50 in magnitude).  A dot product's error is bounded relative to
+            # the sum of the magnitudes of its terms, which the fixture records.  The terms themselves carry the error of a
+            # 24-block backward (1e-6 .. 1e-5 relative in fp32, 1e-2 in bf16, signs random), so the bound is 1e-5 of that
+            # sum in fp32 (measured 3e-6 / 7e-7) and one bf16 rounding, 4e-3, in bf16 (measured 1.3e-3 / 3e-4)
+            terms = gold["alpha_abs_terms"][k]
+            g = float(params[k + ".alpha"].grad.flatten()[0])
+            ref = float(gold["grad_slices"][k + ".alpha"][0])
+            assert abs(g - ref) <= (1e-5 if f32 else 4e-3) * terms, (k, g, ref, terms)
+            continue
+        tol = 5e-3 if f32 else 6e-2
         assert abs(tot[k] - v) <= tol * v, (k, tot[k], v)
