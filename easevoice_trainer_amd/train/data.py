@@ -95,8 +95,15 @@ def open_source(kind, train_input_dir, device, synthetic_factory, batch_size=Non
     if train_input_dir and os.path.exists(marker):
         from .dataset import S1Reader, S2Reader
 
-        reader = S2Reader if kind == "s2" else S1Reader
-        return reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world)
+        if kind == "s2":
+            # the trainer rounds the padded time axes of a batch up to 16 frames unless told otherwise (EVT_PAD_FRAMES; 0 =
+            # the reference's exact layout): every consumer masks by the lengths, so the step computes the same thing, and a
+            # run then repeats a couple of dozen batch shapes instead of > 100, which is what lets the per-shape HIP-graph
+            # replay of the s2 step engage.  Measured (profiles/r04_realdata_pad*.json, 2-10 s clips, B = 16, 240 steps):
+            # 0 -> 1060, 8 -> 1370, 16 -> 1633, 32 -> 1512 audio-s/s (eager share 90 % / 22 % / 18 % / 16 %).
+            pad = int(os.environ.get("EVT_PAD_FRAMES", "16")) if str(device).startswith("cuda") else None
+            return S2Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world, pad_frames=pad)
+        return S1Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world)
     raise FileNotFoundError(
         f"no training input under {train_input_dir!r}: expected the reference's feature directory ({marker}), a tensor "
         f"bundle {bundle}, or EVT_SYNTHETIC_STEPS=<n> for fixed-shape synthetic batches")

@@ -306,6 +306,7 @@ class S2Engine:
 
         self._graph_warmup, self._graph_max = warmup_steps, max_shapes
         self._graph_cache = {}
+        self.graph_steps = {"replayed": 0, "eager": 0}      # how the steps of a run were launched (tools/bench_reader.py)
         if not hip_graphs_safe():
             import warnings
 
@@ -323,6 +324,7 @@ class S2Engine:
             ent["seen"] += 1
             captured = sum(1 for e in self._graph_cache.values() if e["graphs"] is not None)
             if ent["seen"] <= self._graph_warmup or captured >= self._graph_max:
+                self.graph_steps["eager"] += 1
                 self.graphs_enabled = False
                 try:
                     return self.step(*inputs)
@@ -350,6 +352,7 @@ class S2Engine:
                 after()
         self.optim_d.note_replayed_step()
         self.optim_g.note_replayed_step()
+        self.graph_steps["replayed"] += 1
         return ent["result"]
 
     def _capture(self, ent, inputs):

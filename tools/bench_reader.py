@@ -9,6 +9,8 @@ how many steps were replayed from a captured HIP graph, with and without EVT_PAD
 import argparse
 import json
 import os
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime loads: easevoice_trainer_amd/__init__.py
 import sys
 import tempfile
 import time
@@ -90,7 +92,7 @@ def main():
             eng.build_optimizers()
             eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "16")))
             src = S2Reader(root, cfg, args.batch, dev)
-            steps, epoch, wait = 0, 0, 0.0
+            steps, epoch, wait, audio_s = 0, 0, 0.0, 0.0
             torch.cuda.synchronize()
             t_all = time.perf_counter()
             while steps < args.train_steps:
@@ -106,12 +108,15 @@ def main():
                     wait += time.perf_counter() - t0          # time the step loop spent waiting for the reader
                     eng.step(ssl, spec, spec_len, y, text, text_len)
                     steps += 1
+                    audio_s += float(spec_len.sum()) * 640 / 32000        # real (unpadded) audio of the batch
             torch.cuda.synchronize()
             dt = time.perf_counter() - t_all
             cache = getattr(eng, "_graph_cache", {})
             captured = sum(1 for e in cache.values() if e["graphs"] is not None)
+            gs = getattr(eng, "graph_steps", {"replayed": 0, "eager": steps})
             out["train"] = dict(steps=steps, ms_per_step=round(1e3 * dt / steps, 2), reader_wait_ms_per_step=round(1e3 * wait / steps, 2),
-                                shapes_seen=len(cache), shapes_captured=captured)
+                                audio_seconds_per_s=round(audio_s / dt, 1), shapes_seen=len(cache), shapes_captured=captured,
+                                steps_replayed=gs["replayed"], eager_share=round(1.0 - gs["replayed"] / max(steps, 1), 3))
     print(json.dumps(out))
 
 
