@@ -571,8 +571,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 #pragma unroll
     for (int t = 0; t < WKT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // dbias (column sums of A = dy) by the (chunk 0, tap group 0) blocks, read back from the staged tiles
-  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0 && tid < 128;
-  float bsum = 0.f;
+  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0;          // block-uniform
+  f32x4 bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read addresses (bytes, relative to the stage base) for ks = 0; ks = 1 adds 32 rows
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -602,22 +604,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
       if (t < ntap)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    if (do_bias) wg_bias_mma<4>(bacc, a, wc);
     tr_load_step<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < WKT; ++t)
       if (t < ntap)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
-    if (do_bias) {
-      const unsigned char* at = smem + buf * WSTAGE;
-      const int slot = tid >> 3, sub = (tid & 7) * 2;
-      for (int r = 0; r < WPOS; ++r) {
-        const int f = 2 * ((r & 3) | (((r >> 3) & 1) << 2));
-        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * 256 + ((slot ^ f) * 16) + sub));
-      }
-    }
+    if (do_bias) wg_bias_mma<4>(bacc, a, wc);
   }
-  if (do_bias) wg_finish_bias(p, a0 + tid, bsum, blockIdx.y);
+  if (do_bias) wg_finish_bias_mma<4>(p, bacc, a0, wr, wc, g8, j16, blockIdx.y);
   // lane holds A channels g8*4..+3 (rows) x B channel j16 (column) of each tile
   wg_finish<4, WKT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, blockIdx.y);
 }
@@ -691,23 +687,39 @@ __device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned
   for (int t = 0; t < GKT; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_gemm(WgP p, int stages_per_split) {
+// NS: stages of the LDS ring (32 KiB each).  The reduction of one block is a chain of 64-token stages whose operands come
+// through LDS-DMA; with two buffers one stage is in flight per block (two blocks per CU: 64 KiB in flight per CU) and the
+// kernel ran at the pace of one memory round trip per stage (1.8 us per stage at 600 TFLOP/s against 0.4 us of LDS reads +
+// MFMAs).  NS = 4: three stages in flight behind counted waits, one raw barrier per stage, one block per CU.
+template <int NS>
+__global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int stages_per_split) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j16 = lane & 15, g8 = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
 
+  // Block -> (tile, split).  Consecutive workgroup ids go round-robin over the 8 XCDs, so with the plain (x = tile,
+  // y = split) grid the tiles of ONE split -- the blocks that read the same token rows -- sit on all eight L2s and every
+  // L2 pulls (nearly) every operand row across the fabric.  xcd_order: the linear id is decoded so that a split lives on
+  // one XCD (split = xcd + 8 * ...), its tiles dispatched back to back: an operand row enters one L2, once.
+  int tile = blockIdx.x, split = blockIdx.y;
+  if (p.xcd_order) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    tile = idx % (int)gridDim.x;
+    split = xcd + 8 * (idx / (int)gridDim.x);
+  }
   const int ngrp = p.nchunk / GKT;                       // 128-channel groups of x
-  const int cg = blockIdx.x % ngrp;
-  const int atile = blockIdx.x / ngrp;
+  const int cg = tile % ngrp;
+  const int atile = tile / ngrp;
   const int a0 = atile * 128;
 
   const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
   const int total_units = p.nseq * p.Q;
   const int nstages = (total_units + WPOS - 1) / WPOS;
-  const int st_begin = blockIdx.y * stages_per_split;
+  const int st_begin = split * stages_per_split;
   const int st_end = min(nstages, st_begin + stages_per_split);
   if (st_begin >= st_end) return;
 
@@ -744,8 +756,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm(WgP p, int stages_per_split
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int t = 0; t < GKT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.dbias != nullptr && cg == 0 && tid < 128;
-  float bsum = 0.f;
+  // dbias (column sums of dy) on the matrix pipe (wgrad_epi.h), spread over the blocks that read the same dy tile: block
+  // cg takes the fragments i = cg (mod bgrp) in its wc = 0 waves -- one extra MFMA per 16 where ngrp >= 4, no block of the
+  // grid slower than the others (all four fragments in the cg = 0 blocks: 657 TFLOP/s at [32768, 2048, 512], 763 without)
+  const int bgrp = ngrp < 4 ? ngrp : 4;
+  const bool do_bias = p.dbias != nullptr && cg < bgrp && wc == 0;         // wave-uniform
+  bool mine[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mine[i] = do_bias && (i % bgrp) == cg;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  f32x4 bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int frow = g8 * 8 + (j16 >> 2);
@@ -757,11 +781,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm(WgP p, int stages_per_split
   for (int i = 0; i < 4; ++i) a_off[i] = frow * 256 + (((wr * 8 + i * 2 + ((j16 & 3) >> 1)) ^ fa) * 16) + half;
   const int b_off = WA_BYTES + frow * 64 + (((wc * 2 + ((j16 & 3) >> 1)) ^ fb) * 16) + half;
 
-  issue(st_begin, 0);
+  const int nst = st_end - st_begin;
+  constexpr int G = 4 + GKT;                               // DMA instructions per wave per stage
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nst) issue(st_begin + s, s);
   for (int st = st_begin; st < st_end; ++st) {
-    const int buf = (st - st_begin) & 1;
-    __syncthreads();
-    if (st + 1 < st_end) issue(st + 1, buf ^ 1);
+    const int s = st - st_begin;
+    const int buf = s % NS;
+    // groups still allowed in flight once stage s has landed: stages s+1 .. s+NS-2 that exist
+    wait_groups<G, NS - 2>(min(NS - 2, nst - 1 - s));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NS - 1 < nst) issue(st + NS - 1, (s + NS - 1) % NS);
     const unsigned sbase = lds0 + buf * GSTAGE;
     unsigned aa[4];
 #pragma unroll
@@ -773,21 +805,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm(WgP p, int stages_per_split
     for (int t = 0; t < GKT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mine[i]) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
     tr_load_step_g<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < GKT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
-    if (do_bias) {
-      const unsigned char* at = smem + buf * GSTAGE;
-      const int slot = tid >> 3, sub = (tid & 7) * 2;
-      for (int r = 0; r < WPOS; ++r) {
-        const int f = 2 * ((r & 3) | (((r >> 3) & 1) << 2));
-        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * 256 + ((slot ^ f) * 16) + sub));
-      }
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mine[i]) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
+    asm volatile("" ::: "memory");
   }
-  if (do_bias) atomicAdd(p.dbias + a0 + tid, bsum);
+  if (do_bias && j16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mine[i])
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + a0 + wr * 64 + i * 16 + g8 * 4 + r, bacc[i][r]);
+  }
 
   // lane holds dy-channels g8*4..+3 (rows) x x-channel j16 (column) of each tile; image [CA][nchunk][1][32]
 #pragma unroll
@@ -1172,8 +1209,10 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // dbias (column sums of the A operand = dy) by the (chunk 0, tap group 0) blocks, from the staged tiles
-  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0 && tid < 32 * MA;
-  float bsum = 0.f;
+  const bool do_bias = p.dbias != nullptr && ch == 0 && tgi == 0;          // block-uniform
+  f32x4 bacc[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int frow = g8 * 8 + (j16 >> 2);
@@ -1206,21 +1245,17 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
       if (t < ntap)
 #pragma unroll
         for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+    if (do_bias) wg_bias_mma<MA>(bacc, a, wc);
     TrStep<MA, KT>::template load<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
       if (t < ntap)
 #pragma unroll
         for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
-    if (do_bias) {
-      const unsigned char* at = smem + (s % NS) * STAGE;
-      const int slot = tid >> 3, sub = (tid & 7) * 2;
-      for (int r = 0; r < WPOS; ++r)
-        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * AROW + ((slot ^ a_swz<MA>(r)) * 16) + sub));
-    }
+    if (do_bias) wg_bias_mma<MA>(bacc, a, wc);
     asm volatile("" ::: "memory");
   }
-  if (do_bias) wg_finish_bias(p, a0 + tid, bsum, blockIdx.y);
+  if (do_bias) wg_finish_bias_mma<MA>(p, bacc, a0, wr, wc, g8, j16, blockIdx.y);
   wg_finish<MA, KT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, blockIdx.y);
 }
 
@@ -1368,6 +1403,8 @@ bool wgrad_gemm_eligible(const WgP& p, int dtype) {
   return units >= 2048;                                      // long reductions only: the dense layers of s1
 }
 
+static int launch_wgrad_gemm_grid(const WgP& p, long tiles, int per, hipStream_t st);
+
 int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
   WgP p = p_in;
   if (!wgrad_gemm_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
@@ -1383,18 +1420,44 @@ int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
   if (split < 1) split = 1;
   const int per = (int)((nstages + split - 1) / split);
   split = (nstages + per - 1) / per;
+  // XCD-aware order needs the split count to be a multiple of 8 (EVT_WGRAD_GEMM_XCD=0: the plain grid)
+  static const int xcd = getenv("EVT_WGRAD_GEMM_XCD") ? atoi(getenv("EVT_WGRAD_GEMM_XCD")) : 1;
+  p.xcd_order = 0;
+  if (xcd && nstages >= 64) {
+    long s8 = xcd == 2 ? (split / 8 * 8) : (split + 7) / 8 * 8;       // 2: round down (measurement variant)
+    if (s8 < 8) s8 = 8;
+    const int per8 = (int)((nstages + s8 - 1) / s8);
+    if ((long)per8 * (s8 - 1) < nstages) {       // every split non-empty (an empty one only returns, but keep the grid tight)
+      split = s8;
+      p.xcd_order = 1;
+      p.nsplit = (int)split;
+      return launch_wgrad_gemm_grid(p, tiles, per8, st);
+    }
+  }
   p.nsplit = (int)split;
+  return launch_wgrad_gemm_grid(p, tiles, per, st);
+}
+
+template <int NS>
+static int launch_wgrad_gemm_ns(const WgP& p, long tiles, int per, hipStream_t st) {
   static bool attr = false;
-  const size_t lds = 2 * GSTAGE;
+  const size_t lds = NS * GSTAGE;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return EVT_ELAUNCH;
     attr = true;
   }
-  evt_set_last_tag("wgrad_gemm<bf16, 128, 128, 64>");
-  hipLaunchKernelGGL(wgrad_gemm, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
+  evt_set_last_tag("wgrad_gemm<bf16, 128, 128, 64, x%d>", NS);
+  hipLaunchKernelGGL(wgrad_gemm<NS>, dim3((unsigned)tiles, p.nsplit), dim3(256), lds, st, p, per);
   return evt_check_launch();
+}
+
+static int launch_wgrad_gemm_grid(const WgP& p, long tiles, int per, hipStream_t st) {
+  static const int ns = getenv("EVT_WGRAD_GEMM_NS") ? atoi(getenv("EVT_WGRAD_GEMM_NS")) : 2;
+  if (ns == 4) return launch_wgrad_gemm_ns<4>(p, tiles, per, st);
+  if (ns == 3) return launch_wgrad_gemm_ns<3>(p, tiles, per, st);
+  return launch_wgrad_gemm_ns<2>(p, tiles, per, st);
 }
 
 // ---- wgrad_ring dispatch ----

@@ -45,6 +45,7 @@ struct WgP {
   float aact_slope, bact_slope;
   int nsplit;
   int ntapgrp;
+  int xcd_order;      // wgrad_gemm: blocks decoded so that one split's tiles share an XCD (set by its launcher)
   float* dbias;       // optional: += column sums of A_eff (only valid when A is dy)
   // deterministic split-K (evt_conv1d_bwd_weight_parts, wgrad_epi.h); parts == 0: classic fp32 atomics into dw
   float* dw_extra;    // slabs 1 .. parts-1 of the gradient image, part_stride floats apart (slab 0 is dw)

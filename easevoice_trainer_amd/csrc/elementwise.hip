@@ -544,6 +544,18 @@ int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* e
   return evt_check_launch();
 }
 
+int evt_adamw_flat_dev_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t lo, int64_t hi,
+                             const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                             int32_t* step_counter, int32_t bump, float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || !step_counter || lo < 0 || hi <= lo)
+    return EVT_EINVAL;
+  if (bump) hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(grid_for(hi - lo)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, (long)lo,
+                     (long)hi);
+  return evt_check_launch();
+}
+
 int evt_sumsq(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n <= 0) return EVT_EINVAL;
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);

@@ -56,7 +56,7 @@ template <int C> __device__ __forceinline__ int wslot(int row, int slot) {
 // (mid_a, parked in the intermediate tile's own LDS rows: each lane reads its 8 bytes right before it overwrites them
 // with dmid) are all staged in the one pass at the top; the first two weight fragments of a convolution are requested
 // before the barrier in front of it; biases at the very top.
-template <int C, int WM, int WN, int NT1, int NT2, bool BWD>
+template <int C, int WM, int WN, int NT1, int NT2, bool BWD, int R>
 __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
   constexpr int PITCH = C * 2;
   constexpr int SPR = C / 8;                 // 16-byte slots per row
@@ -129,9 +129,11 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
     stage(p.g2, rs, P, q0, [&](const uint4 raw, const int, const int, unsigned char* d) { *reinterpret_cast<uint4*>(d) = raw; });
   }
 
-  // weight fragments (global, L2-resident): ring of four sets, requested two K steps ahead; K steps behind the last one
-  // re-load the last fragment (clamped index) so that no load sits behind a branch
-  u32x4 fa[4][MTW];
+  // weight fragments (global, L2-resident): a ring of R sets, requested R - 2 K steps ahead.  What a block can stream
+  // through its CU is (bytes in flight) / (L2 round trip): with a wave fetching its own rows only, that is
+  // 4 waves x (R - 2) x MTW KB -- 16 KB at R = 4, where the C = 128 launch ran at the pace of its weight stream (20 GB/s per
+  // CU); K steps behind the last one re-load the last fragment (clamped index) so that no load sits behind a branch
+  u32x4 fa[R][MTW];
   const bf16_t* wrow[MTW];
   auto set_w = [&](const bf16_t* w) {
 #pragma unroll
@@ -142,12 +144,17 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) fa[s][i] = *reinterpret_cast<const u32x4*>(wrow[i] + kc * 32);
   };
+  auto prologue_a = [&](const bf16_t* w) {
+    set_w(w);
+#pragma unroll
+    for (int i = 0; i < R - 2; ++i) issue_a(i, i);
+  };
   // one convolution: acc[i][j] over the K steps; rows region `rows`, first row of this wave's tile j = rbase + 16 j.
-  // Straight-line K loop (no branch around a load: behind a control-flow merge the compiler's wait counters fall back to
-  // "wait for everything", which would drain the weight prefetch every step); four K steps per trip so the weight ring
-  // rotates without register copies.  Rows (LDS): ONE fragment set; tile j's fragment of the next K step is requested
-  // right after tile j's MFMAs of this step were issued, i.e. a whole K step before it is needed.
-  // Precondition: set_w(); issue_a(0, 0); issue_a(1, 1) already done (before the barrier in front of the convolution).
+  // Straight-line K loop (no branch around a load in the main part: behind a control-flow merge the compiler's wait
+  // counters fall back to "wait for everything", which would drain the weight prefetch every step); R K steps per trip so
+  // the weight ring rotates without register copies.  Rows (LDS): ONE fragment set; tile j's fragment of the next K step
+  // is requested right after tile j's MFMAs of this step were issued, i.e. a whole K step before it is needed.
+  // Precondition: prologue_a(w) already done (before the barrier in front of the convolution).
   auto conv = [&](auto& acc, auto NT_c, const unsigned char* rows, const int rbase, const int dil) {
     constexpr int NT = decltype(NT_c)::value;
     u32x4 fb[NT];
@@ -176,31 +183,25 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b0 + j * 16 * PITCH);
     }
-    const int main_end = nks & ~3;
     int ks = 0;
-    for (; ks < main_end; ks += 4) {
-      issue_a(ks + 2, 2);
-      issue_a(ks + 3, 3);
-      step(0);
-      step(1);
-      issue_a(ks + 4, 0);
-      issue_a(ks + 5, 1);
-      step(2);
-      step(3);
+    for (; ks + R <= nks; ks += R) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        issue_a(ks + i + R - 2, (i + R - 2) % R);
+        step(i);
+      }
     }
-    if (nks & 2) {          // nks = 2 k at C = 64: two K steps left, their weights are fragment sets 0 and 1
-      step(0);
-      step(1);
-    }
+    const int rest = nks - ks;            // < R K steps left; their weights are (being) fetched into sets 0 .. rest - 1
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+      if (i < rest) step(i);
   };
   auto unpack4 = [](const u32x2 v, float (&o)[4]) {
     o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xFFFF0000u);
     o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xFFFF0000u);
   };
 
-  set_w(p.wA);
-  issue_a(0, 0);
-  issue_a(1, 1);
+  prologue_a(p.wA);
   __syncthreads();
 
   // ---- first convolution: rows m = wn * 16 NT1 + 16 j + n of the intermediate tile (position q0 - hB + m) ----
@@ -213,9 +214,7 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
     const int m0 = wn * 16 * NT1;
     conv(acc, std::integral_constant<int, NT1>{}, xs, m0, p.dilA);
     // the second convolution's first weights travel under this epilogue
-    set_w(p.wB);
-    issue_a(0, 0);
-    issue_a(1, 1);
+    prologue_a(p.wB);
 #pragma unroll
     for (int j = 0; j < NT1; ++j) {
       const int m = m0 + j * 16 + n;
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
   }
 }
 
-template <int C, int WM, int WN, int NT1, int NT2, bool BWD>
+template <int C, int WM, int WN, int NT1, int NT2, bool BWD, int R = 4>
 int launch(WUP p, hipStream_t st) {
   constexpr int P = 16 * NT2 * WN, MROWS = 16 * NT1 * WN;
   const int H = (p.k - 1) / 2, hA = p.dilA * H, hB = p.dilB * H;
@@ -298,13 +297,13 @@ int launch(WUP p, hipStream_t st) {
   if (lds > 160 * 1024) return EVT_ENOTSUP;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_wide<C, WM, WN, NT1, NT2, BWD>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_wide<C, WM, WN, NT1, NT2, BWD, R>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return EVT_ELAUNCH;
     attr = true;
   }
   evt_set_last_tag("resunit_wide_%s<bf16, %d, %dx%d, nt %d-%d>", BWD ? "bwd" : "fwd", C, WM, WN, NT1, NT2);
-  hipLaunchKernelGGL((resunit_wide<C, WM, WN, NT1, NT2, BWD>), dim3(p.nseq * p.tps), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((resunit_wide<C, WM, WN, NT1, NT2, BWD, R>), dim3(p.nseq * p.tps), dim3(256), lds, st, p);
   return evt_check_launch();
 }
 
@@ -341,8 +340,16 @@ int evt_resunit_wide_fwd(const evt_resunit_params* a, const void* x, const void*
   //             2x2 waves, 256 positions (320 blocks)  26 / 33 / 41   |  4x1, 80 positions               26 / 28 / 36
   // i.e. what counts is weight bytes per MFMA: four waves along the channels (a wave fetches only its own rows) and as
   // many position tiles per wave as the accumulators allow.  The first convolution covers P + 2 * 5 rows: 176 >= 170.
-  if (a->C == 128) return launch<128, 4, 1, 11, 10, false>(p, st);
-  return launch<64, 4, 1, 11, 10, false>(p, st);
+  static const int ring = getenv("EVT_WIDE_R") ? atoi(getenv("EVT_WIDE_R")) : 0;      // prefetch-depth experiments
+  if (a->C == 128) {
+    if (ring == 4) return launch<128, 4, 1, 11, 10, false, 4>(p, st);
+    if (ring == 5) return launch<128, 4, 1, 11, 10, false, 5>(p, st);
+    return launch<128, 4, 1, 11, 10, false, 6>(p, st);
+  }
+  if (ring == 4) return launch<64, 4, 1, 11, 10, false, 4>(p, st);
+  if (ring == 6) return launch<64, 4, 1, 11, 10, false, 6>(p, st);
+  if (ring == 12) return launch<64, 4, 1, 11, 10, false, 12>(p, st);
+  return launch<64, 4, 1, 11, 10, false, 8>(p, st);
 }
 
 int evt_resunit_wide_bwd_data(const evt_resunit_params* a, const void* dy, float dy_scale, const void* xa, const void* mid_a,

@@ -89,6 +89,34 @@ __device__ __forceinline__ void wg_finish(const WgP& p, unsigned char* smem, con
   }
 }
 
+// The fused bias gradient = column sums of the A operand (dy) over the block's positions, ON THE MATRIX PIPE: one extra
+// MFMA per A fragment against an all-ones B fragment; every column of the 16 x 16 result then holds the fragment's 16
+// channel sums (the j16 == 0 lanes keep them).  Reading the staged tile back instead -- 64 two-byte LDS loads per thread
+// and stage -- made the blocks that own a bias the slowest of the grid: the s1 dense-layer gradient ran at 605 TFLOP/s
+// with and 795 without it (round 4).  The two waves holding the same A fragments (wc = 0 / 1) take the even / odd ones.
+template <int MI>
+__device__ __forceinline__ void wg_bias_mma(f32x4 (&bacc)[MI], const bf16x8 (&a)[MI], int wc) {
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+    if ((i & 1) == wc) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
+}
+
+__device__ __forceinline__ void wg_finish_bias(const WgP& p, int channel, float bsum, int split);
+
+template <int MI>
+__device__ __forceinline__ void wg_finish_bias_mma(const WgP& p, const f32x4 (&bacc)[MI], int a0, int wr, int wc, int g8,
+                                                   int j16, int split) {
+  if (j16 != 0) return;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+    if ((i & 1) == wc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wg_finish_bias(p, a0 + wr * 16 * MI + i * 16 + g8 * 4 + r, bacc[i][r], split);
+}
+
 // fused bias gradient (column sums of dy over this block's positions): atomics into the parameter's gradient, or --
 // slab mode -- plain stores into db_part[split][channel], summed by evt_wn_grad_multi
 __device__ __forceinline__ void wg_finish_bias(const WgP& p, int channel, float bsum, int split) {

@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // dbias (column sums of the A operand = dy) by the chunk-0 blocks, from the staged tiles
-  const bool do_bias = p.dbias != nullptr && ch == 0 && tid < 32 * MA;
-  float bsum = 0.f;
+  const bool do_bias = p.dbias != nullptr && ch == 0;                      // block-uniform
+  f32x4 bacc[MA];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int frow = g8 * 8 + (j16 >> 2);
@@ -194,6 +196,12 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
 #pragma unroll
         for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_join(a[i]), bv, acc[i][t], 0, 0, 0);
       }
+      if (do_bias) {
+        bf16x8 af[MA];
+#pragma unroll
+        for (int i = 0; i < MA; ++i) af[i] = tr_join(a[i]);
+        wg_bias_mma<MA>(bacc, af, wc);
+      }
     };
     // both halves' fragments live at once only where the register file allows two blocks per CU with them; no branch on
     // the sequence tail (its rows of A are zero): one straight-line body keeps the accumulators where they are
@@ -214,15 +222,9 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
       landed(fa[0], fb[0]);
       mma(fa[0], fb[0]);
     }
-    if (do_bias) {
-      const unsigned char* at = smem + (s % NS) * STAGE;
-      const int slot = tid >> 3, sub = (tid & 7) * 2;
-      for (int r = 0; r < HPOS; ++r)
-        bsum += bf2f(*reinterpret_cast<const bf16_t*>(at + r * AROW + ((slot ^ a_swz<MA>(r)) * 16) + sub));
-    }
     asm volatile("" ::: "memory");
   }
-  if (do_bias) wg_finish_bias(p, a0 + tid, bsum, blockIdx.y);
+  if (do_bias) wg_finish_bias_mma<MA>(p, bacc, a0, wr, wc, g8, j16, blockIdx.y);
   wg_finish<MA, NT>(p, smem, acc, NT, a0, ch, 0, wr, wc, g8, j16, blockIdx.y);
 }
 

@@ -300,12 +300,16 @@ class WeightBank:
                         b.grad.data_ptr() if (b is not None and b.grad is not None) else 0))
         return out
 
-    def fold(self):
-        """w = g*v/|v| -> REG/ALT images for every conv of the model: ONE launch."""
+    def fold(self, lo=None, hi=None):
+        """w = g*v/|v| -> REG/ALT images for every conv of the model: ONE launch (or the rows [lo, hi) of rows_of())."""
         if self._items is None:
             self.build_tables()
-        L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
-                "evt_wn_fold_multi")
+        lo = 0 if lo is None else lo
+        hi = self._nrows if hi is None else hi
+        if hi <= lo:
+            return
+        rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
+        L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_fold_multi")
 
     def zero_dw(self):
         if self._deferred or self._held:
@@ -363,14 +367,19 @@ class WeightBank:
             self.build_tables()
         return self._slot_rows[idx[0]][0], self._slot_rows[idx[-1]][1]
 
-    def grads(self, lo=None, hi=None):
-        """dW images -> weight_v.grad / weight_g.grad (or weight.grad), ACCUMULATED (+=): one launch over the whole
-        model, or over the row range [lo, hi) of rows_of() -- every row must be visited exactly once per backward."""
-        self.join_side()
+    def check_tables(self):
         if self._items is None or (not torch.cuda.is_current_stream_capturing() and self._grad_stamp != self._grad_ptrs()):
             # a .grad was replaced since the tables were built (zero_grad(set_to_none=True), a caller assigning a new
             # tensor): the fused bias gradients / dv / dg would go to the old storage -- rebuild the tables
             self.build_tables()
+
+    def grads(self, lo=None, hi=None, join=True):
+        """dW images -> weight_v.grad / weight_g.grad (or weight.grad), ACCUMULATED (+=): one launch over the whole
+        model, or over the row range [lo, hi) of rows_of() -- every row must be visited exactly once per backward.
+        join=False: the caller's stream already waits for the weight-gradient side stream (ModelRuntime.book_piece)."""
+        if join:
+            self.join_side()
+        self.check_tables()
         lo = 0 if lo is None else lo
         hi = self._nrows if hi is None else hi
         if hi <= lo:

@@ -153,6 +153,21 @@ class FlatAdamW:
                                            C.c_float(self.betas[1]), C.c_float(self.eps), L.ptr(self._step_dev),
                                            C.c_float(grad_scale), L.stream_ptr()), "evt_adamw_flat_dev")
 
+    def step_range(self, lo, hi, bump, grad_scale=1.0):
+        """the update of the arena elements [lo, hi) only (evt_adamw_flat_dev_range): one sub-model's parameters, as soon as
+        its gradients are complete.  The ranges of one step partition the arena; the first one enqueued passes bump=True
+        (the step number moves once), the others must be ordered after it on the device."""
+        if bump:
+            self.step_count += 1
+            self.arena.updates += 1
+        tab, nseg = self._segments()
+        a = self.arena
+        L.check(L.lib().evt_adamw_flat_dev_range(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                                 C.c_int64(lo), C.c_int64(hi), L.ptr(tab), nseg, C.c_float(self.betas[0]),
+                                                 C.c_float(self.betas[1]), C.c_float(self.eps), L.ptr(self._step_dev),
+                                                 1 if bump else 0, C.c_float(grad_scale), L.stream_ptr()),
+                "evt_adamw_flat_dev_range")
+
     def note_replayed_step(self):
         """a captured graph ran the update: keep the python-side counter (checkpoints) in step with the device one"""
         self.step_count += 1
@@ -213,6 +228,7 @@ class ModelRuntime:
                 m.cd = dtype
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._fold_stamp = None
+        self._book = None
         # Parameters whose gradient comes from autograd (linears, norms, embeddings -- everything that is not a fused
         # conv): autograd's AccumulateGrad would run one `grad += new` launch per parameter per backward (~420 tiny
         # launches in the s2 generator).  Instead their .grad is detached from the arena during the backward (autograd
@@ -264,6 +280,19 @@ class ModelRuntime:
                 self.bank.grads(at, lo)
                 at = hi
             self.bank.grads(at, None)
+        self.gather_free_grads()
+
+    # ---- pipelined bookkeeping: a sub-model's weight-norm gradient, AdamW update and refold run on a side stream as
+    #      soon as its backward is done, under the backward of the next sub-model.  These three launches are HBM streams
+    #      over the parameters (2.0 of the 24.5 ms s2 step when they run after the backward, on the main stream); the
+    #      backward next to them is MFMA / latency bound.  Same kernels, same per-element arithmetic as the serial order.
+    def book_stream(self):
+        if self._book is None:
+            self._book = torch.cuda.Stream(device=self.device)
+        return self._book
+
+    def gather_free_grads(self):
+        """autograd-owned gradients -> their arena views (what finish_grads does after the convolutions' rows)"""
         dst, src = [], []
         for p, view in self._free:
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
@@ -272,6 +301,41 @@ class ModelRuntime:
             p.grad = view
         if dst:
             torch._foreach_copy_(dst, src)
+
+    def book_piece(self, optim, grad_rows, fold_rows, ranges, first, grad_scale=1.0):
+        """grad_rows / fold_rows: [(lo, hi)] of the bank's row table (rows_of); ranges: [(lo, hi)] floats of the arena.
+        Enqueued on the bookkeeping stream behind everything the current stream holds so far and behind the queued weight
+        gradients.  A convolution whose parameters are updated by a LATER piece must not be in fold_rows here."""
+        bank = self.bank
+        bank.flush_deferred()
+        bank.check_tables()
+        cur, book = torch.cuda.current_stream(self.device), self.book_stream()
+        book.wait_stream(cur)
+        if bank._side is not None:
+            book.wait_stream(bank._side)
+        with torch.cuda.stream(book):
+            for lo, hi in grad_rows:
+                bank.grads(lo, hi, join=False)
+            n = 0
+            for lo, hi in ranges:
+                if hi > lo:
+                    optim.step_range(lo, hi, first and n == 0, grad_scale)
+                    n += 1
+            for lo, hi in fold_rows:
+                bank.fold(lo, hi)
+
+    def book_join(self, all_folded=True):
+        """the current stream waits for the bookkeeping stream; with all_folded the images are marked current (the
+        prepare() at the top of the next step then has nothing to do)"""
+        if self._book is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._book)
+        self.bank.join_side()
+        if all_folded:
+            self.mark_folded()
+
+    def mark_folded(self):
+        a = self.arena
+        self._fold_stamp = (a.updates, a.param._version, sum(p._version for p in self.model.parameters()))
 
     def grad_sumsq(self):
         """sum of squares of all gradients, as a device scalar (no host sync)"""

@@ -56,7 +56,13 @@ class S2Engine:
         # data parallelism: gradients are reduced sub-model by sub-model on a side stream while the backward of the next
         # sub-model runs (EVT_DP_OVERLAP=0: the two whole-arena reductions between the phases, nothing overlapped)
         self.overlap = (reducer is not None and reducer.world > 1 and os.environ.get("EVT_DP_OVERLAP", "1") != "0")
-        if self.overlap:
+        # one GPU, EVT_BOOK_PIPE=1: the same cuts, used to run each sub-model's bookkeeping (weight-norm gradient, AdamW,
+        # refold) on a side stream under the backward of the next sub-model (ModelRuntime.book_piece).  Off by default:
+        # measured round 4, the launches do overlap (kernel trace) and the step does not get shorter -- 24.7-24.8 ms
+        # against 24.6-24.7 -- although it is 2.0 ms shorter without them: the backward next to them slows down by as much
+        self.pipe = ((reducer is None or reducer.world == 1) and self.device.type == "cuda"
+                     and os.environ.get("EVT_BOOK_PIPE", "0") == "1")
+        if self.overlap or self.pipe:
             self.net_g.split_backward = True
             nd = len(self.net_d.discriminators)
             self._d_ranges = [self.rt_d.arena.range_of_prefix(f"discriminators.{i}.") for i in range(nd)]
@@ -77,6 +83,12 @@ class S2Engine:
             # a range is reduced as soon as its convolutions' gradients are finished; a parameter whose gradient only
             # arrives with the final gather (an autograd-owned one) must not sit inside such a range -- it would be
             # reduced before it was written: silent gradient loss under data parallelism
+            # row ranges of the same pieces in the banks' tables; dec.cond's rows get their gradient with the vocoder's (its
+            # operands are complete then) but are refolded with the rest, after its parameters were updated
+            self._d_rows = [self.rt_d.bank.rows_of(c) for c in self._d_convs]
+            self._dec_rows = self.rt_g.bank.rows_of(self._dec_convs)
+            self._dec_rows_fold = self.rt_g.bank.rows_of([m for m in self._dec_convs if m is not self.net_g.dec.cond])
+            self._fq_rows = self.rt_g.bank.rows_of(self._fq_convs)
             early = [(self._dec_range, self.rt_g), (self._fq_range, self.rt_g)] + [(r, self.rt_d) for r in self._d_ranges]
             for (lo, hi), rt in early:
                 for p_, view in rt._free:
@@ -153,7 +165,7 @@ class S2Engine:
         st.gss_d = rt_d.grad_sumsq() * (st.inv_world * st.inv_world)   # norm of the AVERAGED gradient, as DDP logs it
         if st.hook_after_d is not None:
             st.hook_after_d()
-        if st.do_opt:
+        if st.do_opt and not getattr(st, "piped", False):
             self.optim_d.step(grad_scale=st.inv_world)   # 1/world averaging folded into the AdamW launch
             rt_d.prepare()   # D weights changed: refold before the generator's pass through D
         # ---- generator step (sovits.py:509-525) ----
@@ -213,17 +225,24 @@ class S2Engine:
         """the generator's backward below the vocoder, first part: KL term + the gradient saved at the vocoder's input
         -> flow, posterior encoder (both end at the second cut: their own copy of the style vector, detached prior
         statistics)"""
+        self._bwd_b1(st)
+        st.g_done.append(self.rt_g.finish_conv_grads(self._fq_convs))
+
+    def _bwd_b1(self, st):
         z_full, z_cut = self.net_g._cut[0]
         roots, grads = [st.loss_kl + st.kl_ssl * 1], [None]
         if z_cut.grad is not None:
             roots.append(z_full)
             grads.append(z_cut.grad)
         torch.autograd.backward(roots, grads)
-        st.g_done.append(self.rt_g.finish_conv_grads(self._fq_convs))
 
     def _phase_b2(self, st):
         """second part: the gradients that arrived at the cuts -> prior encoder (m_p, logs_p) and style encoder (the style
         vector as the vocoder, the flow and the posterior encoder used it)"""
+        self._bwd_b2(st)
+        self.rt_g.finish_grads(done=st.g_done)
+
+    def _bwd_b2(self, st):
         (ge, ge_dec), = self.net_g._cut[1:]
         (ge2, ge_fq), (m_p, m_p_cut), (logs_p, logs_p_cut) = self.net_g._cut2
         roots, grads = [], []
@@ -241,17 +260,62 @@ class S2Engine:
         if roots:
             torch.autograd.backward(roots, grads)
         self.net_g._cut = self.net_g._cut2 = None
-        self.rt_g.finish_grads(done=st.g_done)
+
+    # ---- one GPU: the whole step as one phase, every sub-model's bookkeeping enqueued right behind its backward ----
+    @staticmethod
+    def _complement(ivs, n):
+        out, at = [], 0
+        for lo, hi in sorted(ivs):
+            if lo > at:
+                out.append((at, lo))
+            at = max(at, hi)
+        if at < n:
+            out.append((at, n))
+        return out
+
+    def _phase_pipe(self, st):
+        rt_g, rt_d = self.rt_g, self.rt_d
+        st.piped = True
+        self._phase_a(st, backward=False)
+        order = list(reversed(range(len(self._d_convs))))
+        for n, i in enumerate(order):
+            st.d_losses[i].backward()
+            rt_d.book_piece(self.optim_d, [self._d_rows[i]], [self._d_rows[i]], [self._d_ranges[i]], first=n == 0)
+        left = self._complement(self._d_ranges, rt_d.arena.numel)      # nothing in today's discriminators
+        if left:
+            rt_d.book_piece(self.optim_d, [], [], left, first=False)
+        rt_d.gather_free_grads()
+        rt_d.book_join()
+        # ---- generator step: D update and refold are done; losses, then the backward in its three parts ----
+        self._phase_b(st, backward=False)
+        (st.loss_gen + st.loss_fm + st.loss_mel).backward()
+        rt_d.bank.weight_grads = True
+        rt_g.book_piece(self.optim_g, [self._dec_rows], [self._dec_rows_fold], [self._dec_range], first=True)
+        self._bwd_b1(st)
+        rt_g.book_piece(self.optim_g, [self._fq_rows], [self._fq_rows], [self._fq_range], first=False)
+        self._bwd_b2(st)
+        rt_g.gather_free_grads()
+        nrows = rt_g.bank._nrows
+        rt_g.book_piece(self.optim_g, self._complement([self._dec_rows, self._fq_rows], nrows),
+                        self._complement([self._dec_rows_fold, self._fq_rows], nrows),
+                        self._complement([self._dec_range, self._fq_range], rt_g.arena.numel), first=False)
+        rt_g.book_join()
+        st.gss_g = rt_g.grad_sumsq()
 
     def _reduce_async(self, flat, lo, hi):
         self.reducer.all_reduce(flat[lo:hi], async_op=True)
 
-    def _program(self):
-        """[(phase, host action after it)]: the phases are what a HIP graph captures, the actions run between them"""
-        if not self.overlap:
+    def _program(self, piped=True):
+        """[(phase, host action after it)]: the phases are what a HIP graph captures, the actions run between them.
+        piped=False: the caller needs the optimiser calls at their serial places (do_opt=False, hook_after_d)."""
+        if self.pipe and piped:
+            return [(self._phase_pipe, None)]
+        if not self.overlap and not self.pipe:
             return [(self._phase_a, lambda: self._reduce(self.rt_d.arena)),
                     (self._phase_b, lambda: self._reduce(self.rt_g.arena)), (self._phase_c, None)]
+        # the cut program (the generator's graph is built with its cuts: only this order of backward calls walks all of it)
         gd, gg, red = self.rt_d.arena.grad, self.rt_g.arena.grad, self.reducer
+        dp = self.overlap
         prog = [(self._phase_a0, None)]
         order = list(reversed(range(len(self._d_convs))))          # the reference's engine would also end with d0
         for n, i in enumerate(order):
@@ -262,24 +326,19 @@ class S2Engine:
                 self._reduce_async(gd, lo, hi)
                 if last:
                     red.wait()                                      # optim_d reads the reduced gradients
-            prog.append((lambda st, i=i: self._phase_a_bwd(st, i), after))
+            prog.append((lambda st, i=i: self._phase_a_bwd(st, i), after if dp else None))
         dlo, dhi = self._dec_range
-        prog.append((self._phase_b0, lambda: self._reduce_async(gg, dlo, dhi)))
+        prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
 
         flo, fhi = self._fq_range
-        prog.append((self._phase_b1, lambda: self._reduce_async(gg, flo, fhi)))
+        prog.append((self._phase_b1, (lambda: self._reduce_async(gg, flo, fhi)) if dp else None))
 
         def after_b2():
             # what is left: everything outside the two early ranges (prior / style encoders, dec.cond)
-            at = 0
-            for lo, hi in sorted([(dlo, dhi), (flo, fhi)]):
-                if lo > at:
-                    self._reduce_async(gg, at, lo)
-                at = hi
-            if at < gg.numel():
-                self._reduce_async(gg, at, gg.numel())
+            for lo, hi in self._complement([(dlo, dhi), (flo, fhi)], gg.numel()):
+                self._reduce_async(gg, lo, hi)
             red.wait()
-        prog.append((self._phase_b2, after_b2))
+        prog.append((self._phase_b2, after_b2 if dp else None))
         prog.append((self._phase_c, None))
         return prog
 
@@ -291,7 +350,7 @@ class S2Engine:
         st = SimpleNamespace(ssl=ssl, spec=spec, spec_lengths=spec_lengths, y=y, text=text, text_lengths=text_lengths,
                              eps=eps, ids_slice_in=ids_slice, do_opt=do_opt, hook_after_d=hook_after_d,
                              inv_world=1.0 / self.reducer.world if self.reducer is not None else 1.0)
-        for phase, after in self._program():
+        for phase, after in self._program(piped=do_opt and hook_after_d is None):
             phase(st)
             if after is not None:
                 after()
@@ -346,12 +405,20 @@ class S2Engine:
                 dst.copy_(src, non_blocking=True)
         self.optim_d._segments()    # scheduler changes reach the device tables (in place) before the replay
         self.optim_g._segments()
+        if self.pipe:
+            # the captured step refolds every image right after its update and holds no fold at its top: parameters
+            # written from outside since the last step (load_state_dict, broadcast) are folded here
+            self.rt_g.prepare()
+            self.rt_d.prepare()
         for g, after in zip(ent["graphs"], ent["after"]):
             g.replay()
             if after is not None:
                 after()
         self.optim_d.note_replayed_step()
         self.optim_g.note_replayed_step()
+        if self.pipe:
+            self.rt_g.mark_folded()
+            self.rt_d.mark_folded()
         self.graph_steps["replayed"] += 1
         return ent["result"]
 

@@ -356,6 +356,13 @@ int evt_adamw_flat(float* param, const float* grad, float* exp_avg, float* exp_a
 int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                        const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
                        int32_t* step_counter, float grad_scale, void* stream);
+/* The same update restricted to the elements [lo, hi) of the arena: lets a step update one sub-model's parameters as soon
+ * as its gradients are complete, on a side stream, under the backward of the next sub-model (AdamW is element-wise: the
+ * ranges of one step may run in any order and give the bits of the single launch).  bump != 0 increments *step_counter
+ * first -- exactly one range call per step passes it, the first one enqueued; all of them must be ordered after it. */
+int evt_adamw_flat_dev_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t lo, int64_t hi,
+                             const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                             int32_t* step_counter, int32_t bump, float grad_scale, void* stream);
 /* out[0] = sum(x^2) over n floats (grad-norm at commons.py:140-155 without the per-parameter .item()) */
 int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
 
