@@ -19,6 +19,54 @@ from . import conv as HC
 from . import lib as L
 
 
+def mpd_fold(periods, cd, src0, src1=None):
+    """[n, T] waveform batches (fp32 or bf16; src1 stacked behind src0) -> the prepared input of every sub-discriminator
+    in ONE launch (csrc/mpd_fold.hip): for period p a [(n0 + n1) * p, ceil(T / p), 1] tensor of dtype `cd`, period 1 =
+    DiscriminatorS.  No gradient (MPDFoldFn / MPDGenLossFn.backward call mpd_unfold)."""
+    src0 = src0.contiguous()
+    n0, T = src0.shape
+    n1, dt1 = 0, L.dt_of(src0)
+    if src1 is not None:
+        src1 = src1.contiguous()
+        n1, dt1 = src1.size(0), L.dt_of(src1)
+    outs = [torch.empty(((n0 + n1) * p, (T + p - 1) // p, 1), dtype=cd, device=src0.device) for p in periods]
+    per = (C.c_int32 * len(periods))(*periods)
+    ptrs = (C.c_void_p * len(periods))(*[o.data_ptr() for o in outs])
+    L.check(L.lib().evt_mpd_fold(L.dt_of(src0), L.ptr(src0), n0, dt1, L.ptr(src1), n1, T, per, len(periods), ptrs,
+                                 L.dt_of(outs[0]), L.stream_ptr()), "evt_mpd_fold")
+    return outs
+
+
+def mpd_unfold(periods, grads, b0, n, T, dtype):
+    """sum of the prepared batches' gradients (rows of items b0 .. b0 + n - 1) back onto the [n, T] waveform"""
+    grads = [g.contiguous() for g in grads]
+    out = torch.empty((n, T), dtype=dtype, device=grads[0].device)
+    per = (C.c_int32 * len(periods))(*periods)
+    ptrs = (C.c_void_p * len(periods))(*[g.data_ptr() for g in grads])
+    L.check(L.lib().evt_mpd_unfold(L.dt_of(grads[0]), ptrs, per, len(periods), b0, n, T, L.dt_of(out), L.ptr(out),
+                                   L.stream_ptr()), "evt_mpd_unfold")
+    return out
+
+
+class MPDFoldFn(torch.autograd.Function):
+    """differentiable mpd_fold of ONE waveform batch (the D path through the per-layer conv nodes; the generator step
+    folds inside MPDGenLossFn)"""
+
+    @staticmethod
+    def forward(ctx, x, periods, cd):
+        ctx.periods, ctx.shape, ctx.dtype = periods, tuple(x.shape), x.dtype
+        return tuple(mpd_fold(periods, cd, x))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, T = ctx.shape
+        gs = []
+        for g, p in zip(grads, ctx.periods):
+            gs.append(g if g is not None else torch.zeros((n * p, (T + p - 1) // p, 1), dtype=grads[0].dtype,
+                                                          device=grads[0].device))
+        return mpd_unfold(ctx.periods, gs, 0, n, T, ctx.dtype), None, None
+
+
 def _seg_table(a, b, da, scales, device):
     segs = [L.Seg(x.data_ptr(), y.data_ptr() if y is not None else None, g.data_ptr() if g is not None else None,
                   x.numel(), sc, 0) for x, y, g, sc in zip(a, b, da, scales)]
@@ -27,17 +75,19 @@ def _seg_table(a, b, da, scales, device):
 
 class MPDGenLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, plan, n_items, *xs):
-        """plan: per sub-discriminator (conv slots, (act, slope) per conv); xs: the prepared generated inputs
-        [n_i, L_i, 1] (differentiable) followed by the prepared real inputs (same shapes).
-        Returns (loss_gen, loss_fm, *generated logits [n_items, -1])."""
+    def forward(ctx, anchor, plan, periods, y_hat, y_real):
+        """plan: per sub-discriminator (conv slots, (act, slope) per conv); periods: its input period (1 = DiscriminatorS);
+        y_hat [n, T] the generated waveforms (differentiable), y_real [n, T].
+        Returns (loss_gen, loss_fm, *generated logits [n, -1])."""
         nd = len(plan)
-        fakes, reals = xs[:nd], xs[nd:]
-        dev = fakes[0].device
-        dt = L.dt_of(fakes[0])
+        n_items, T = y_hat.shape
+        dev = y_hat.device
+        cd = plan[0][0][0].bank.dtype
+        dt = L.DT_BF16 if cd == torch.bfloat16 else L.DT_F32
+        # [real ; generated] of every sub-discriminator, prepared in one launch
+        both = mpd_fold(periods, cd, y_real, y_hat)
         maps, saved = [], []           # per sub-D: list of batched outputs
-        for (slots, acts), xf, xr in zip(plan, fakes, reals):
-            x = torch.cat([xr, xf], dim=0)
+        for (slots, acts), x in zip(plan, both):
             ys = []
             for s, (act, slope) in zip(slots, acts):
                 x = HC._fwd(s, x, None, 1.0, act, slope)
@@ -60,7 +110,8 @@ class MPDGenLossFn(torch.autograd.Function):
                                             C.c_float(1.0), L.ptr(out[:1]), L.stream_ptr()), "evt_lsgan_multi_fwd")
         ctx.plan, ctx.dt = plan, dt
         ctx.counts = [len(ys) for ys in maps]
-        ctx.in_shapes = [tuple(x.shape) for x in fakes]
+        ctx.in_shapes = [(x.size(0) // 2, x.size(1), 1) for x in both]
+        ctx.periods, ctx.wav = periods, (n_items, T, y_hat.dtype)
         ctx.save_for_backward(*[y for ys in maps for y in ys])
         logits = [lg.reshape(n_items, -1).detach() for lg in la]
         ctx.mark_non_differentiable(*logits)
@@ -119,4 +170,5 @@ class MPDGenLossFn(torch.autograd.Function):
                 else:
                     dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, add, half, lin, 1.0, a_kind, a_slope)
             grads.append(dy)
-        return (None, None, None, *grads, *([None] * nd))
+        n_items, T, wdt = ctx.wav
+        return None, None, None, mpd_unfold(ctx.periods, grads, 0, n_items, T, wdt), None

@@ -553,7 +553,9 @@ class DiscriminatorP(nn.Module, _ComputeDtype):
 
     def forward(self, x):
         """x [N, T] fp32 waveform -> (logits [N, p*H'] , fmaps list of [N*p, H_i, C_i])"""
-        x = self.prepare(x)
+        return self.forward_prepared(self.prepare(x))
+
+    def forward_prepared(self, x):
         n = x.size(0) // self.period
         fmap = []
         for l in self.convs:
@@ -586,7 +588,9 @@ class DiscriminatorS(nn.Module, _ComputeDtype):
                 tuple([(L.ACT_LRELU, LRELU_SLOPE)] * len(self.convs) + [(L.ACT_NONE, 1.0)]))
 
     def forward(self, x):
-        x = self.prepare(x)
+        return self.forward_prepared(self.prepare(x))
+
+    def forward_prepared(self, x):
         fmap = []
         for l in self.convs:
             x = l(x, out_act=L.ACT_LRELU, out_slope=LRELU_SLOPE)
@@ -607,12 +611,30 @@ class MultiPeriodDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm)] +
                                             [DiscriminatorP(p, use_spectral_norm=use_spectral_norm) for p in periods])
 
+    def periods(self):
+        """input period of every sub-discriminator (1: DiscriminatorS takes the waveform itself)"""
+        return tuple(getattr(d, "period", 1) for d in self.discriminators)
+
+    def _prepared(self, y, y2=None):
+        """the prepared input of every sub-discriminator for the waveform batch [y ; y2]: on the GPU one launch for all of
+        them (hip/disc.py::mpd_fold), differentiable towards a single batch"""
+        if y.is_cuda:
+            from ..hip.disc import MPDFoldFn, mpd_fold
+
+            cd = self.discriminators[0].cd
+            if y2 is None and y.requires_grad:
+                return list(MPDFoldFn.apply(y, self.periods(), cd))
+            if y2 is None or not (y.requires_grad or y2.requires_grad):
+                return mpd_fold(self.periods(), cd, y, y2)
+        x = y if y2 is None else torch.cat([y.float(), y2.float()], dim=0)
+        return [d.prepare(x.float()) for d in self.discriminators]
+
     def forward_single(self, y):
         """y [N, 1, T] or [N, T] -> (logits list, fmaps list-of-lists)"""
-        y = y.reshape(y.size(0), -1).float()
+        y = y.reshape(y.size(0), -1)
         outs, fmaps = [], []
-        for d in self.discriminators:
-            o, f = d(y)
+        for d, x in zip(self.discriminators, self._prepared(y)):
+            o, f = d.forward_prepared(x)
             outs.append(o)
             fmaps.append(f)
         return outs, fmaps
@@ -624,23 +646,19 @@ class MultiPeriodDiscriminator(nn.Module):
         from ..hip.disc import MPDGenLossFn
 
         n = y.size(0)
-        yr, yg = y.reshape(n, -1).float(), y_hat.reshape(n, -1).float()
-        with torch.no_grad():
-            reals = [d.prepare(yr) for d in self.discriminators]
-        fakes = [d.prepare(yg) for d in self.discriminators]
         plan = tuple(d.plan() for d in self.discriminators)
         if any(s is None for slots, _ in plan for s in slots):
             raise L.EvtError("MultiPeriodDiscriminator used before WeightBank.attach(); there is no eager fallback")
         anchor = plan[0][0][0].bank.anchor
-        out = MPDGenLossFn.apply(anchor, plan, n, *fakes, *reals)
+        out = MPDGenLossFn.apply(anchor, plan, self.periods(), y_hat.reshape(n, -1).contiguous(),
+                                 y.reshape(n, -1).detach().contiguous())
         return out[0], out[1], list(out[2:])
 
     def forward(self, y, y_hat):
         n = y.size(0)
-        both = torch.cat([y.reshape(n, -1).float(), y_hat.reshape(n, -1).float()], dim=0)
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d in self.discriminators:
-            o, f = d(both)
+        for d, x in zip(self.discriminators, self._prepared(y.reshape(n, -1), y_hat.reshape(n, -1))):
+            o, f = d.forward_prepared(x)
             y_d_rs.append(o[:n])
             y_d_gs.append(o[n:])
             # sequences are ordered (item, period-phase): the first half of every fmap is the real audio

@@ -363,6 +363,19 @@ int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* e
 int evt_adamw_flat_dev_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t lo, int64_t hi,
                              const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
                              int32_t* step_counter, int32_t bump, float grad_scale, void* stream);
+/* Input side of MultiPeriodDiscriminator (src/easevoice/module/models.py:541-547 DiscriminatorP: reflect-pad to a multiple of
+ * the period, view [B, 1, T/p, p]; models.py:576-587 DiscriminatorS: the waveform itself = period 1) for ALL sub-discriminators
+ * in one launch.  The waveform batch is [src0 ; src1] (n0 + n1 items of T samples; src1 may be NULL with n1 = 0), for
+ * period p_i:   outs[i][(b * p_i + ph)][j][0] = x[b][t],  t = j * p_i + ph,  t >= T mirrored to 2T - 2 - t,
+ * outs[i] holding (n0 + n1) * p_i sequences of ceil(T / p_i) positions of one channel, in out_dtype.  nper <= 8; the two
+ * sources may differ in dtype (real audio fp32, generated audio in the compute dtype). */
+int evt_mpd_fold(int32_t src0_dtype, const void* src0, int32_t n0, int32_t src1_dtype, const void* src1, int32_t n1, int32_t T,
+                 const int32_t* periods, int32_t nper, void* const* outs, int32_t out_dtype, void* stream);
+/* Its backward: dsrc[b][t] = sum_i (douts[i] at the positions that read x[b0 + b][t], the mirrored tail included), for the
+ * n items starting at item b0 of the prepared batches (the generated half of [real ; generated]: b0 = n0). */
+int evt_mpd_unfold(int32_t grad_dtype, const void* const* douts, const int32_t* periods, int32_t nper, int32_t b0, int32_t n,
+                   int32_t T, int32_t dsrc_dtype, void* dsrc, void* stream);
+
 /* out[0] = sum(x^2) over n floats (grad-norm at commons.py:140-155 without the per-parameter .item()) */
 int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
 
