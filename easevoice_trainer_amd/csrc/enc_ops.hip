@@ -332,6 +332,53 @@ __global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigne
 
 __global__ void counter_add_kernel(unsigned* c, unsigned inc) { *c += inc; }
 
+
+// ---- mean-only residual coupling + Flip of the s2 flow, everything after the layer's `post` projection as one launch:
+//        y = flip_channels( [ x0 , (x1 + stats) * row_mask ] ),   x0n = first half of y in the compute dtype (what the next
+//      layer's `pre` projection reads).  Through torch: mask multiply, cast, multiply, add, cat, flip and the slice + cast of
+//      the next layer's input (7 launches, ~12 backward); the tensors are [B, T, 192] -- launch-bound ----
+template <typename T>
+__global__ void coupling_flip_fwd(const float* x, const T* stats, const int* lens, int rows_per_seq, long rows, int h,
+                                  float* y, T* x0n) {
+  const int C2 = 2 * h;
+  const long total = rows * C2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C2;
+    const int c = (int)(i - row * C2);
+    const int cs = C2 - 1 - c;
+    float v = x[row * C2 + cs];
+    if (cs >= h) {
+      bool live = true;
+      if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+      v = live ? v + to_f<T>(stats[row * h + cs - h]) : 0.f;
+    }
+    y[i] = v;
+    if (x0n && c < h) x0n[row * h + c] = from_f<T>(v);
+  }
+}
+
+// dy [rows][2h] (+ dx0n [rows][h] on its first half) -> dx [rows][2h], dstats [rows][h]
+template <typename T>
+__global__ void coupling_flip_bwd(const float* dy, const T* dx0n, const int* lens, int rows_per_seq, long rows, int h,
+                                  float* dx, T* dstats) {
+  const int C2 = 2 * h;
+  const long total = rows * C2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C2;
+    const int c = (int)(i - row * C2);
+    const int cs = C2 - 1 - c;
+    float t = dy[i];
+    if (dx0n && c < h) t += to_f<T>(dx0n[row * h + c]);
+    if (cs >= h) {
+      bool live = true;
+      if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+      t = live ? t : 0.f;
+      dstats[row * h + cs - h] = from_f<T>(t);
+    }
+    dx[row * C2 + cs] = t;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -380,6 +427,38 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
   else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_BWD(float, 2); else RDL_BWD(float, 4); }
   else return EVT_EINVAL;
 #undef RDL_BWD
+  return evt_check_launch();
+}
+
+int evt_coupling_flip_fwd(int32_t dtype, const float* x, const void* stats, const int32_t* lens, int32_t rows_per_seq,
+                          int64_t rows, int32_t h, float* y, void* x0n, void* stream) {
+  if (!x || !stats || !y || rows <= 0 || h <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
+  long blocks = (rows * 2 * h + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(coupling_flip_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, x, (const bf16_t*)stats, lens,
+                       rows_per_seq, (long)rows, h, y, (bf16_t*)x0n);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(coupling_flip_fwd<float>, dim3((int)blocks), dim3(256), 0, st, x, (const float*)stats, lens,
+                       rows_per_seq, (long)rows, h, y, (float*)x0n);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_coupling_flip_bwd(int32_t dtype, const float* dy, const void* dx0n, const int32_t* lens, int32_t rows_per_seq,
+                          int64_t rows, int32_t h, float* dx, void* dstats, void* stream) {
+  if (!dy || !dx || !dstats || rows <= 0 || h <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
+  long blocks = (rows * 2 * h + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(coupling_flip_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, dy, (const bf16_t*)dx0n, lens,
+                       rows_per_seq, (long)rows, h, dx, (bf16_t*)dstats);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(coupling_flip_bwd<float>, dim3((int)blocks), dim3(256), 0, st, dy, (const float*)dx0n, lens,
+                       rows_per_seq, (long)rows, h, dx, (float*)dstats);
+  else return EVT_EINVAL;
   return evt_check_launch();
 }
 

@@ -368,6 +368,49 @@ def wn_residual_last(rs, acc, lens):
     return WNResidualFn.apply(None, rs, acc, lens, True)
 
 
+class CouplingFlipFn(torch.autograd.Function):
+    """mean-only residual coupling + Flip after the layer's `post` projection (modules.py:404-458 with logs == 0, followed by
+    the Flip of models.py:273-315):  y = flip([x0, (x1 + stats) * mask]) in fp32 and x0n = y[..., :h] in the compute dtype
+    -- the next layer's projection input -- in ONE launch (evt_coupling_flip_fwd); the backward takes the gradients of both
+    outputs in one launch.  x [B, T, 2h] fp32, stats [B, T, h] compute dtype (unmasked), lens [B] int32."""
+
+    @staticmethod
+    def forward(ctx, x, stats, lens, want_x0n):
+        B, T, C2 = x.shape
+        h = C2 // 2
+        x = x.contiguous()
+        stats = stats.contiguous()
+        y = torch.empty_like(x)
+        x0n = torch.empty((B, T, h), dtype=stats.dtype, device=x.device) if want_x0n else None
+        L.check(L.lib().evt_coupling_flip_fwd(L.dt_of(stats), L.ptr(x), L.ptr(stats), L.ptr(lens), T, C.c_int64(B * T), h,
+                                              L.ptr(y), L.ptr(x0n), L.stream_ptr()), "evt_coupling_flip_fwd")
+        ctx.save_for_backward(lens)
+        ctx.dims, ctx.sdt = (B, T, h), stats.dtype
+        if want_x0n:
+            return y, x0n
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, dx0n):
+        lens, = ctx.saved_tensors
+        B, T, h = ctx.dims
+        if dy is None:
+            dy = torch.zeros((B, T, 2 * h), dtype=torch.float32, device=lens.device)
+        dy = dy.contiguous()
+        if dx0n is not None:
+            dx0n = dx0n.to(ctx.sdt).contiguous()
+        dx = torch.empty_like(dy)
+        dstats = torch.empty((B, T, h), dtype=ctx.sdt, device=dy.device)
+        dt = L.DT_BF16 if ctx.sdt == torch.bfloat16 else L.DT_F32
+        L.check(L.lib().evt_coupling_flip_bwd(dt, L.ptr(dy), L.ptr(dx0n), L.ptr(lens), T, C.c_int64(B * T), h, L.ptr(dx),
+                                              L.ptr(dstats), L.stream_ptr()), "evt_coupling_flip_bwd")
+        return dx, dstats, None, None
+
+
+def coupling_flip(x, stats, lens, want_x0n=True):
+    return CouplingFlipFn.apply(x, stats, lens, want_x0n)
+
+
 class UnbindRowsFn(torch.autograd.Function):
     """t [L, ...] -> L views; the backward stacks the L gradients with ONE concatenation (torch's unbind backward
     zero-fills and copies per slice)."""

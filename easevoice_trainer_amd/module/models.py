@@ -164,6 +164,18 @@ class ResidualCouplingLayer(nn.Module, _ComputeDtype):
             x1 = (x1 - m) * torch.exp(-logs) * x_mask
         return torch.cat([x0, x1], dim=-1)
 
+    def forward_flip(self, x, x0c, x_mask, mask_cd, g, lens, want_next):
+        """this layer followed by its Flip, training direction, mean_only, on the GPU: (flipped output [B, T, C] fp32, its
+        first half in the compute dtype for the next layer's `pre` or None).  x0c: x[..., :half] in the compute dtype as
+        the previous layer left it (None: taken from x)."""
+        from ..hip.enc import coupling_flip
+
+        if x0c is None:
+            x0c = x[..., :self.half_channels]
+        h = (self.pre(x0c) * mask_cd).contiguous()
+        h = self.enc(h, x_mask, g=g, lens=lens)
+        return coupling_flip(x, self.post(h), lens, want_next)
+
 
 class Flip(nn.Module):
     def forward(self, x, *args, **kwargs):
@@ -182,6 +194,15 @@ class ResidualCouplingBlock(nn.Module):
             self.flows.append(Flip())
 
     def forward(self, x, x_mask, g=None, reverse=False, lens=None):
+        if (not reverse and x.is_cuda and lens is not None and x.dtype == torch.float32
+                and all(f.mean_only for f in self.flows[0::2])):
+            # every coupling layer with its Flip: the element-wise tail of a layer and the head of the next in one launch
+            x0c = None
+            n = len(self.flows) // 2
+            mask_cd = x_mask.to(self.flows[0].cd)
+            for i in range(n):
+                x, x0c = self.flows[2 * i].forward_flip(x, x0c, x_mask, mask_cd, g, lens, want_next=i + 1 < n)
+            return x
         flows = self.flows if not reverse else reversed(self.flows)
         for flow in flows:
             x = flow(x, x_mask, g=g, reverse=reverse, lens=lens)

@@ -504,6 +504,16 @@ int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, 
 int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void* acc, const int32_t* lens,
                         int32_t rows_per_seq, void* x_out, void* acc_out, int64_t rows, int32_t H, int32_t last,
                         void* stream);
+/* Mean-only residual coupling + Flip of the s2 flow (src/easevoice/module/modules.py:404-458 forward with logs == 0,
+ * models.py:273-315: flows = [coupling, Flip] x 4), everything after the layer's `post` projection in one launch:
+ *   y[row][c] = v[row][2h-1-c],  v = [ x[:, :h] , (x[:, h:] + stats) * row_mask ];  x0n = y[:, :h] in `dtype` (the next
+ *   layer's projection input) or NULL.  x, y fp32 [rows][2h]; stats [rows][h] in `dtype`; the row mask from lens as above. */
+int evt_coupling_flip_fwd(int32_t dtype, const float* x, const void* stats, const int32_t* lens, int32_t rows_per_seq,
+                          int64_t rows, int32_t h, float* y, void* x0n, void* stream);
+/* dy [rows][2h] fp32 (+ dx0n [rows][h] in `dtype`, the gradient that arrived at x0n; may be NULL) ->
+ * dx [rows][2h] fp32, dstats [rows][h] in `dtype` */
+int evt_coupling_flip_bwd(int32_t dtype, const float* dy, const void* dx0n, const int32_t* lens, int32_t rows_per_seq,
+                          int64_t rows, int32_t h, float* dx, void* dstats, void* stream);
 int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out, const int32_t* lens,
                         int32_t rows_per_seq, void* dx, void* drs, int64_t rows, int32_t H, int32_t last, void* stream);
 

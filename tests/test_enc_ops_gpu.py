@@ -180,3 +180,44 @@ def test_wn_stack_node(gpu, dtype):
     close(gg.grad, gr.grad, "dg")
     for k, p_ in m.named_parameters():
         close(p_.grad, sd[k].grad, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_coupling_flip_equals_torch_composition(gpu, dtype):
+    """the fused tail of a mean-only coupling layer + Flip (hip/enc.py::CouplingFlipFn) against the torch lines it replaces
+    (models.py ResidualCouplingLayer.forward + Flip), values and both gradients, with the next layer's input as a second
+    consumer; exact in fp32, bf16 only rounds the stored x0n / dstats"""
+    from easevoice_trainer_amd.hip.enc import coupling_flip
+
+    B, T, h = 3, 37, 96
+    g = torch.Generator().manual_seed(3)
+    lens = torch.tensor([37, 20, 1], dtype=torch.int32, device=gpu)
+    mask = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    x = torch.randn(B, T, 2 * h, generator=g).to(gpu).requires_grad_(True)
+    stats = torch.randn(B, T, h, generator=g).to(gpu).to(dtype).requires_grad_(True)
+    wy = torch.randn(B, T, 2 * h, generator=g).to(gpu)
+    wn = torch.randn(B, T, h, generator=g).to(gpu)
+
+    def ref(x, stats):
+        x0, x1 = torch.split(x, [h, h], dim=-1)
+        st = (stats * mask.to(stats.dtype)).float()
+        y = torch.flip(torch.cat([x0, st + x1 * mask], dim=-1), [-1])
+        return y, y[..., :h].to(dtype)
+
+    y_r, n_r = ref(x, stats)
+    ((y_r * wy).sum() + (n_r.float() * wn).sum()).backward()
+    gx_r, gs_r = x.grad.clone(), stats.grad.clone()
+    x.grad = stats.grad = None
+    y, n = coupling_flip(x, stats, lens, True)
+    assert torch.equal(y, y_r) and torch.equal(n, n_r)
+    ((y * wy).sum() + (n.float() * wn).sum()).backward()
+    tol = 0 if dtype == torch.float32 else 2e-2
+    assert (x.grad - gx_r).abs().max() <= tol * gx_r.abs().max() + 1e-6
+    assert (stats.grad.float() - gs_r.float()).abs().max() <= tol * gs_r.float().abs().max() + 1e-6
+    # without the second output (the block's last layer)
+    x.grad = stats.grad = None
+    y2, none = coupling_flip(x, stats, lens, False)
+    assert none is None and torch.equal(y2, y_r)
+    (y2 * wy).sum().backward()
+    x0g = torch.autograd.grad((ref(x, stats)[0] * wy).sum(), x)[0]
+    assert torch.allclose(x.grad, x0g, rtol=0, atol=1e-6)
