@@ -67,6 +67,12 @@ def feature_loss(fmap_r, fmap_g):
     return _SegLossFn.apply(0, 0.0, sc, len(a), *a, *b)
 
 
+def l1_mean_scaled(a, b, scale):
+    """scale * mean|a - b| with b as the constant side (the mel reconstruction term, sovits.py:513: F.l1_loss * c_mel):
+    one reduction launch forward, one backward, where F.l1_loss runs sub / abs / mean / mul and their four gradients"""
+    return _SegLossFn.apply(0, 0.0, [float(scale) / a.numel()], 1, a, b.detach())
+
+
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
     """losses.py:18-32: sum_i mean((1-dr_i)^2) + mean(dg_i^2).  Returns the scalar only (the per-term
     python lists of the reference exist to be `.item()`-ed for logging, which this path avoids)."""
@@ -75,6 +81,46 @@ def discriminator_loss(disc_real_outputs, disc_generated_outputs):
     g = _SegLossFn.apply(1, 0.0, [1.0 / t.numel() for t in disc_generated_outputs], len(disc_generated_outputs),
                          *disc_generated_outputs)
     return r + g
+
+
+class _DLossBatchedFn(torch.autograd.Function):
+    """discriminator_loss over logits that hold BOTH halves, o_i = [real ; generated] rows (how the D step runs every
+    sub-discriminator): the same two reductions, their gradients written into the two halves of ONE tensor per o_i --
+    no zero-padded slice gradients and no sums of them (3 launches per sub-discriminator through o[:n] / o[n:])."""
+
+    @staticmethod
+    def forward(ctx, *outs):
+        outs = [o.contiguous() for o in outs]
+        dev, dt = outs[0].device, L.dt_of(outs[0])
+        halves = [(o[: o.size(0) // 2], o[o.size(0) // 2:]) for o in outs]
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        for k, target in ((0, 1.0), (1, 0.0)):
+            segs = [h[k] for h in halves]
+            tab = _table([(t, None) for t in segs], [1.0 / t.numel() for t in segs], [None] * len(segs), dev)
+            L.check(L.lib().evt_lsgan_multi_fwd(dt, L.ptr(tab), len(segs), C.c_float(target), L.ptr(out), L.stream_ptr()),
+                    "evt_lsgan_multi_fwd")
+        ctx.dt = dt
+        ctx.save_for_backward(*outs)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        outs = ctx.saved_tensors
+        dev = outs[0].device
+        grads = [torch.empty_like(o) for o in outs]
+        dl = dloss.reshape(1).float().contiguous()
+        for k, target in ((0, 1.0), (1, 0.0)):
+            segs = [(o[: o.size(0) // 2], g[: o.size(0) // 2]) if k == 0 else (o[o.size(0) // 2:], g[o.size(0) // 2:])
+                    for o, g in zip(outs, grads)]
+            tab = _table([(a, None) for a, _ in segs], [1.0 / a.numel() for a, _ in segs], [g for _, g in segs], dev)
+            L.check(L.lib().evt_lsgan_multi_bwd(ctx.dt, L.ptr(tab), len(segs), C.c_float(target), L.ptr(dl),
+                                                L.stream_ptr()), "evt_lsgan_multi_bwd")
+        return tuple(grads)
+
+
+def discriminator_loss_batched(outs):
+    """discriminator_loss(real halves, generated halves) of logits o_i [2n, ...] = [real ; generated]"""
+    return _DLossBatchedFn.apply(*outs)
 
 
 def generator_loss(disc_outputs):

@@ -675,6 +675,13 @@ class MultiPeriodDiscriminator(nn.Module):
                                  y.reshape(n, -1).detach().contiguous())
         return out[0], out[1], list(out[2:])
 
+    def forward_batched(self, y, y_hat):
+        """the D step's pass: logits of every sub-discriminator over [real ; generated] as ONE tensor each ([2n, -1]; the
+        first n rows are the real audio) -- for losses.discriminator_loss_batched, which needs no slices"""
+        n = y.size(0)
+        return [d.forward_prepared(x)[0] for d, x in zip(self.discriminators,
+                                                         self._prepared(y.reshape(n, -1), y_hat.reshape(n, -1)))]
+
     def forward(self, y, y_hat):
         n = y.size(0)
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []

@@ -20,7 +20,8 @@ from torch.nn import functional as F
 from ..hip import lib as L
 from ..hip.enc import bump_rng
 from ..module import commons
-from ..module.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+from ..module.losses import (discriminator_loss, discriminator_loss_batched, feature_loss, generator_loss, kl_loss,
+                             l1_mean_scaled)
 from ..module.mel_processing import mel_spectrogram_torch, spec_to_mel_slices
 from ..module.models import MultiPeriodDiscriminator, SynthesizerTrn
 from ..runtime import FlatAdamW, ModelRuntime
@@ -149,13 +150,23 @@ class S2Engine:
         st.y_seg = commons.slice_segments_1d(st.y.squeeze(1), st.ids_slice * hop, seg)
         # ---- discriminator step (sovits.py:497-507) ----
         rt_d.bank.weight_grads = True
-        y_d_hat_r, y_d_hat_g, _, _ = net_d(st.y_seg, st.y_hat.detach())
+        if self.device.type == "cuda":
+            # logits over [real ; generated] as one tensor per sub-discriminator: the loss writes both halves' gradients
+            outs = net_d.forward_batched(st.y_seg, st.y_hat.detach())
+            if not backward:
+                st.d_losses = [discriminator_loss_batched([o]) for o in outs]
+            else:
+                st.loss_disc = discriminator_loss_batched(outs)
+        else:
+            y_d_hat_r, y_d_hat_g, _, _ = net_d(st.y_seg, st.y_hat.detach())
+            if not backward:
+                st.d_losses = [discriminator_loss([r], [g]) for r, g in zip(y_d_hat_r, y_d_hat_g)]
+            else:
+                st.loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
         if not backward:
-            st.d_losses = [discriminator_loss([r], [g]) for r, g in zip(y_d_hat_r, y_d_hat_g)]
             st.d_done = []
             st.loss_disc = torch.stack([l.detach() for l in st.d_losses]).sum()
             return
-        st.loss_disc = discriminator_loss(y_d_hat_r, y_d_hat_g)
         st.loss_disc.backward()
         rt_d.finish_grads()
 
@@ -173,7 +184,10 @@ class S2Engine:
         # D on real + generated audio, feature / generator losses, gradients towards y_hat: one autograd node
         st.loss_gen, st.loss_fm, st.y_d_hat_g = net_d.generator_losses(st.y_seg, st.y_hat)
         z, z_p, m_p, logs_p, m_q, logs_q = st.lat
-        st.loss_mel = F.l1_loss(st.y_mel, st.y_hat_mel) * t["c_mel"]
+        if self.device.type == "cuda" and st.y_mel.dtype == st.y_hat_mel.dtype:
+            st.loss_mel = l1_mean_scaled(st.y_hat_mel, st.y_mel, t["c_mel"])
+        else:
+            st.loss_mel = F.l1_loss(st.y_mel, st.y_hat_mel) * t["c_mel"]
         st.loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, st.z_mask, lens=st.spec_lengths) * t["c_kl"]
         st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
         if not backward:
