@@ -1326,6 +1326,9 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
     hipLaunchKernelGGL(conv_deep32, dim3(8 * ((p.P + 7) / 8) * p.Y, nphase), dim3(256), lds32, st, p);
     return evt_check_launch();
   }
+  // Tried in round 4 and dropped: this 128 x 128 tile on the 3- / 4-stage ring of conv_ring (96 / 128 KiB of LDS, ONE block
+  // per CU) instead of two double-buffered blocks per CU -- 1024 -> 1024 k5: 104 -> 134-142 us forward, the s2 step
+  // 23.8 -> 24.4 / 24.8 ms.  Four waves per CU cannot cover their own fragment-read latency; the second resident block does.
   static bool attr = false;
   const size_t lds = 2 * STAGE_BYTES;
   if (!attr) {
