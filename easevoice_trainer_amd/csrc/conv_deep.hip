@@ -687,10 +687,7 @@ __device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned
   for (int t = 0; t < GKT; ++t) { r.u = make_uint4(bl[t].x, bl[t].y, bh[t].x, bh[t].y); b[t] = r.v; }
 }
 
-// NS: stages of the LDS ring (32 KiB each).  The reduction of one block is a chain of 64-token stages whose operands come
-// through LDS-DMA; with two buffers one stage is in flight per block (two blocks per CU: 64 KiB in flight per CU) and the
-// kernel ran at the pace of one memory round trip per stage (1.8 us per stage at 600 TFLOP/s against 0.4 us of LDS reads +
-// MFMAs).  NS = 4: three stages in flight behind counted waits, one raw barrier per stage, one block per CU.
+// NS: stages of the LDS ring (32 KiB each); the product launches NS = 2 (two blocks per CU), see launch_wgrad_gemm_grid.
 template <int NS>
 __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int stages_per_split) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1457,9 +1454,9 @@ static int launch_wgrad_gemm_ns(const WgP& p, long tiles, int per, hipStream_t s
 }
 
 static int launch_wgrad_gemm_grid(const WgP& p, long tiles, int per, hipStream_t st) {
-  static const int ns = getenv("EVT_WGRAD_GEMM_NS") ? atoi(getenv("EVT_WGRAD_GEMM_NS")) : 2;
-  if (ns == 4) return launch_wgrad_gemm_ns<4>(p, tiles, per, st);
-  if (ns == 3) return launch_wgrad_gemm_ns<3>(p, tiles, per, st);
+  // NS = 3 / 4 (one block per CU) measured slower than two double-buffered blocks per CU: 367-430 against 600-800 TFLOP/s
+  // at [32768, 2048, 512] -- the stage is not waiting for its DMA, a wave is waiting for its own transpose reads, and only
+  // a second resident block fills that (PMC: LDS array 12 % busy, no bank conflicts, MFMA 20 %)
   return launch_wgrad_gemm_ns<2>(p, tiles, per, st);
 }
 

@@ -129,10 +129,9 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
     stage(p.g2, rs, P, q0, [&](const uint4 raw, const int, const int, unsigned char* d) { *reinterpret_cast<uint4*>(d) = raw; });
   }
 
-  // weight fragments (global, L2-resident): a ring of R sets, requested R - 2 K steps ahead.  What a block can stream
-  // through its CU is (bytes in flight) / (L2 round trip): with a wave fetching its own rows only, that is
-  // 4 waves x (R - 2) x MTW KB -- 16 KB at R = 4, where the C = 128 launch ran at the pace of its weight stream (20 GB/s per
-  // CU); K steps behind the last one re-load the last fragment (clamped index) so that no load sits behind a branch
+  // weight fragments (global, L2-resident): a ring of R sets, requested R - 2 K steps ahead (4 waves x (R - 2) x MTW KB in
+  // flight per block; deeper rings measured alike, see evt_resunit_wide_fwd); K steps behind the last one re-load the last
+  // fragment (clamped index) so that no load sits behind a branch
   u32x4 fa[R][MTW];
   const bf16_t* wrow[MTW];
   auto set_w = [&](const bf16_t* w) {
@@ -340,16 +339,12 @@ int evt_resunit_wide_fwd(const evt_resunit_params* a, const void* x, const void*
   //             2x2 waves, 256 positions (320 blocks)  26 / 33 / 41   |  4x1, 80 positions               26 / 28 / 36
   // i.e. what counts is weight bytes per MFMA: four waves along the channels (a wave fetches only its own rows) and as
   // many position tiles per wave as the accumulators allow.  The first convolution covers P + 2 * 5 rows: 176 >= 170.
-  static const int ring = getenv("EVT_WIDE_R") ? atoi(getenv("EVT_WIDE_R")) : 0;      // prefetch-depth experiments
-  if (a->C == 128) {
-    if (ring == 4) return launch<128, 4, 1, 11, 10, false, 4>(p, st);
-    if (ring == 5) return launch<128, 4, 1, 11, 10, false, 5>(p, st);
-    return launch<128, 4, 1, 11, 10, false, 6>(p, st);
-  }
-  if (ring == 4) return launch<64, 4, 1, 11, 10, false, 4>(p, st);
-  if (ring == 6) return launch<64, 4, 1, 11, 10, false, 6>(p, st);
-  if (ring == 12) return launch<64, 4, 1, 11, 10, false, 12>(p, st);
-  return launch<64, 4, 1, 11, 10, false, 8>(p, st);
+  // ring depth R (weight fragment sets, requested R - 2 K steps ahead): 4, 5, 6, 8, 12 measured alike (C = 128, k = 11:
+  // 40.9 / 41.1 / 41.3 / 41.6 / 41.3 us) -- the launch is not waiting for its weight stream; per K step a wave issues
+  // 22 MFMAs (352 cycles) and, with all four waves of the block reading every row fragment, the LDS delivers 45 KB
+  // (352 cycles at 128 B/clk): the two are equal, and whatever fails to overlap shows (t = 19 us + 2 x MFMA time).
+  if (a->C == 128) return launch<128, 4, 1, 11, 10, false, 4>(p, st);
+  return launch<64, 4, 1, 11, 10, false, 4>(p, st);
 }
 
 int evt_resunit_wide_bwd_data(const evt_resunit_params* a, const void* dy, float dy_scale, const void* xa, const void* mid_a,
