@@ -504,7 +504,7 @@ int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, 
 int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void* acc, const int32_t* lens,
                         int32_t rows_per_seq, void* x_out, void* acc_out, int64_t rows, int32_t H, int32_t last,
                         void* stream);
-/* Mean-only residual coupling + Flip of the s2 flow (src/easevoice/module/modules.py:404-458 forward with logs == 0,
+/* Mean-only residual coupling + Flip of the s2 flow (src/easevoice/module/modules.py:404-458 forward with logs == 0 (mean_only),
  * models.py:273-315: flows = [coupling, Flip] x 4), everything after the layer's `post` projection in one launch:
  *   y[row][c] = v[row][2h-1-c],  v = [ x[:, :h] , (x[:, h:] + stats) * row_mask ];  x0n = y[:, :h] in `dtype` (the next
  *   layer's projection input) or NULL.  x, y fp32 [rows][2h]; stats [rows][h] in `dtype`; the row mask from lens as above. */
