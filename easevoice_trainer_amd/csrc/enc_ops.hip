@@ -15,6 +15,7 @@
 // Dropout: keep(element) = hash(*seed_dev, site, element index) >= p * 2^32, scaled by 1/(1-p).  *seed_dev is a device
 // counter the engine bumps once per step (evt_counter_inc), so a replayed HIP graph draws fresh masks every step.
 #include "evt_common.h"
+#include <type_traits>
 #include "../../include/evt.h"
 
 namespace {
@@ -333,6 +334,100 @@ __global__ void relu_dropout_bwd(const T* x, const T* dy, float p, const unsigne
 __global__ void counter_add_kernel(unsigned* c, unsigned inc) { *c += inc; }
 
 
+// ---- style encoder element-wise chains (src/easevoice/module/modules.py:521-566, 685-763) ----
+// Mish + dropout:  y = drop(x * tanh(softplus(x)))  -- torch: cast, softplus, tanh, mul, dropout (5 launches, 6 backward)
+__device__ __forceinline__ float mish_f(float x) {
+  const float sp = x > 20.f ? x : log1pf(__expf(x));       // F.softplus: threshold 20
+  return x * tanhf(sp);
+}
+__device__ __forceinline__ float mish_grad(float x) {
+  const float sp = x > 20.f ? x : log1pf(__expf(x));
+  const float t = tanhf(sp);
+  const float sg = 1.f / (1.f + __expf(-x));                // d softplus / dx
+  return t + x * (1.f - t * t) * sg;
+}
+// x in T, y (and dy) in TY: the reference's autocast leaves Mish / the GLU residual stream in fp32 next to half-precision
+// projections; [B, T, 128] tensors -- launch-bound, one element per thread and pass
+template <typename T, typename TY>
+__global__ void mish_dropout_fwd(const T* x, float p, const unsigned* seed_dev, unsigned site, TY* y, long n) {
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = from_f<TY>(mish_f(to_f<T>(x[i])) * drop_mult(dc, (unsigned long)i));
+}
+template <typename T, typename TY>
+__global__ void mish_dropout_bwd(const T* x, const TY* dy, float p, const unsigned* seed_dev, unsigned site, T* dx, long n) {
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = from_f<T>(to_f<TY>(dy[i]) * drop_mult(dc, (unsigned long)i) * mish_grad(to_f<T>(x[i])));
+}
+// Conv1dGLU tail:  y = res + drop(h[:, :C] * sigmoid(h[:, C:]))  -- torch: sigmoid, mul, dropout, add (+ 6 backward);
+// h (and dh) in T, res / y / dy in TR
+template <typename T, typename TR>
+__global__ void glu_dropout_res_fwd(const T* h, const TR* res, float p, const unsigned* seed_dev, unsigned site, TR* y,
+                                    long rows, int C) {
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  const long n = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    const float sg = 1.f / (1.f + __expf(-to_f<T>(h[row * 2 * C + C + c])));
+    y[i] = from_f<TR>(to_f<TR>(res[i]) + to_f<T>(h[row * 2 * C + c]) * sg * drop_mult(dc, (unsigned long)i));
+  }
+}
+template <typename T, typename TR>
+__global__ void glu_dropout_res_bwd(const T* h, const TR* dy, float p, const unsigned* seed_dev, unsigned site, T* dh,
+                                    long rows, int C) {
+  const DropCfg dc = drop_cfg(p, seed_dev, site);
+  const long n = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    const float a = to_f<T>(h[row * 2 * C + c]);
+    const float sg = 1.f / (1.f + __expf(-to_f<T>(h[row * 2 * C + C + c])));
+    const float g = to_f<TR>(dy[i]) * drop_mult(dc, (unsigned long)i);
+    dh[row * 2 * C + c] = from_f<T>(g * sg);
+    dh[row * 2 * C + C + c] = from_f<T>(g * a * sg * (1.f - sg));
+  }
+}
+
+// ---- posterior encoder tail (src/easevoice/module/models.py:352-358):  stats = proj(h) * mask;  m, logs = split(stats);
+//      z = (m + eps * exp(logs)) * mask  -- mask, cast, split, exp, multiply, add, mask as one launch (and one backward) ----
+template <typename T>
+__global__ void reparam_fwd(const T* stats, const float* eps, const int* lens, int rows_per_seq, long rows, int C, float* z,
+                            float* m, float* logs) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    bool live = true;
+    if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+    const float mv = live ? to_f<T>(stats[row * 2 * C + c]) : 0.f;
+    const float lv = live ? to_f<T>(stats[row * 2 * C + C + c]) : 0.f;
+    m[i] = mv;
+    logs[i] = lv;
+    z[i] = live ? mv + eps[i] * __expf(lv) : 0.f;
+  }
+}
+template <typename T>
+__global__ void reparam_bwd(const float* dz, const float* dm, const float* dlogs, const float* eps, const float* logs,
+                            const int* lens, int rows_per_seq, long rows, int C, T* dstats) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    bool live = true;
+    if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
+    float gm = 0.f, gl = 0.f;
+    if (live) {
+      const float gz = dz ? dz[i] : 0.f;
+      gm = gz + (dm ? dm[i] : 0.f);
+      gl = gz * eps[i] * __expf(logs[i]) + (dlogs ? dlogs[i] : 0.f);
+    }
+    dstats[row * 2 * C + c] = from_f<T>(gm);
+    dstats[row * 2 * C + C + c] = from_f<T>(gl);
+  }
+}
+
 // ---- mean-only residual coupling + Flip of the s2 flow, everything after the layer's `post` projection as one launch:
 //        y = flip_channels( [ x0 , (x1 + stats) * row_mask ] ),   x0n = first half of y in the compute dtype (what the next
 //      layer's `pre` projection reads).  Through torch: mask multiply, cast, multiply, add, cat, flip and the slice + cast of
@@ -381,6 +476,24 @@ __global__ void coupling_flip_bwd(const float* dy, const T* dx0n, const int* len
 
 }  // namespace
 
+static inline dim3 ew_grid(long nv) {
+  long blocks = (nv + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return dim3((int)blocks);
+}
+
+// dtype: x / h (and dx / dh); wide_dtype: y / res / dy -- the same, or fp32 next to bf16 operands.  f(T*, TR*) launches
+// the instantiation for the pair.
+template <typename F>
+static int mixed_dispatch(int32_t dtype, int32_t wide_dtype, F&& f) {
+  if (dtype == EVT_DT_BF16 && wide_dtype == EVT_DT_BF16) f((bf16_t*)nullptr, (bf16_t*)nullptr);
+  else if (dtype == EVT_DT_BF16 && wide_dtype == EVT_DT_F32) f((bf16_t*)nullptr, (float*)nullptr);
+  else if (dtype == EVT_DT_F32 && wide_dtype == EVT_DT_F32) f((float*)nullptr, (float*)nullptr);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
 extern "C" {
 
 int evt_counter_inc(uint32_t* counter, uint32_t inc, void* stream) {
@@ -428,6 +541,80 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
   else return EVT_EINVAL;
 #undef RDL_BWD
   return evt_check_launch();
+}
+
+
+int evt_reparam_fwd(int32_t dtype, const void* stats, const float* eps, const int32_t* lens, int32_t rows_per_seq,
+                    int64_t rows, int32_t C, float* z, float* m, float* logs, void* stream) {
+  if (!stats || !eps || !z || !m || !logs || rows <= 0 || C <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(reparam_fwd<bf16_t>, ew_grid(rows * C), dim3(256), 0, st, (const bf16_t*)stats, eps, lens, rows_per_seq,
+                       (long)rows, C, z, m, logs);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(reparam_fwd<float>, ew_grid(rows * C), dim3(256), 0, st, (const float*)stats, eps, lens, rows_per_seq,
+                       (long)rows, C, z, m, logs);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+int evt_reparam_bwd(int32_t dtype, const float* dz, const float* dm, const float* dlogs, const float* eps, const float* logs,
+                    const int32_t* lens, int32_t rows_per_seq, int64_t rows, int32_t C, void* dstats, void* stream) {
+  if (!eps || !logs || !dstats || rows <= 0 || C <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EVT_DT_BF16)
+    hipLaunchKernelGGL(reparam_bwd<bf16_t>, ew_grid(rows * C), dim3(256), 0, st, dz, dm, dlogs, eps, logs, lens, rows_per_seq,
+                       (long)rows, C, (bf16_t*)dstats);
+  else if (dtype == EVT_DT_F32)
+    hipLaunchKernelGGL(reparam_bwd<float>, ew_grid(rows * C), dim3(256), 0, st, dz, dm, dlogs, eps, logs, lens, rows_per_seq,
+                       (long)rows, C, (float*)dstats);
+  else return EVT_EINVAL;
+  return evt_check_launch();
+}
+
+#define EVT_TT(t, tr) using T = std::remove_pointer_t<decltype(t)>; using TR = std::remove_pointer_t<decltype(tr)>
+
+int evt_mish_dropout_fwd(int32_t dtype, int32_t wide_dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site,
+                         void* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return mixed_dispatch(dtype, wide_dtype, [&](auto* t, auto* tr) {
+    EVT_TT(t, tr);
+    hipLaunchKernelGGL((mish_dropout_fwd<T, TR>), ew_grid(n), dim3(256), 0, st, (const T*)x, p, seed_dev, site, (TR*)y, (long)n);
+  });
+}
+
+int evt_mish_dropout_bwd(int32_t dtype, int32_t wide_dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev,
+                         uint32_t site, void* dx, int64_t n, void* stream) {
+  if (!x || !dy || !dx || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return mixed_dispatch(dtype, wide_dtype, [&](auto* t, auto* tr) {
+    EVT_TT(t, tr);
+    hipLaunchKernelGGL((mish_dropout_bwd<T, TR>), ew_grid(n), dim3(256), 0, st, (const T*)x, (const TR*)dy, p, seed_dev, site,
+                       (T*)dx, (long)n);
+  });
+}
+
+int evt_glu_dropout_res_fwd(int32_t dtype, int32_t wide_dtype, const void* h, const void* res, float p,
+                            const uint32_t* seed_dev, uint32_t site, void* y, int64_t rows, int32_t C, void* stream) {
+  if (!h || !res || !y || rows <= 0 || C <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return mixed_dispatch(dtype, wide_dtype, [&](auto* t, auto* tr) {
+    EVT_TT(t, tr);
+    hipLaunchKernelGGL((glu_dropout_res_fwd<T, TR>), ew_grid(rows * C), dim3(256), 0, st, (const T*)h, (const TR*)res, p,
+                       seed_dev, site, (TR*)y, (long)rows, C);
+  });
+}
+
+int evt_glu_dropout_res_bwd(int32_t dtype, int32_t wide_dtype, const void* h, const void* dy, float p,
+                            const uint32_t* seed_dev, uint32_t site, void* dh, int64_t rows, int32_t C, void* stream) {
+  if (!h || !dy || !dh || rows <= 0 || C <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return mixed_dispatch(dtype, wide_dtype, [&](auto* t, auto* tr) {
+    EVT_TT(t, tr);
+    hipLaunchKernelGGL((glu_dropout_res_bwd<T, TR>), ew_grid(rows * C), dim3(256), 0, st, (const T*)h, (const TR*)dy, p,
+                       seed_dev, site, (T*)dh, (long)rows, C);
+  });
 }
 
 int evt_coupling_flip_fwd(int32_t dtype, const float* x, const void* stats, const int32_t* lens, int32_t rows_per_seq,

@@ -368,6 +368,109 @@ def wn_residual_last(rs, acc, lens):
     return WNResidualFn.apply(None, rs, acc, lens, True)
 
 
+class MishDropoutFn(torch.autograd.Function):
+    """y = dropout(x * tanh(softplus(x))) in one pass (modules.py:521-545 Mish + nn.Dropout of the style encoder); the
+    backward regenerates the mask from the device counter and applies mish'(x).  out_dtype: y's dtype (fp32 next to a
+    bf16 x where the reference's autocast leaves the activation in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, p, site, out_dtype):
+        x = x.contiguous()
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        L.check(L.lib().evt_mish_dropout_fwd(L.dt_of(x), L.dt_of(y), L.ptr(x), C.c_float(p), L.ptr(rng_counter(x.device)),
+                                             C.c_uint32(site), L.ptr(y), C.c_int64(x.numel()), L.stream_ptr()),
+                "evt_mish_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (p, site, out_dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        p, site, out_dtype = ctx.cfg
+        dy = dy.to(out_dtype).contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().evt_mish_dropout_bwd(L.dt_of(x), L.dt_of(dy), L.ptr(x), L.ptr(dy), C.c_float(p),
+                                             L.ptr(rng_counter(x.device)), C.c_uint32(site), L.ptr(dx), C.c_int64(x.numel()),
+                                             L.stream_ptr()), "evt_mish_dropout_bwd")
+        return dx, None, None, None
+
+
+def mish_dropout(x, p, site, out_dtype=None):
+    return MishDropoutFn.apply(x, float(p), int(site), out_dtype or x.dtype)
+
+
+class GluDropoutResFn(torch.autograd.Function):
+    """y = res + dropout(h[..., :C] * sigmoid(h[..., C:])) in one pass (Conv1dGLU, modules.py:548-566); h [..., 2C] in the
+    compute dtype, res / y in res's dtype (fp32 or the compute dtype)"""
+
+    @staticmethod
+    def forward(ctx, h, res, p, site):
+        h = h.contiguous()
+        if res.dtype not in (h.dtype, torch.float32):
+            res = res.to(h.dtype)
+        res = res.contiguous()
+        Cc = h.size(-1) // 2
+        y = torch.empty_like(res)
+        L.check(L.lib().evt_glu_dropout_res_fwd(L.dt_of(h), L.dt_of(res), L.ptr(h), L.ptr(res), C.c_float(p),
+                                                L.ptr(rng_counter(h.device)), C.c_uint32(site), L.ptr(y),
+                                                C.c_int64(h.numel() // (2 * Cc)), Cc, L.stream_ptr()),
+                "evt_glu_dropout_res_fwd")
+        ctx.save_for_backward(h)
+        ctx.cfg = (p, site, Cc, res.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, = ctx.saved_tensors
+        p, site, Cc, rdt = ctx.cfg
+        dy = dy.to(rdt).contiguous()
+        dh = torch.empty_like(h)
+        L.check(L.lib().evt_glu_dropout_res_bwd(L.dt_of(h), L.dt_of(dy), L.ptr(h), L.ptr(dy), C.c_float(p),
+                                                L.ptr(rng_counter(h.device)), C.c_uint32(site), L.ptr(dh),
+                                                C.c_int64(h.numel() // (2 * Cc)), Cc, L.stream_ptr()),
+                "evt_glu_dropout_res_bwd")
+        return dh, dy, None, None
+
+
+def glu_dropout_res(h, res, p, site):
+    return GluDropoutResFn.apply(h, res, float(p), int(site))
+
+
+class ReparamFn(torch.autograd.Function):
+    """posterior encoder tail (models.py:352-358): stats [B, T, 2C] (the projection's output, compute dtype), eps [B, T, C]
+    fp32, lens -> z, m, logs fp32 (masked) in one launch; one launch back"""
+
+    @staticmethod
+    def forward(ctx, stats, eps, lens):
+        stats = stats.contiguous()
+        eps = eps.float().contiguous()
+        B, T, C2 = stats.shape
+        Cc = C2 // 2
+        z = torch.empty((B, T, Cc), dtype=torch.float32, device=stats.device)
+        m, logs = torch.empty_like(z), torch.empty_like(z)
+        L.check(L.lib().evt_reparam_fwd(L.dt_of(stats), L.ptr(stats), L.ptr(eps), L.ptr(lens), T, C.c_int64(B * T), Cc,
+                                        L.ptr(z), L.ptr(m), L.ptr(logs), L.stream_ptr()), "evt_reparam_fwd")
+        ctx.save_for_backward(eps, logs, lens)
+        ctx.sdt, ctx.dims = stats.dtype, (B, T, Cc)
+        return z, m, logs
+
+    @staticmethod
+    def backward(ctx, dz, dm, dlogs):
+        eps, logs, lens = ctx.saved_tensors
+        B, T, Cc = ctx.dims
+        gs = [g.float().contiguous() if g is not None else None for g in (dz, dm, dlogs)]
+        dstats = torch.empty((B, T, 2 * Cc), dtype=ctx.sdt, device=eps.device)
+        dt = L.DT_BF16 if ctx.sdt == torch.bfloat16 else L.DT_F32
+        L.check(L.lib().evt_reparam_bwd(dt, L.ptr(gs[0]), L.ptr(gs[1]), L.ptr(gs[2]), L.ptr(eps), L.ptr(logs), L.ptr(lens), T,
+                                        C.c_int64(B * T), Cc, L.ptr(dstats), L.stream_ptr()), "evt_reparam_bwd")
+        return dstats, None, None
+
+
+def reparam(stats, eps, lens):
+    return ReparamFn.apply(stats, eps, lens)
+
+
 class CouplingFlipFn(torch.autograd.Function):
     """mean-only residual coupling + Flip after the layer's `post` projection (modules.py:404-458 with logs == 0, followed by
     the Flip of models.py:273-315):  y = flip([x0, (x1 + stats) * mask]) in fp32 and x0n = y[..., :h] in the compute dtype

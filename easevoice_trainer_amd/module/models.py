@@ -124,6 +124,14 @@ class PosteriorEncoder(nn.Module, _ComputeDtype):
             g = g.detach()
         h = (self.pre(x) * x_mask).to(self.cd).contiguous()
         h = self.enc(h, x_mask, g=g, lens=lens)
+        if h.is_cuda and lens is not None:
+            # mask, split, cast, exp, scale, add, mask: one launch (hip/enc.py::ReparamFn)
+            from ..hip.enc import reparam
+
+            stats = self.proj(h)
+            if eps is None:
+                eps = torch.randn((stats.size(0), stats.size(1), self.out_channels), dtype=torch.float32, device=h.device)
+            return reparam(stats, eps, lens)
         stats = self.proj(h) * x_mask
         m, logs = torch.split(stats.float(), self.out_channels, dim=-1)
         if eps is None:
@@ -305,10 +313,16 @@ class Conv1dGLU(nn.Module, _ComputeDtype):
         self.out_channels = out_channels
         self.conv1 = ConvNorm(in_channels, 2 * out_channels, kernel_size)
         self.dropout = nn.Dropout(dropout)
+        self._site = new_site()
 
     def forward(self, x):
         residual = x
         h = self.conv1(x.to(self.cd).contiguous())
+        if h.is_cuda:
+            # sigmoid, product, dropout and the residual add in one launch (hip/enc.py)
+            from ..hip.enc import glu_dropout_res
+
+            return glu_dropout_res(h, residual, self.dropout.p if self.training else 0.0, self._site)
         x1, x2 = torch.split(h, self.out_channels, dim=-1)
         return residual + self.dropout(x1 * torch.sigmoid(x2))
 
@@ -356,13 +370,26 @@ class MelStyleEncoder(nn.Module):
         self.slf_attn = StyleAttention(style_head, style_hidden, style_hidden // style_head,
                                        style_hidden // style_head, dropout)
         self.fc = LinearNorm(style_hidden, style_vector_dim)
+        self._sites = (new_site(), new_site())
+
+    def _spectral(self, x):
+        """self.spectral with Mish + Dropout as one launch per pair on the GPU (the Sequential keeps the reference's
+        state_dict keys spectral.0 / spectral.3)"""
+        sp = self.spectral
+        if not x.is_cuda:
+            return sp(x)
+        from ..hip.enc import mish_dropout
+
+        x = mish_dropout(sp[0](x), sp[2].p if self.training else 0.0, self._sites[0])        # feeds a projection: its dtype
+        # the second activation starts the fp32 residual stream of `temporal` (as under the reference's autocast)
+        return mish_dropout(sp[3](x), sp[5].p if self.training else 0.0, self._sites[1], torch.float32)
 
     def forward(self, x, x_mask, lens=None):
         """x [B, T, n_mel], x_mask [B, T, 1], lens [B] (= x_mask.sum(1)) -> [B, style_vector_dim]"""
         pad = x_mask.squeeze(-1) == 0                     # [B, T] True = padding
         if lens is None:
             lens = x_mask.sum(dim=(1, 2))
-        x = self.spectral(x)
+        x = self._spectral(x)
         x = self.temporal(x)
         x = x.masked_fill(pad.unsqueeze(-1), 0)
         x = self.slf_attn(x, lens.to(torch.int32))

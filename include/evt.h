@@ -504,6 +504,28 @@ int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, 
 int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void* acc, const int32_t* lens,
                         int32_t rows_per_seq, void* x_out, void* acc_out, int64_t rows, int32_t H, int32_t last,
                         void* stream);
+/* Element-wise chains of the style encoder (MelStyleEncoder, src/easevoice/module/modules.py:685-763), dropout masks from the
+ * device counter + `site` as in evt_relu_dropout_*:
+ *   Mish + Dropout (modules.py:521-545 LinearNorm / Mish / Dropout of `spectral`):  y = drop(x * tanh(softplus(x)))
+ *   Conv1dGLU tail (modules.py:548-566):  y = res + drop(h[:, :C] * sigmoid(h[:, C:])),  h [rows][2C], res / y [rows][C]
+ * backward: dx = dy * mask/(1-p) * mish'(x);  dh from dy (the residual's gradient is dy itself).
+ * dtype: x / h and their gradients; wide_dtype: y / res / dy -- the same, or EVT_DT_F32 next to bf16 operands (the
+ * reference's autocast keeps Mish outputs and the GLU residual stream in fp32 around its half-precision projections). */
+int evt_mish_dropout_fwd(int32_t dtype, int32_t wide_dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site,
+                         void* y, int64_t n, void* stream);
+int evt_mish_dropout_bwd(int32_t dtype, int32_t wide_dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev,
+                         uint32_t site, void* dx, int64_t n, void* stream);
+int evt_glu_dropout_res_fwd(int32_t dtype, int32_t wide_dtype, const void* h, const void* res, float p,
+                            const uint32_t* seed_dev, uint32_t site, void* y, int64_t rows, int32_t C, void* stream);
+int evt_glu_dropout_res_bwd(int32_t dtype, int32_t wide_dtype, const void* h, const void* dy, float p,
+                            const uint32_t* seed_dev, uint32_t site, void* dh, int64_t rows, int32_t C, void* stream);
+/* Tail of the posterior encoder (src/easevoice/module/models.py:352-358): with stats [rows][2C] the projection's output,
+ *   m = stats[:, :C] * mask, logs = stats[:, C:] * mask, z = (m + eps * exp(logs)) * mask     (fp32 [rows][C] each)
+ * and its backward: dstats from dz / dm / dlogs (each may be NULL), eps and the saved logs. */
+int evt_reparam_fwd(int32_t dtype, const void* stats, const float* eps, const int32_t* lens, int32_t rows_per_seq,
+                    int64_t rows, int32_t C, float* z, float* m, float* logs, void* stream);
+int evt_reparam_bwd(int32_t dtype, const float* dz, const float* dm, const float* dlogs, const float* eps, const float* logs,
+                    const int32_t* lens, int32_t rows_per_seq, int64_t rows, int32_t C, void* dstats, void* stream);
 /* Mean-only residual coupling + Flip of the s2 flow (src/easevoice/module/modules.py:404-458 forward with logs == 0 (mean_only),
  * models.py:273-315: flows = [coupling, Flip] x 4), everything after the layer's `post` projection in one launch:
  *   y[row][c] = v[row][2h-1-c],  v = [ x[:, :h] , (x[:, h:] + stats) * row_mask ];  x0n = y[:, :h] in `dtype` (the next

@@ -221,3 +221,100 @@ def test_coupling_flip_equals_torch_composition(gpu, dtype):
     (y2 * wy).sum().backward()
     x0g = torch.autograd.grad((ref(x, stats)[0] * wy).sum(), x)[0]
     assert torch.allclose(x.grad, x0g, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+def test_mish_and_glu_chains_equal_torch(gpu, dtype, tol):
+    """the style encoder's fused element-wise chains (hip/enc.py::MishDropoutFn / GluDropoutResFn) against the torch lines
+    they replace (models.py Mish + Dropout, Conv1dGLU.forward), dropout off: values and gradients"""
+    from easevoice_trainer_amd.hip.enc import glu_dropout_res, mish_dropout
+
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(4, 50, 128, generator=g) * 3).to(gpu).to(dtype).requires_grad_(True)
+    w = torch.randn(4, 50, 128, generator=g).to(gpu)
+    ref = (x.float() * torch.tanh(F.softplus(x.float())))
+    (ref * w).sum().backward()
+    gr = x.grad.clone()
+    x.grad = None
+    y = mish_dropout(x, 0.0, 3)
+    assert y.dtype == dtype
+    assert (y.float() - ref).abs().max() <= tol * ref.abs().max()
+    (y.float() * w).sum().backward()
+    assert (x.grad.float() - gr.float()).abs().max() <= tol * gr.float().abs().max() + 1e-6
+
+    y32 = mish_dropout(x, 0.0, 3, torch.float32)                                  # fp32 output next to a bf16 operand
+    assert y32.dtype == torch.float32 and (y32 - ref).abs().max() <= 2e-6 * ref.abs().max()
+    x.grad = None
+    (y32 * w).sum().backward()
+    assert (x.grad.float() - gr.float()).abs().max() <= tol * gr.float().abs().max() + 1e-6
+
+    h = torch.randn(4, 50, 256, generator=g).to(gpu).to(dtype).requires_grad_(True)
+    res = torch.randn(4, 50, 128, generator=g).to(gpu).requires_grad_(True)       # fp32 residual stream
+    x1, x2 = torch.split(h.float(), 128, dim=-1)
+    ref = res.float() + x1 * torch.sigmoid(x2)
+    (ref * w).sum().backward()
+    gh, gres = h.grad.clone(), res.grad.clone()
+    h.grad = res.grad = None
+    y = glu_dropout_res(h, res, 0.0, 4)
+    assert (y.float() - ref).abs().max() <= tol * ref.abs().max()
+    (y.float() * w).sum().backward()
+    assert (h.grad.float() - gh.float()).abs().max() <= tol * gh.float().abs().max() + 1e-6
+    assert (res.grad.float() - gres.float()).abs().max() <= tol * gres.float().abs().max() + 1e-6
+
+
+def test_mish_and_glu_dropout_masks(gpu):
+    """dropout on: the kept fraction is 1 - p, kept values are scaled by 1 / (1 - p), and the backward regenerates the same
+    mask (gradient zero exactly where the output was dropped)"""
+    from easevoice_trainer_amd.hip.enc import glu_dropout_res, mish_dropout
+
+    p = 0.25
+    x = (torch.rand(8, 100, 128, device=gpu) + 0.5).requires_grad_(True)          # mish(x) != 0 everywhere
+    y = mish_dropout(x, p, 11)
+    full = mish_dropout(x.detach(), 0.0, 11)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    assert torch.allclose(y[kept], full[kept] / (1 - p), rtol=1e-5)
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, kept)
+    h = (torch.rand(8, 100, 256, device=gpu) + 0.5).requires_grad_(True)
+    res = torch.zeros(8, 100, 128, device=gpu)
+    y = glu_dropout_res(h, res, p, 12)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    y.sum().backward()
+    assert torch.equal(h.grad[..., :128] != 0, kept) and torch.equal(h.grad[..., 128:] != 0, kept)
+    y2 = glu_dropout_res(h.detach(), res, p, 13)                                   # another site: another mask
+    assert not torch.equal(y2 != 0, kept)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)], ids=["f32", "bf16"])
+def test_reparam_equals_torch_lines(gpu, dtype, tol):
+    """posterior encoder tail (hip/enc.py::ReparamFn) against models.py PosteriorEncoder.forward's torch lines"""
+    from easevoice_trainer_amd.hip.enc import reparam
+
+    B, T, Cc = 3, 41, 192
+    g = torch.Generator().manual_seed(2)
+    lens = torch.tensor([41, 7, 30], dtype=torch.int32, device=gpu)
+    mask = (torch.arange(T, device=gpu)[None, :] < lens[:, None]).float().unsqueeze(-1)
+    stats = (torch.randn(B, T, 2 * Cc, generator=g) * 0.7).to(gpu).to(dtype).requires_grad_(True)
+    eps = torch.randn(B, T, Cc, generator=g).to(gpu)
+    ws = [torch.randn(B, T, Cc, generator=g).to(gpu) for _ in range(3)]
+
+    st = (stats * mask.to(dtype)).float()
+    m_r, l_r = torch.split(st, Cc, dim=-1)
+    z_r = (m_r + eps * torch.exp(l_r)) * mask
+    ((z_r * ws[0]).sum() + (m_r * ws[1]).sum() + (l_r * ws[2]).sum()).backward()
+    gr = stats.grad.clone()
+    stats.grad = None
+    z, m, logs = reparam(stats, eps, lens)
+    for a, b in ((z, z_r), (m, m_r), (logs, l_r)):
+        assert (a - b).abs().max() <= 1e-6 * b.abs().max() + 1e-6
+    ((z * ws[0]).sum() + (m * ws[1]).sum() + (logs * ws[2]).sum()).backward()
+    assert (stats.grad.float() - gr.float()).abs().max() <= tol * gr.float().abs().max() + 1e-6
+    stats.grad = None
+    z2, _, _ = reparam(stats, eps, lens)             # only z consumed: the other two gradients arrive as None
+    (z2 * ws[0]).sum().backward()
+    want = torch.autograd.grad((((torch.split((stats * mask.to(dtype)).float(), Cc, dim=-1)[0]
+                                  + eps * torch.exp(torch.split((stats * mask.to(dtype)).float(), Cc, dim=-1)[1])) * mask)
+                                * ws[0]).sum(), stats)[0]
+    assert (stats.grad.float() - want.float()).abs().max() <= tol * want.float().abs().max() + 1e-6
