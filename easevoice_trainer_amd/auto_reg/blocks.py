@@ -81,11 +81,12 @@ class FFNBlockFn(torch.autograd.Function):
         g_param, b_param = ctx.params
         dx_res, dff, dgamma, dbeta = _res_drop_ln_bwd(x, ff, gamma, b_param, g_param, dout.contiguous(), mean, rstd, p,
                                                       site_res)
-        dw2, db2 = gemm_bwd_weight(s2, h, dff)
+        need = ctx.needs_input_grad          # x, w1, b1, w2, b2, ...: a frozen weight gets no gradient launch
+        dw2, db2 = gemm_bwd_weight(s2, h, dff, want_bias=need[4]) if need[3] else (None, None)
         # d(linear1 output before relu) = (dff W2) * dropout multiplier * (pre-activation > 0): both read off h
         dz1 = gemm_bwd_data(s2, dff, gate=h, gate_pos=1.0 / (1.0 - p) if p > 0.0 else 1.0)
-        dw1, db1 = gemm_bwd_weight(s1, x, dz1)
-        dx = gemm_bwd_data(s1, dz1, add=dx_res) if ctx.needs_input_grad[0] else None
+        dw1, db1 = gemm_bwd_weight(s1, x, dz1, want_bias=need[2]) if need[1] else (None, None)
+        dx = gemm_bwd_data(s1, dz1, add=dx_res) if need[0] else None
         return dx, dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 
 
@@ -121,7 +122,8 @@ class AttnBlockFn(torch.autograd.Function):
         si, so, ap, p, site = ctx.cfg
         g_param, b_param = ctx.params
         dx_res, dsa, dgamma, dbeta = _res_drop_ln_bwd(x, sa, gamma, b_param, g_param, dout.contiguous(), mean, rstd, p, site)
-        dwo, dbo = gemm_bwd_weight(so, o, dsa)
+        need = ctx.needs_input_grad          # x, w_in, b_in, w_out, b_out, ...
+        dwo, dbo = gemm_bwd_weight(so, o, dsa, want_bias=need[4]) if need[3] else (None, None)
         d_o = gemm_bwd_data(so, dsa)
         B, Lq, E = x.shape
         dqkv = torch.empty_like(qkv)
@@ -131,8 +133,8 @@ class AttnBlockFn(torch.autograd.Function):
             C.byref(ap), C.c_void_p(qb), C.c_void_p(qb + E * esz), C.c_void_p(qb + 2 * E * esz), L.ptr(o), L.ptr(d_o),
             L.ptr(lse), L.ptr(x_lens), L.ptr(y_lens), C.c_void_p(gb), C.c_void_p(gb + E * esz),
             C.c_void_p(gb + 2 * E * esz), L.ptr(delta), L.stream_ptr()), "evt_attn_prefixlm_bwd")
-        dwi, dbi = gemm_bwd_weight(si, x, dqkv)
-        dx = gemm_bwd_data(si, dqkv, add=dx_res) if ctx.needs_input_grad[0] else None
+        dwi, dbi = gemm_bwd_weight(si, x, dqkv, want_bias=need[2]) if need[1] else (None, None)
+        dx = gemm_bwd_data(si, dqkv, add=dx_res) if need[0] else None
         return dx, dwi, dbi, dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

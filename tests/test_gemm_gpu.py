@@ -209,3 +209,26 @@ def test_s1_blocks_match_composition(gpu, dtype, B):
     assert rel(dx, xr.grad) < (6e-2 if bf else tol)            # through 8 bf16 GEMMs, the attention and two LayerNorms
     for k, g_ in grads.items():
         assert rel(g_, P[k].grad) < ((1e-1 if "linear" in k else 5e-2) if bf else tol), k
+
+
+def test_s1_blocks_skip_frozen_weights(gpu):
+    """a weight that does not require a gradient gets no gradient launch (ctx.needs_input_grad), everything else is
+    unchanged bit for bit"""
+    from easevoice_trainer_amd.auto_reg.blocks import attn_block, ffn_block
+
+    layer, x, (x_lens, y_lens, x_len, Lq, E), wgt, out, dx, grads = _run_layer_blocks(gpu, torch.bfloat16, 2)
+    for p_ in layer.parameters():
+        p_.grad = None
+    layer.linear1.weight.requires_grad_(False)
+    layer.self_attn.out_proj.bias.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    h = attn_block(xg, layer.self_attn, layer.norm1, x_lens, y_lens, x_len, 1, 0.0, 1)
+    out2 = ffn_block(h, layer.linear1, layer.linear2, layer.norm2, 0.0, 2, 3)
+    (out2.float() * wgt).sum().backward()
+    assert layer.linear1.weight.grad is None and layer.self_attn.out_proj.bias.grad is None
+    assert torch.equal(out2, out) and torch.equal(xg.grad, dx)
+    for k, p_ in layer.named_parameters():
+        if k in ("linear1.weight", "self_attn.out_proj.bias"):
+            continue
+        # fp32 atomics of the split reductions: the order of the adds differs between runs
+        assert rel(p_.grad, grads[k]) < 1e-4, k
