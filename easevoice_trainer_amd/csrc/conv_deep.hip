@@ -512,10 +512,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
   const int j16 = lane & 15, g8 = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
 
+  // Block -> (dy tile, x chunk, tap group).  A block reads the dy columns of its A tile and the x columns of its chunk for
+  // its split's positions; consecutive workgroup ids go round-robin over the 8 XCDs, so with the plain decode (chunk
+  // fastest) every L2 pulls ALL dy tiles and 1/8 of the x chunks: (8 A + B) / (A + B) = 4.5 x the operand bytes at
+  // 1024 -> 1024 (PMC round 3: FETCH 105 MB per launch against 27.5 MB of operands).  xcd_order: the tile grid is cut into
+  // 2 (dy-tile halves) x 4 (chunk quarters) rectangles, one per XCD -- an L2 sees half of dy and a quarter of x:
+  // 8 x (A/2 + B/4) = 3 x.  (A split of the positions over the XCDs would give 1 x, but the split count is bounded by
+  // the slabs of the deterministic reduction: 3 for a 21 MB image.)
   int bx = blockIdx.x;
-  const int ch = bx % p.nchunk; bx /= p.nchunk;
-  const int tgi = bx % p.ntapgrp;
-  const int atile = bx / p.ntapgrp;
+  int ch, tgi, atile;
+  if (p.xcd_order) {
+    const int xcd = bx & 7, j = bx >> 3;
+    const int na = (p.CA >> 7) >> 1, nc = p.nchunk >> 2;           // tiles per rectangle side
+    const int cl = j % nc, r = j / nc;
+    tgi = r % p.ntapgrp;
+    const int al = r / p.ntapgrp;
+    atile = (xcd & 1) * na + al;
+    ch = (xcd >> 1) * nc + cl;
+  } else {
+    ch = bx % p.nchunk; bx /= p.nchunk;
+    tgi = bx % p.ntapgrp;
+    atile = bx / p.ntapgrp;
+  }
   const int t0 = tgi * WKT;
   const int ntap = min(WKT, p.KHp - t0);
   const int a0 = atile * 128;
@@ -1370,6 +1388,9 @@ int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
   p.nchunk = p.CB / 32;
   p.ntapgrp = (p.KHp + WKT - 1) / WKT;
   const long tiles = (long)(p.CA / 128) * p.nchunk * p.ntapgrp;
+  // XCD-aware tile order (EVT_WGRAD_DEEP_XCD=0: plain decode): needs an even number of dy tiles and chunks in fours
+  static const bool xcd_on = !(getenv("EVT_WGRAD_DEEP_XCD") && atoi(getenv("EVT_WGRAD_DEEP_XCD")) == 0);
+  p.xcd_order = (xcd_on && (p.CA / 128) % 2 == 0 && p.nchunk % 4 == 0) ? 1 : 0;
   const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
   // ~2 blocks per CU in flight, >= 8 K stages per block so the pipeline amortises its fill and the atomics; slab mode:
   // one resident wave of blocks is enough once the tile leaves as plain stores
