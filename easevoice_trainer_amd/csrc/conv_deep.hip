@@ -1170,7 +1170,16 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
   const int j16 = lane & 15, g8 = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
 
-  int bx = blockIdx.x;
+  // xcd_order (split count a multiple of 8): a split -- one range of positions -- lives on ONE XCD, its tiles dispatched back
+  // to back (consecutive workgroup ids go round-robin over the 8 XCDs): the rows of that range enter one L2 instead of
+  // all eight (PMC round 3: 34.8 MB per launch against 5 MB of operands for the 192 -> 384 k5 gradient)
+  int bx = blockIdx.x, split = blockIdx.y;
+  if (p.xcd_order) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int idx = lin >> 3;
+    bx = idx % (int)gridDim.x;
+    split = (lin & 7) + 8 * (idx / (int)gridDim.x);
+  }
   const int ch = bx % p.nchunk; bx /= p.nchunk;
   const int tgi = bx % p.ntapgrp;
   const int atile = bx / p.ntapgrp;
@@ -1182,7 +1191,7 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
   const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
   const int total_units = p.nseq * p.Q;
   const int nstages = (total_units + WPOS - 1) / WPOS;
-  const int st_begin = blockIdx.y * stages_per_split;
+  const int st_begin = split * stages_per_split;
   const int nst = min(nstages, st_begin + stages_per_split) - st_begin;
   if (nst <= 0) return;
 
@@ -1270,8 +1279,8 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
     if (do_bias) wg_bias_mma<MA>(bacc, a, wc);
     asm volatile("" ::: "memory");
   }
-  if (do_bias) wg_finish_bias_mma<MA>(p, bacc, a0, wr, wc, g8, j16, blockIdx.y);
-  wg_finish<MA, KT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, blockIdx.y);
+  if (do_bias) wg_finish_bias_mma<MA>(p, bacc, a0, wr, wc, g8, j16, split);
+  wg_finish<MA, KT>(p, smem, acc, ntap, a0, ch, t0, wr, wc, g8, j16, split);
 }
 
 }  // namespace
@@ -1523,6 +1532,15 @@ int launch_wgrad_ring(const WgP& p_in, hipStream_t st) {
   static const long target = getenv("EVT_RING_BLOCKS") ? atol(getenv("EVT_RING_BLOCKS")) : 256;   // tuning knob (measured: 256 best)
   int nsplit, per;                                // ~1 block per CU: more splits only add partial tiles; >= 3 K stages per block
   wgrad_pick_split(p, tiles, nstages, target, 3, &nsplit, &per);
+  // XCD-aware order (EVT_WGRAD_RING_XCD=0: plain grid): the split count rounded DOWN to a multiple of 8 (it is bounded by
+  // the slabs the caller holds), every split non-empty
+  static const bool xcd_on = !(getenv("EVT_WGRAD_RING_XCD") && atoi(getenv("EVT_WGRAD_RING_XCD")) == 0);
+  p.xcd_order = 0;
+  if (xcd_on && nsplit >= 8) {
+    const int s8 = nsplit / 8 * 8;
+    const int per8 = (nstages + s8 - 1) / s8;
+    if ((long)per8 * (s8 - 1) < nstages) { nsplit = s8; per = per8; p.xcd_order = 1; }
+  }
   p.nsplit = nsplit;
   p.now_used = p.prev_used > nsplit ? p.prev_used : nsplit;
   if (p.parts > 0 && p.used_host) *p.used_host = p.now_used;
