@@ -126,6 +126,80 @@ class ScaledAdam:
         self.param_groups[0]["lr"] = sd.get("lr", self.lr)
 
 
+    # ---- the reference optimiser's own state layout (what a Lightning checkpoint of src/train/gpt.py holds under
+    #      "optimizer_states"[0]): torch.optim.Optimizer.state_dict() of its BatchedOptimizer -- parameters of equal
+    #      (dtype, shape) are stacked, batches sorted by that key, the state of a batch stored under its FIRST parameter's
+    #      index with a leading stacking dimension (optim.py:60-127, :253-298); the first batch also carries the clipping
+    #      history (optim.py:339-362).  `order`: parameter names in the reference's param_groups order (= the order of the
+    #      checkpoint's state_dict keys). ----
+    def _ref_batches(self, order):
+        named = dict(self.arena.model.named_parameters())
+        mine = {n: t for t, n in enumerate(self.names)}
+        groups = {}
+        for idx, n in enumerate(order):
+            if n not in mine:
+                raise KeyError(f"optimizer state: parameter {n!r} of the checkpoint is not optimised here")
+            p = named[n]
+            groups.setdefault(("torch.float32", *p.shape), []).append((idx, n, mine[n], p))
+        if len(groups) == 0 or sum(len(v) for v in groups.values()) != len(self.names):
+            raise ValueError("optimizer state: the checkpoint's parameter list differs from this model's")
+        return [groups[k] for k in sorted(groups)]
+
+    @torch.no_grad()
+    def load_reference_state(self, sd, order):
+        """continue a run the reference started: `sd` = its optimizer.state_dict()"""
+        state = sd["state"]
+        a = self.arena
+        for bi, batch in enumerate(self._ref_batches(order)):
+            st = state[batch[0][0]]
+            self.step_count = int(st["step"])
+            for i, (_idx, n, t, p) in enumerate(batch):
+                b, e = a.range_of(n, p.numel())
+                self.delta[b:e].copy_(st["delta"][i].reshape(-1))
+                self.exp_avg_sq[b:e].copy_(st["exp_avg_sq"][i].reshape(-1))
+                if p.numel() > 1:
+                    self.param_rms[t] = st["param_rms"][i].reshape(())
+                    self.scale_exp_avg_sq[t] = st["scale_exp_avg_sq"][i].reshape(())
+                    self.scale_grads[:, t] = st["scale_grads"][:, i].reshape(self.P)
+            if bi == 0:
+                if "model_norms" in st:
+                    self.model_norms.copy_(st["model_norms"])
+                thr = st.get("model_norm_threshold")
+                self.model_norm_threshold = None if thr is None else torch.as_tensor(float(thr), device=a.device)
+                self.num_clipped = int(st.get("num_clipped", 0))
+        self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.lr)
+
+    @torch.no_grad()
+    def reference_state_dict(self, order):
+        """this optimiser's state in the reference optimiser's layout (its load_state_dict takes it)"""
+        a = self.arena
+        state = {}
+        for bi, batch in enumerate(self._ref_batches(order)):
+            shape = batch[0][3].shape
+            cut = lambda buf: torch.stack([buf[slice(*a.range_of(n, p.numel()))].reshape(shape).cpu().clone()
+                                           for _i, n, _t, p in batch])
+            st = dict(step=self.step_count, delta=cut(self.delta), exp_avg_sq=cut(self.exp_avg_sq))
+            ts = [t for _i, _n, t, _p in batch]
+            stacked_numel = len(batch) * batch[0][3].numel()          # optim.py:279-281: the STACKED tensor decides
+            if stacked_numel > 1:
+                one = (len(batch),) + (1,) * len(shape)
+                st["param_rms"] = self.param_rms[ts].reshape(one).cpu().clone()
+                st["scale_exp_avg_sq"] = self.scale_exp_avg_sq[ts].reshape(one).cpu().clone()
+                st["scale_grads"] = self.scale_grads[:, ts].reshape((self.P,) + one).cpu().clone()
+            if bi == 0 and self.clipping_scale is not None and self.step_count > 0:
+                st["model_norms"] = self.model_norms.cpu().clone()
+                if self.model_norm_threshold is not None:
+                    st["model_norm_threshold"] = float(self.model_norm_threshold)
+                st["num_clipped"] = int(self.num_clipped)
+            state[batch[0][0]] = st
+        beta1, beta2 = self.betas
+        group = dict(lr=self.param_groups[0]["lr"], clipping_scale=self.clipping_scale, betas=(beta1, beta2),
+                     scalar_lr_scale=self.scalar_lr_scale, eps=self.eps, param_min_rms=self.param_min_rms,
+                     param_max_rms=self.param_max_rms, scalar_max=self.scalar_max, size_update_period=self.P,
+                     clipping_update_period=self.clip_period, params=list(range(len(order))))
+        return dict(state=state, param_groups=[group])
+
+
 class WarmupCosineLRSchedule:
     """src/easevoice/soundstorm/auto_reg/modules/lr_schedulers.py:11-65.  The reference computes the warm-up / cosine
     value and then OVERWRITES it: every step() pins the optimiser's lr to 0.002 (line 61).  Reproduced as is."""
@@ -133,6 +207,9 @@ class WarmupCosineLRSchedule:
     def __init__(self, optimizer, init_lr, peak_lr, end_lr, warmup_steps=10000, total_steps=400000, current_step=0):
         self.init_lr, self.peak_lr, self.end_lr, self.optimizer = init_lr, peak_lr, end_lr, optimizer
         self.warmup_steps, self.total_steps, self._current_step = warmup_steps, total_steps, current_step
+        # the two slopes are fixed at construction (from the end_lr given here: step() overwrites end_lr afterwards)
+        self._warmup_rate = (peak_lr - init_lr) / warmup_steps
+        self._decay_rate = (end_lr - peak_lr) / (total_steps - warmup_steps)
         self.lr = init_lr
         self._last_lr = [self.lr]
 
@@ -146,3 +223,14 @@ class WarmupCosineLRSchedule:
             g["lr"] = self.end_lr
         self._current_step += 1
         return self.lr
+
+    def state_dict(self):
+        """torch's _LRScheduler.state_dict(): every attribute but the optimiser (what a Lightning checkpoint stores under
+        "lr_schedulers")"""
+        return {k: v for k, v in vars(self).items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        for k in ("init_lr", "peak_lr", "end_lr", "warmup_steps", "total_steps", "_current_step", "lr", "_last_lr",
+                  "_warmup_rate", "_decay_rate"):
+            if k in sd:
+                setattr(self, k, sd[k])

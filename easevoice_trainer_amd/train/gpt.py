@@ -94,8 +94,17 @@ class GPTTrain:
         if newest:
             ck = torch.load(os.path.join(self.train_ckpts_output, newest), map_location="cpu", weights_only=False)
             eng.model.load_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
-            eng.optimizer.load_state_dict({k: (v.to(device) if torch.is_tensor(v) else v)
-                                           for k, v in ck["optimizer_states"][0].items()})
+            opt_sd = ck["optimizer_states"][0]
+            if "state" in opt_sd and "param_groups" in opt_sd:
+                # a checkpoint the reference's Lightning trainer wrote (src/train/gpt.py:172-177): its optimiser's own
+                # state_dict, parameters in the order of the module's state_dict
+                ours = set(eng.optimizer.names)
+                order = [k[len("model."):] for k in ck["state_dict"] if k.startswith("model.") and k[len("model."):] in ours]
+                eng.optimizer.load_reference_state(opt_sd, order)
+            else:
+                eng.optimizer.load_state_dict({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in opt_sd.items()})
+            if ck.get("lr_schedulers"):
+                eng.scheduler.load_state_dict(ck["lr_schedulers"][0])
             start_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
         if reducer is not None:
             reducer.broadcast_params(eng.arena.param)
@@ -128,10 +137,17 @@ class GPTTrain:
                 # the previous resume point in place
                 before = os.listdir(self.train_ckpts_output) if c["if_save_latest"] else []
                 sd = OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in eng.model.state_dict().items())
-                opt_sd = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in eng.optimizer.state_dict().items()}
+                # optimiser and scheduler state in the layout the reference's Lightning checkpoint holds them in
+                # (torch.optim.Optimizer.state_dict() of its batched ScaledAdam, parameters in named_parameters() order;
+                # the scheduler's attribute dict), so that either trainer can pick the other's file up.  Lightning's own
+                # "loops" / "callbacks" entries are not written (its legacy path restores epoch / global_step without them).
+                order = [n for n, _ in eng.model.named_parameters() if n in set(eng.optimizer.names)]
+                opt_sd = eng.optimizer.reference_state_dict(order)
+                sch_sd = eng.scheduler.state_dict()
                 new_name = f"epoch={epoch}-step={self.global_step}.ckpt"
                 ckpt.save_with_torch({"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
-                                      "optimizer_states": [opt_sd], "hyper_parameters": {"config": cfg}},
+                                      "optimizer_states": [opt_sd], "lr_schedulers": [sch_sd],
+                                      "hyper_parameters": {"config": cfg}},
                                      os.path.join(self.train_ckpts_output, new_name))
                 for name in before:
                     if name != new_name:

@@ -210,6 +210,15 @@ def test_lr_schedule_trajectory():
     for _ in range(150):
         assert ra.step() == rb.step() and ra.get_last_lr() == rb.get_last_lr()
         assert [g["lr"] for g in a.param_groups] == [g["lr"] for g in b.param_groups]
+    # the state a Lightning checkpoint keeps under "lr_schedulers": same keys and values, loadable either way
+    sa, sb = ra.state_dict(), rb.state_dict()
+    assert set(sa) == set(sb) and all(sa[k] == pytest.approx(sb[k]) for k in sa), (sa, sb)
+    c = Opt()
+    rc = Ours(c, init_lr=1.0, peak_lr=2.0, end_lr=3.0, warmup_steps=1, total_steps=2)
+    rc.load_state_dict(sa)
+    assert rc._current_step == 150 and rc.warmup_steps == 20 and rc.get_last_lr() == ra.get_last_lr()
+    ra.load_state_dict(sb)
+    assert ra._current_step == 150
 
 
 def test_kmeans_codebook_init_matches_reference():
@@ -461,3 +470,98 @@ def test_scaled_adam_random_trajectories():
                 opt.param_groups[0]["lr"] = lr
                 for k in shapes:
                     assert torch.allclose(params[k].detach(), ref_p[k].detach(), rtol=1e-4, atol=3e-6), (case, step, k)
+
+
+def test_scaled_adam_state_crosses_to_and_from_the_reference_optimizer():
+    """src/train/gpt.py:172-177 resumes from a Lightning checkpoint whose "optimizer_states"[0] is the reference
+    optimiser's own state_dict (stacked same-shape batches, state under the first parameter of a batch, clipping history in
+    the first batch).  ScaledAdam.load_reference_state continues such a run -- same parameters as the reference optimiser
+    continuing itself -- and reference_state_dict hands a run back: the reference optimiser loads it and continues like
+    ours."""
+    from cpu_emu import cpu_emulation_s1
+    from easevoice_trainer_amd.auto_reg.optim import ScaledAdam
+    from easevoice_trainer_amd.runtime import ParamArena
+    from src.easevoice.soundstorm.auto_reg.modules.optim import ScaledAdam as RefScaledAdam
+
+    g = torch.Generator().manual_seed(3)
+    shapes = {"emb.w": (7, 6), "a.alpha": (1,), "l0.w": (4, 6), "l0.b": (4,), "b.alpha": (1,), "l1.w": (4, 6), "l1.b": (4,),
+              "out.w": (9, 4)}
+    init = {k: torch.randn(v, generator=g) * (0.5 if len(v) > 1 else 0.2) for k, v in shapes.items()}
+    order = list(shapes)                                  # the reference's parameter order
+    kw = dict(lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0, clipping_update_period=5)
+
+    def ref_opt(values):
+        ps = {k: torch.nn.Parameter(values[k].clone()) for k in order}
+        return ps, RefScaledAdam(list(ps.values()), parameters_names=[order], show_dominant_parameters=False, **kw)
+
+    class Holder(torch.nn.Module):                        # registers its parameters in ANOTHER order than the reference
+        def __init__(self, values):
+            super().__init__()
+            for k in reversed(order):
+                self.register_parameter(k.replace(".", "_"), torch.nn.Parameter(values[k].clone()))
+
+    def grads(step):
+        gg = torch.Generator().manual_seed(100 + step)
+        return {k: torch.randn(shapes[k], generator=gg) * (0.8 if step % 6 == 5 else 0.1) for k in order}
+
+    def ours(values):
+        h = Holder(values)
+        arena = ParamArena(h, "cpu")
+        return h, arena, ScaledAdam(arena, **kw)
+
+    name_of = {k: k.replace(".", "_") for k in order}
+    with cpu_emulation_s1():
+        # ---- reference runs 13 steps, we continue from its state_dict ----
+        rp, ropt = ref_opt(init)
+        for step in range(13):
+            for k, gr in grads(step).items():
+                rp[k].grad = gr
+            ropt.step()
+        sd = ropt.state_dict()
+        h, arena, opt = ours({k: rp[k].detach() for k in order})
+        opt.load_reference_state(sd, [name_of[k] for k in order])
+        assert opt.step_count == 13
+        params = dict(h.named_parameters())
+        for step in range(13, 25):
+            gs = grads(step)
+            arena.zero_grad()
+            for k in order:
+                rp[k].grad = gs[k]
+                params[name_of[k]].grad.copy_(gs[k])
+            ropt.step()
+            opt.step()
+            for k in order:
+                assert torch.allclose(params[name_of[k]].detach(), rp[k].detach(), rtol=1e-4, atol=3e-6), (step, k)
+        # ---- and back: our state in the reference's layout, loaded by a fresh reference optimiser ----
+        back = opt.reference_state_dict([name_of[k] for k in order])
+        rp2, ropt2 = ref_opt({k: params[name_of[k]].detach() for k in order})
+        ropt2.load_state_dict(back)
+        for step in range(25, 36):
+            gs = grads(step)
+            arena.zero_grad()
+            for k in order:
+                rp2[k].grad = gs[k]
+                params[name_of[k]].grad.copy_(gs[k])
+            ropt2.step()
+            opt.step()
+            for k in order:
+                assert torch.allclose(params[name_of[k]].detach(), rp2[k].detach(), rtol=1e-4, atol=3e-6), (step, k)
+
+
+def test_s1_parameter_order_equals_reference():
+    """the s1 resume file stores the optimiser state by parameter INDEX in named_parameters() order (the reference's
+    configure_optimizers, t2s_lightning_module.py:94-108): names, order and shapes of our Text2SemanticDecoder equal the
+    reference's, so an index means the same tensor on both sides"""
+    import yaml
+    from easevoice_trainer_amd.auto_reg.t2s_model import Text2SemanticDecoder as Ours
+    from src.easevoice.soundstorm.auto_reg.models.t2s_model import Text2SemanticDecoder as Ref
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(repo, "configs", "gpt.yaml")))
+    cfg["model"].update(n_layer=2)                       # two layers show the pattern
+    ref = Ref(config=cfg, top_k=3)
+    ours = Ours(cfg)
+    a = [(n, tuple(p.shape)) for n, p in ref.named_parameters()]
+    b = [(n, tuple(p.shape)) for n, p in ours.named_parameters()]
+    assert a == b
+    assert [k for k in ref.state_dict()] == [k for k in ours.state_dict()]
