@@ -59,6 +59,14 @@ def _res_drop_ln_bwd(x, y, gamma, beta_param, gamma_param, dout, mean, rstd, p, 
     return dx, (dy if dy is not None else dx), (None if sunk else dgamma), (None if sunk else dbeta)
 
 
+def _wgrad(slot, x, dy, need_w, need_b):
+    """(dw, db) of one dense layer, nothing launched when neither is wanted"""
+    if not (need_w or need_b):
+        return None, None
+    dw, db = gemm_bwd_weight(slot, x, dy, want_bias=bool(need_b))
+    return (dw if need_w else None), db
+
+
 class FFNBlockFn(torch.autograd.Function):
     """out = LayerNorm(x + dropout(linear2(dropout(relu(linear1(x))))))"""
 
@@ -81,11 +89,11 @@ class FFNBlockFn(torch.autograd.Function):
         g_param, b_param = ctx.params
         dx_res, dff, dgamma, dbeta = _res_drop_ln_bwd(x, ff, gamma, b_param, g_param, dout.contiguous(), mean, rstd, p,
                                                       site_res)
-        need = ctx.needs_input_grad          # x, w1, b1, w2, b2, ...: a frozen weight gets no gradient launch
-        dw2, db2 = gemm_bwd_weight(s2, h, dff, want_bias=need[4]) if need[3] else (None, None)
+        need = ctx.needs_input_grad          # x, w1, b1, w2, b2, ...: a frozen layer gets no gradient launch (the bias
+        dw2, db2 = _wgrad(s2, h, dff, need[3], need[4])          # gradient comes out of the weight-gradient launch)
         # d(linear1 output before relu) = (dff W2) * dropout multiplier * (pre-activation > 0): both read off h
         dz1 = gemm_bwd_data(s2, dff, gate=h, gate_pos=1.0 / (1.0 - p) if p > 0.0 else 1.0)
-        dw1, db1 = gemm_bwd_weight(s1, x, dz1, want_bias=need[2]) if need[1] else (None, None)
+        dw1, db1 = _wgrad(s1, x, dz1, need[1], need[2])
         dx = gemm_bwd_data(s1, dz1, add=dx_res) if need[0] else None
         return dx, dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None
 
@@ -123,7 +131,7 @@ class AttnBlockFn(torch.autograd.Function):
         g_param, b_param = ctx.params
         dx_res, dsa, dgamma, dbeta = _res_drop_ln_bwd(x, sa, gamma, b_param, g_param, dout.contiguous(), mean, rstd, p, site)
         need = ctx.needs_input_grad          # x, w_in, b_in, w_out, b_out, ...
-        dwo, dbo = gemm_bwd_weight(so, o, dsa, want_bias=need[4]) if need[3] else (None, None)
+        dwo, dbo = _wgrad(so, o, dsa, need[3], need[4])
         d_o = gemm_bwd_data(so, dsa)
         B, Lq, E = x.shape
         dqkv = torch.empty_like(qkv)
@@ -133,7 +141,7 @@ class AttnBlockFn(torch.autograd.Function):
             C.byref(ap), C.c_void_p(qb), C.c_void_p(qb + E * esz), C.c_void_p(qb + 2 * E * esz), L.ptr(o), L.ptr(d_o),
             L.ptr(lse), L.ptr(x_lens), L.ptr(y_lens), C.c_void_p(gb), C.c_void_p(gb + E * esz),
             C.c_void_p(gb + 2 * E * esz), L.ptr(delta), L.stream_ptr()), "evt_attn_prefixlm_bwd")
-        dwi, dbi = gemm_bwd_weight(si, x, dqkv, want_bias=need[2]) if need[1] else (None, None)
+        dwi, dbi = _wgrad(si, x, dqkv, need[1], need[2])
         dx = gemm_bwd_data(si, dqkv, add=dx_res) if need[0] else None
         return dx, dwi, dbi, dwo, dbo, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 

@@ -16,6 +16,7 @@
 // counter the engine bumps once per step (evt_counter_inc), so a replayed HIP graph draws fresh masks every step.
 #include "evt_common.h"
 #include <type_traits>
+#include <cstdlib>
 #include "../../include/evt.h"
 
 namespace {
@@ -114,14 +115,17 @@ __global__ __launch_bounds__(256) void res_drop_ln_fwd(const T* x, const T* y, c
 }
 
 // dx = d(x + drop(y)) (residual branch), dy = dx * dropout multiplier (sub-layer branch; null when p == 0: same tensor)
-template <typename T, int NP>
-__global__ __launch_bounds__(256) void res_drop_ln_bwd(const T* x, const T* y, const float* gamma, const T* dout,
+// WAVES: waves per block.  The pass is a stream (3 reads + 1-2 writes of [rows, C]); with 256 blocks of 4 waves a CU held
+// one wave per SIMD and 12 KB of loads in flight: 2.6 TB/s on the s1 shapes ([32768, 512]: 52 us).  Long inputs take 8 waves
+// per block and up to 512 blocks (4 waves per SIMD); the per-channel atomics double to 0.5 M, still one per block and channel.
+template <typename T, int NP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void res_drop_ln_bwd(const T* x, const T* y, const float* gamma, const T* dout,
                                                        const float* mean, const float* rstd, const int* lens,
                                                        int rows_per_seq, float p, const unsigned* seed_dev,
                                                        unsigned site, T* dx, T* dy, float* dgamma, float* dbeta,
                                                        long rows, int C, int rows_per_block) {
   constexpr int V = Vec16<T>::V;
-  __shared__ float sg[4][64 * V * NP], sb[4][64 * V * NP];
+  __shared__ float sg[WAVES][64 * V * NP], sb[WAVES][64 * V * NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const DropCfg dc = drop_cfg(p, seed_dev, site);
   float ag[NP][V], ab[NP][V], gm[NP][V];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void res_drop_ln_bwd(const T* x, const T* y, c
     }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
-  for (long row = r0 + wave; row < r1; row += 4) {
+  for (long row = r0 + wave; row < r1; row += WAVES) {
     bool live = true;
     if (lens) { const long b = row / rows_per_seq; live = (int)(row - b * rows_per_seq) < lens[b]; }
     if (!live) {
@@ -207,9 +211,12 @@ __global__ __launch_bounds__(256) void res_drop_ln_bwd(const T* x, const T* y, c
       sb[wave][(pss * 64 + lane) * V + e] = ab[pss][e];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  for (int c = threadIdx.x; c < C; c += 64 * WAVES) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { tg += sg[w][c]; tb += sb[w][c]; }
+    atomicAdd(dgamma + c, tg);
+    atomicAdd(dbeta + c, tb);
   }
 }
 
@@ -530,15 +537,21 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
   if (p > 0.f && !dy) return EVT_EINVAL;
   if (C > 1024 || C % 8) return EVT_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
-  long rpb = (rows + 255) / 256;     // <= 256 blocks: each ends with one atomic per channel
+  static const int wide_off = getenv("EVT_LN_BWD_WAVES4") != nullptr;      // A/B switch for measurements
+  const bool wide = rows >= 8192 && !wide_off;
+  const int maxb = wide ? 512 : 256;            // each block ends with one atomic per channel
+  long rpb = (rows + maxb - 1) / maxb;
   if (rpb < 16) rpb = 16;
   const int blocks = (int)((rows + rpb - 1) / rpb);
-#define RDL_BWD(T, E) hipLaunchKernelGGL((res_drop_ln_bwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, \
-                                         gamma, (const T*)dout, mean, rstd, lens, rows_per_seq, p, seed_dev, site, (T*)dx,   \
-                                         (T*)dy, dgamma, dbeta, (long)rows, C, (int)rpb)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) RDL_BWD(bf16_t, 1); else RDL_BWD(bf16_t, 2); }
-  else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_BWD(float, 2); else RDL_BWD(float, 4); }
-  else return EVT_EINVAL;
+#define RDL_BWD(T, E, W) hipLaunchKernelGGL((res_drop_ln_bwd<T, E, W>), dim3(blocks), dim3(64 * W), 0, st, (const T*)x,      \
+                                            (const T*)y, gamma, (const T*)dout, mean, rstd, lens, rows_per_seq, p, seed_dev, \
+                                            site, (T*)dx, (T*)dy, dgamma, dbeta, (long)rows, C, (int)rpb)
+  if (dtype == EVT_DT_BF16) {
+    if (C <= 512) { if (wide) RDL_BWD(bf16_t, 1, 8); else RDL_BWD(bf16_t, 1, 4); }
+    else { if (wide) RDL_BWD(bf16_t, 2, 8); else RDL_BWD(bf16_t, 2, 4); }
+  } else if (dtype == EVT_DT_F32) {
+    if (C <= 512) RDL_BWD(float, 2, 4); else RDL_BWD(float, 4, 4);
+  } else return EVT_EINVAL;
 #undef RDL_BWD
   return evt_check_launch();
 }
