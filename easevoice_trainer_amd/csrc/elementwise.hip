@@ -224,6 +224,33 @@ __global__ void gated_bwd_kernel(const T* xin, const T* g, const T* dacts, T* dx
   }
 }
 
+// the same backward when the conditioning gradient is wanted: dg[s][c] = sum over the sequence's positions.  A block takes
+// `tch` positions of ONE sequence, a thread keeps a channel pair and adds its positions in registers: one atomic per
+// (block, channel) instead of one per element (1.2 M atomics on 6144 addresses per WN layer: 12.5 us for 6 MB of traffic)
+template <typename T>
+__global__ __launch_bounds__(256) void gated_bwd_dg_kernel(const T* xin, const T* g, const T* dacts, T* dxin, float* dg,
+                                                           int nseq, int len, int H, int tch) {
+  const int per_seq = (len + tch - 1) / tch;
+  const int s = blockIdx.x / per_seq;
+  const int t0 = (blockIdx.x - s * per_seq) * tch, t1 = min(len, t0 + tch);
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const float ga = to_f<T>(g[(long)s * 2 * H + h]), gb = to_f<T>(g[(long)s * 2 * H + H + h]);
+    float sa = 0.f, sb = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const long nt = (long)s * len + t;
+      const float a = to_f<T>(xin[nt * 2 * H + h]) + ga, b = to_f<T>(xin[nt * 2 * H + H + h]) + gb;
+      const float th = tanhf(a), sg = sigmoid_f(b), d = to_f<T>(dacts[nt * H + h]);
+      const float da = d * sg * (1.f - th * th), db = d * th * sg * (1.f - sg);
+      dxin[nt * 2 * H + h] = from_f<T>(da);
+      dxin[nt * 2 * H + H + h] = from_f<T>(db);
+      sa += da;
+      sb += db;
+    }
+    atomicAdd(dg + (long)s * 2 * H + h, sa);
+    atomicAdd(dg + (long)s * 2 * H + H + h, sb);
+  }
+}
+
 // ---- fused loss reductions over a table of segments ------------------------------------------------
 // The segments (37 feature maps from 10 K to 21 M elements) are treated as ONE flat index space split evenly over the
 // blocks: a block walks the part of each segment that falls into its range with 16-byte loads and finishes with a
@@ -475,6 +502,20 @@ int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void*
   if (!xin || !dacts || !dxin || nseq <= 0 || len <= 0 || H <= 0) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)nseq * len * H;
+  if (dg && g) {
+    // positions per block: >= 512 blocks when the problem has them, at least 4 positions each
+    int tch = (int)(((long)nseq * len + 511) / 512);
+    if (tch < 4) tch = 4;
+    const int blocks = nseq * ((len + tch - 1) / tch);
+    if (dtype == EVT_DT_BF16)
+      hipLaunchKernelGGL(gated_bwd_dg_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)xin, (const bf16_t*)g,
+                         (const bf16_t*)dacts, (bf16_t*)dxin, dg, nseq, len, H, tch);
+    else if (dtype == EVT_DT_F32)
+      hipLaunchKernelGGL(gated_bwd_dg_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)xin, (const float*)g,
+                         (const float*)dacts, (float*)dxin, dg, nseq, len, H, tch);
+    else return EVT_EINVAL;
+    return evt_check_launch();
+  }
   if (dtype == EVT_DT_BF16)
     hipLaunchKernelGGL(gated_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)xin,
                        (const bf16_t*)g, (const bf16_t*)dacts, (bf16_t*)dxin, dg, nseq, len, H);
