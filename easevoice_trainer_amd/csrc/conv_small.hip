@@ -7,6 +7,7 @@
 //     transposed FIR over an LDS tile of dy_eff; weight gradient = one thread per (channel, tap) over LDS tiles.
 // HBM-bound byte work: coalesced 16-byte reads, LDS only for the small weight vector / block reduction.
 #include "evt_common.h"
+#include <cstdlib>
 #include "../../include/evt.h"
 #include "conv_p.h"
 
@@ -413,6 +414,82 @@ SP make_sp(const evt_conv1d_params* c) {
   return p;
 }
 
+// ---- Cout == 1 weight gradient, x-stationary form (stride 1, dilation 1): a thread keeps ONE 16-byte piece of an input
+//      row and adds it into the K taps it belongs to (output positions q = i + pad - t), so every input row is read once
+//      instead of once per tap, and the per-tap dy values are 4-byte loads that hit L1.  K * V accumulators per thread.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void cout1_bwd_weight_xs(SP p, int rows_per_block) {
+  constexpr int V = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);   // [npl][K * cin]
+  const int ppr = p.cin / V;
+  int pp = 1;
+  while (pp < ppr) pp <<= 1;                       // pieces per row padded to a power of two (<= 256)
+  const int npl = 256 / pp;                        // rows in flight per block trip
+  const int rl = threadIdx.x / pp, pc = threadIdx.x % pp;
+  float acc[K][V];
+#pragma unroll
+  for (int t = 0; t < K; ++t)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[t][e] = 0.f;
+  const T* x = reinterpret_cast<const T*>(p.x);
+  const T* dy = reinterpret_cast<const T*>(p.dy);
+  const T* ys = reinterpret_cast<const T*>(p.y_in);
+  const long total = (long)p.nseq * p.lin;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(total, r0 + rows_per_block);
+  constexpr int UP = 4;                            // rows per thread and trip: their loads are issued before the first use
+  if (pc < ppr) {
+    for (long rb = r0 + rl; rb < r1; rb += (long)npl * UP) {
+      uint4 v[UP];
+      float d[UP][K];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const long r = rb + (long)u * npl;
+        const bool live = r < r1;
+        const long seq = live ? r / p.lin : 0;
+        const int i = live ? (int)(r - seq * p.lin) : 0;
+        v[u] = live ? *reinterpret_cast<const uint4*>(x + r * p.cin + pc * V) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int q = i + p.pad - t;
+          const bool ok = live && q >= 0 && q < p.lout;
+          const long o = seq * p.lout + (ok ? q : 0);
+          float dv = ok ? to_f<T>(dy[o]) : 0.f;
+          if (ok && ys) dv *= dact_from_out(p.out_act, to_f<T>(ys[o]), p.out_slope);
+          d[u][t] = dv;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const T* pv = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float xv = lrelu_f(to_f<T>(pv[e]), p.in_slope);
+#pragma unroll
+          for (int t = 0; t < K; ++t) acc[t][e] += d[u][t] * xv;
+        }
+      }
+    }
+  }
+  // the row lanes of the block meet in LDS and are added in lane order (deterministic)
+  const int kc = K * p.cin;
+  if (pc < ppr) {
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[rl * kc + t * p.cin + pc * V + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kc; i += 256) {
+    const int t = i / p.cin, c = i - t * p.cin;
+    float v = red[i];
+    for (int l = 1; l < npl; ++l) v += red[l * kc + i];
+    if (p.ws) p.ws[(long)blockIdx.x * p.ws_row + sreg_index(p, 0, c, t)] = v;
+    else atomicAdd(p.dw + sreg_index(p, 0, c, t), v);
+  }
+}
+
 }  // namespace
 
 extern "C" int evt_small_kind(const evt_conv1d_params* c) {
@@ -435,7 +512,8 @@ extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const vo
   p.G = G;
   const long total = (long)p.nseq * p.lout;
   long blocks = (total * G + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  static const long cap = getenv("EVT_COUT1_FWD_CAP") ? atol(getenv("EVT_COUT1_FWD_CAP")) : 4096;   // measurement knob
+  if (blocks > cap) blocks = cap;
   const size_t lds = (size_t)c->k * c->cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cout1_fwd");
@@ -455,22 +533,41 @@ extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, c
   if (ws && img * 2 <= ws_floats) {
     // partial rows instead of atomics: the block count is no longer bounded by same-address atomics, and the loop is
     // latency-bound (a trip = 4 positions per lane) -- four times the blocks, a quarter of the trips
-    ppb = (total + 1023) / 1024;
-    if (ppb < 16) ppb = 16;
+    static const long tgt = getenv("EVT_COUT1_WG_BLOCKS") ? atol(getenv("EVT_COUT1_WG_BLOCKS")) : 1024;   // measurement knob
+    static const long minp = getenv("EVT_COUT1_WG_MINP") ? atol(getenv("EVT_COUT1_WG_MINP")) : 16;
+    ppb = (total + tgt - 1) / tgt;
+    if (ppb < minp) ppb = minp;
     const long maxb = ws_floats / img;
     if ((total + ppb - 1) / ppb > maxb) ppb = (total + maxb - 1) / maxb;
     p.ws = ws; p.ws_row = img;
   }
   p.pos_per_block = (int)ppb;
-  const int blocks = (int)((total + ppb - 1) / ppb);
+  int blocks = (int)((total + ppb - 1) / ppb);
   const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
-  int pp = 1;
-  while (pp < c->k * (c->cin / V) && pp < 256) pp <<= 1;
-  const size_t lds = (size_t)(256 / pp) * c->k * c->cin * sizeof(float);    // one partial per position lane
   hipStream_t st = (hipStream_t)stream;
-  evt_set_last_tag("cout1_bwd_weight");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(cout1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p);
+  static const bool xs_off = getenv("EVT_NO_COUT1_XS") != nullptr;          // A/B switch
+  int ppr2 = 1;
+  while (ppr2 < c->cin / V) ppr2 <<= 1;
+  const size_t lds_xs = (size_t)(256 / ppr2) * c->k * c->cin * sizeof(float);
+  if (!xs_off && p.stride == 1 && p.dil == 1 && (c->k == 3 || c->k == 7) && ppr2 <= 256 && lds_xs <= (60u << 10)) {
+    // x-stationary form: blocks over INPUT rows (same bounds on the block count as below)
+    const long rows = (long)p.nseq * p.lin;
+    long rpb = (rows + blocks - 1) / blocks;
+    if (rpb < 16) rpb = 16;
+    blocks = (int)((rows + rpb - 1) / rpb);
+    evt_set_last_tag("cout1_bwd_weight_xs<k%d>", c->k);
+#define XS(T, K_) hipLaunchKernelGGL((cout1_bwd_weight_xs<T, K_>), dim3(blocks), dim3(256), lds_xs, st, p, (int)rpb)
+    if (c->dtype == EVT_DT_BF16) { if (c->k == 3) XS(bf16_t, 3); else XS(bf16_t, 7); }
+    else { if (c->k == 3) XS(float, 3); else XS(float, 7); }
+#undef XS
+  } else {
+    int pp = 1;
+    while (pp < c->k * (c->cin / V) && pp < 256) pp <<= 1;
+    const size_t lds = (size_t)(256 / pp) * c->k * c->cin * sizeof(float);    // one partial per position lane
+    evt_set_last_tag("cout1_bwd_weight");
+    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(cout1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p);
+  }
   int rc = evt_check_launch();
   if (rc || !p.ws) return rc;
   // the image's padded entries (kp > k, ck > cin) are never written by the blocks: only the k * cin live ones are folded

@@ -74,6 +74,11 @@ def main():
     for ci, co in [(512, 1536), (512, 512), (512, 2048), (2048, 512)]:
         shapes.append((f"s1 lin {ci}->{co}", 32, 1024, ci, co, 1, 1, 0, 1, 1, False, 1.0, 0))
     shapes.append(("conv_post 16->1 k7", B, 20480, 16, 1, 7, 1, 3, 1, 1, False, 0.01, 2))
+    # first / last layers of the period discriminators (Cin = 1 / Cout = 1): [real ; fake] x period sequences
+    shapes.append(("dP2 first 1->32 k5 s3", 2 * B * 2, 10240, 1, 32, 5, 3, 2, 1, 1, False, 1.0, 1))
+    shapes.append(("dP7 first 1->32 k5 s3", 2 * B * 7, 2926, 1, 32, 5, 3, 2, 1, 1, False, 1.0, 1))
+    shapes.append(("dP2 last 1024->1 k3", 2 * B * 2, 127, 1024, 1, 3, 1, 1, 1, 1, False, 1.0, 0))
+    shapes.append(("dP7 last 1024->1 k3", 2 * B * 7, 37, 1024, 1, 3, 1, 1, 1, 1, False, 1.0, 0))
 
     if a.only:
         shapes = [sh for sh in shapes if any(tok in sh[0] for tok in a.only.split(','))]

@@ -7,6 +7,7 @@ mkdir -p $O
 t0=$(date +%s)
 timeout 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$? $(( $(date +%s)-t0 ))s" > $O/times.txt
 tail -3 $O/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/times.txt; tail -1 $O/smoke.log
 t1=$(date +%s)
 timeout 500 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s)-t1 ))s" >> $O/times.txt
 mkdir -p $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
