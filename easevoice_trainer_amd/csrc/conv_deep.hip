@@ -1532,9 +1532,11 @@ int launch_wgrad_ring(const WgP& p_in, hipStream_t st) {
   static const long target = getenv("EVT_RING_BLOCKS") ? atol(getenv("EVT_RING_BLOCKS")) : 256;   // tuning knob (measured: 256 best)
   int nsplit, per;                                // ~1 block per CU: more splits only add partial tiles; >= 3 K stages per block
   wgrad_pick_split(p, tiles, nstages, target, 3, &nsplit, &per);
-  // XCD-aware order (EVT_WGRAD_RING_XCD=0: plain grid): the split count rounded DOWN to a multiple of 8 (it is bounded by
-  // the slabs the caller holds), every split non-empty
-  static const bool xcd_on = !(getenv("EVT_WGRAD_RING_XCD") && atoi(getenv("EVT_WGRAD_RING_XCD")) == 0);
+  // XCD-aware order, EVT_WGRAD_RING_XCD=1 (default: plain grid): the split count rounded DOWN to a multiple of 8 (it is
+  // bounded by the slabs the caller holds), every split non-empty.  Measured (round 4): FETCH_SIZE of the WN in-layer
+  // gradient (192 -> 384 k5, 3200 positions, 36 tiles x 8 splits) 12.1 -> 1.9 MB per launch, and the launch 15 -> 20 us:
+  // the 36 tiles of a split land on the 32 CUs of one XCD at once.  These operands fit every L2; time decides: off.
+  static const bool xcd_on = getenv("EVT_WGRAD_RING_XCD") && atoi(getenv("EVT_WGRAD_RING_XCD")) == 1;
   p.xcd_order = 0;
   if (xcd_on && nsplit >= 8) {
     const int s8 = nsplit / 8 * 8;
