@@ -388,6 +388,15 @@ class S2Engine:
             return
         self.graphs_enabled = True
 
+    def _room_for_capture(self):
+        """a captured shape keeps its own activation pool (a few GB at B = 16 x 4 s): stop capturing new shapes -- they run
+        eagerly then -- once less than a sixth of the device memory (at least 16 GB) is free"""
+        try:
+            free, total = torch.cuda.mem_get_info(self.device)
+        except Exception:
+            return True
+        return free >= max(total // 6, 16 << 30)
+
     def _step_graphed(self, inputs) -> S2Losses:
         key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in inputs)
         ent = self._graph_cache.get(key)
@@ -396,7 +405,7 @@ class S2Engine:
         if ent["graphs"] is None:
             ent["seen"] += 1
             captured = sum(1 for e in self._graph_cache.values() if e["graphs"] is not None)
-            if ent["seen"] <= self._graph_warmup or captured >= self._graph_max:
+            if ent["seen"] <= self._graph_warmup or captured >= self._graph_max or not self._room_for_capture():
                 self.graph_steps["eager"] += 1
                 self.graphs_enabled = False
                 try:

@@ -91,7 +91,8 @@ class SovitsTrain:
         if os.environ.get("EVT_GRAPHS", "1") != "0":
             # batches whose shapes repeat (bucketed / fixed-length sources) are replayed as HIP graphs after two eager
             # steps of that shape; other shapes keep running eagerly
-            eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "16")))
+            # (up to EVT_GRAPH_SHAPES of them, default 64; the engine also stops capturing when device memory runs short)
+            eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "64")))
         source = open_source("s2", hps["data"]["exp_dir"], device,
                              lambda n: SyntheticS2Batches(t["batch_size"], 4, n, device, seed=t["seed"], rank=rank, world=world),
                              batch_size=t["batch_size"], cfg=hps["data"], rank=rank, world=world)

@@ -90,9 +90,11 @@ def main():
             cb.embed.normal_()
             cb.inited.fill_(1.0)
             eng.build_optimizers()
-            eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "16")))
+            eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "64")))      # the trainer's default
             src = S2Reader(root, cfg, args.batch, dev)
             steps, epoch, wait, audio_s = 0, 0, 0.0, 0.0
+            tail_from = args.train_steps * 2 // 3           # the last third: most shapes are captured by then
+            tail_t0 = tail_audio0 = tail_rep0 = None
             torch.cuda.synchronize()
             t_all = time.perf_counter()
             while steps < args.train_steps:
@@ -106,6 +108,10 @@ def main():
                     except StopIteration:
                         break
                     wait += time.perf_counter() - t0          # time the step loop spent waiting for the reader
+                    if steps == tail_from:
+                        torch.cuda.synchronize()
+                        tail_t0, tail_audio0 = time.perf_counter(), audio_s
+                        tail_rep0 = getattr(eng, "graph_steps", {"replayed": 0})["replayed"]
                     eng.step(ssl, spec, spec_len, y, text, text_len)
                     steps += 1
                     audio_s += float(spec_len.sum()) * 640 / 32000        # real (unpadded) audio of the batch
@@ -117,6 +123,14 @@ def main():
             out["train"] = dict(steps=steps, ms_per_step=round(1e3 * dt / steps, 2), reader_wait_ms_per_step=round(1e3 * wait / steps, 2),
                                 audio_seconds_per_s=round(audio_s / dt, 1), shapes_seen=len(cache), shapes_captured=captured,
                                 steps_replayed=gs["replayed"], eager_share=round(1.0 - gs["replayed"] / max(steps, 1), 3))
+            if tail_t0 is not None and steps > tail_from:
+                nt = steps - tail_from
+                tdt = time.perf_counter() - tail_t0
+                out["train"]["last_third"] = dict(steps=nt, ms_per_step=round(1e3 * tdt / nt, 2),
+                                                  audio_seconds_per_s=round((audio_s - tail_audio0) / tdt, 1),
+                                                  eager_share=round(1.0 - (gs["replayed"] - tail_rep0) / nt, 3))
+            free, total = torch.cuda.mem_get_info(dev)
+            out["train"]["device_memory_gb"] = dict(used=round((total - free) / 2 ** 30, 1), total=round(total / 2 ** 30, 1))
     print(json.dumps(out))
 
 
