@@ -174,7 +174,7 @@ def test_sovits_trainer_loop_glue(feature_dir, tmp_path, monkeypatch):
     assert tr.global_step == 20 and [l["step"] for l in lines] == [0, 10]                   # 77 items -> 20 batches of 4
     assert lines[0]["loss"] == 44.0 and lines[0]["loss/d/total"] == 2.0 and lines[1]["loss/g/total"] == 34.0
     assert lines[0]["learning_rate"] == pytest.approx(1e-4 * 0.999875)                      # ExponentialLR fast-forwarded once
-    assert tr.engine.graphs == dict(warmup_steps=2, max_shapes=16)
+    assert tr.engine.graphs == dict(warmup_steps=2, max_shapes=64)
     assert sorted(os.listdir(os.path.join(d, "logs"))) == ["D_latest.pth", "G_latest.pth"]
     ck = torch.load(os.path.join(d, "logs", "G_latest.pth"), weights_only=False)
     assert set(ck) == {"model", "iteration", "optimizer", "learning_rate"} and ck["iteration"] == 1
