@@ -340,9 +340,10 @@ int evt_resunit_wide_fwd(const evt_resunit_params* a, const void* x, const void*
   // i.e. what counts is weight bytes per MFMA: four waves along the channels (a wave fetches only its own rows) and as
   // many position tiles per wave as the accumulators allow.  The first convolution covers P + 2 * 5 rows: 176 >= 170.
   // ring depth R (weight fragment sets, requested R - 2 K steps ahead): 4, 5, 6, 8, 12 measured alike (C = 128, k = 11:
-  // 40.9 / 41.1 / 41.3 / 41.6 / 41.3 us) -- the launch is not waiting for its weight stream; per K step a wave issues
-  // 22 MFMAs (352 cycles) and, with all four waves of the block reading every row fragment, the LDS delivers 45 KB
-  // (352 cycles at 128 B/clk): the two are equal, and whatever fails to overlap shows (t = 19 us + 2 x MFMA time).
+  // 40.9 / 41.1 / 41.3 / 41.6 / 41.3 us) -- the launch is not waiting for its weight stream.  Counters (rocprofv3 --pmc,
+  // profiles/r04_resunit_pmc.txt): MFMA busy 16-24 %, LDS array busy 15-27 % (a tenth of that bank conflicts), 0.7-1.1
+  // waves per SIMD: neither pipe is near its rate; one block of four waves per CU means every wave waits out its own
+  // fragment-read -> MFMA chain with nothing else to run (t = 19 us + 2 x MFMA time over k = 3 / 7 / 11).
   if (a->C == 128) return launch<128, 4, 1, 11, 10, false, 4>(p, st);
   return launch<64, 4, 1, 11, 10, false, 4>(p, st);
 }
