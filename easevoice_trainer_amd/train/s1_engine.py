@@ -54,9 +54,13 @@ class S1Engine:
     def micro_step(self, batch: dict, batch_idx: int):
         """one micro-batch: forward_old (or the DPO `forward` when config train.if_dpo, t2s_lightning_module.py:44) +
         backward (+ optimiser step on the reference's schedule)"""
-        fwd = self.model.forward if self.config.get("train", {}).get("if_dpo", False) is True else self.model.forward_old
+        dpo = self.config.get("train", {}).get("if_dpo", False) is True
+        fwd = self.model.forward if dpo else self.model.forward_old
         stepping = batch_idx > 0 and batch_idx % 4 == 0
-        overlap = stepping and self.reducer is not None and self.reducer.world > 1 and bool(self._cuts)
+        # the DPO forward walks the block stack twice (chosen and rejected targets, t2s_model.py:393-429): a hook at a cut
+        # block's input would fire in the rejected pass's backward while the chosen pass still has gradients to add to the
+        # same arena range -> a range is only final after the whole backward, so DPO reduces the arena in one piece
+        overlap = stepping and not dpo and self.reducer is not None and self.reducer.world > 1 and bool(self._cuts)
         # the forward plants the tensor hooks at the cut blocks' inputs
         self.model.h.grad_hook_blocks = tuple(self._cuts) if overlap else ()
         try:

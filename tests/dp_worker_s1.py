@@ -17,6 +17,8 @@ from util_fill import fill_module  # noqa: E402
 def small_cfg():
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
     cfg["model"].update(hidden_dim=64, embedding_dim=64, head=4, n_layer=4, linear_units=256)
+    if os.environ.get("EVT_TEST_DPO", "0") == "1":       # the DPO forward: the block stack is walked twice per backward
+        cfg.setdefault("train", {})["if_dpo"] = True
     return cfg
 
 
@@ -46,14 +48,20 @@ def main():
         eng.model.eval()                      # dropout off: the comparison is about the gradient exchange
         if world > 1:
             eng.reducer.broadcast_params(eng.arena.param)
-            stepped = [eng.micro_step(batch(rank, i), i)[2] for i in range(5)]
+            stepped = []
+            for i in range(5):
+                torch.manual_seed(77 + 10 * rank + i)     # make_reject_y draws from the global generator (DPO case)
+                stepped.append(eng.micro_step(batch(rank, i), i)[2])
             assert stepped == [False] * 4 + [True]
             # one collective per piece (the test model is far below the bucket size): three with two cuts, one without
             pieces = 1 + len([c for c in os.environ.get("EVT_DP_S1_CUTS", "16,8").split(",") if c.strip() != "" and int(c) < 3])
+            if os.environ.get("EVT_TEST_DPO", "0") == "1":
+                pieces = 1                    # no range is final before the second traversal's backward: one piece
             assert eng.reducer.stats["all_reduce"] == pieces, (eng.reducer.stats, pieces)
         else:                                 # the same ten micro-batches in one process, mean of the two ranks' sums
             for r in range(2):
                 for i in range(5):
+                    torch.manual_seed(77 + 10 * r + i)
                     eng.micro_step(batch(r, i), 1)
             eng.arena.grad.mul_(0.5)
             eng.optimizer.step()

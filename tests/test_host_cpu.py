@@ -236,6 +236,31 @@ def test_s1_engine_data_parallel_gloo(tmp_path):
         assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a)), tag
 
 
+def test_s1_engine_data_parallel_gloo_dpo(tmp_path):
+    """the same equality with train.if_dpo (the forward walks the block stack twice, chosen and rejected targets): with
+    cut points configured the reduction must still be ONE piece after the backward -- a hook-driven early piece would
+    hand a range to the collective before the second traversal has added its gradients"""
+    import subprocess
+    import sys
+    from easevoice_trainer_amd.dist import spawn_ranks
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker_s1.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["EVT_TEST_DPO"] = "1"
+    subprocess.run([sys.executable, worker, str(tmp_path / "single")], check=True, env=env)
+    one = torch.load(tmp_path / "single0")
+    os.environ["EVT_DP_S1_CUTS"] = "2,1"
+    os.environ["EVT_TEST_DPO"] = "1"
+    try:
+        codes = spawn_ranks([sys.executable, worker, str(tmp_path / "dpo")], [0, 1])
+    finally:
+        del os.environ["EVT_DP_S1_CUTS"], os.environ["EVT_TEST_DPO"]
+    assert codes == [0, 0]
+    a, b = torch.load(tmp_path / "dpo0"), torch.load(tmp_path / "dpo1")
+    assert torch.equal(a, b)
+    assert torch.allclose(a, one, rtol=1e-5, atol=1e-7) and not torch.equal(a, torch.zeros_like(a))
+
+
 def test_split_subgroups_gloo(tmp_path):
     """BASELINE config 5's layout: one world, two sub-communicators (s1 ranks / s2 ranks), each reducing only its own
     gradients through GradReducer(group=...)"""
