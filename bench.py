@@ -38,10 +38,11 @@ def init_dist(n_gpus):
         if backend != "nccl":
             local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("EVT_DP_FORCE", "0") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -69,7 +70,7 @@ def run_s2(args, world, rank, local):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(hps["train"]["seed"])
     reducer = None
-    if world > 1:
+    if world > 1 or os.environ.get("EVT_DP_FORCE", "0") == "1":
         from easevoice_trainer_amd.dist import GradReducer
 
         reducer = GradReducer(world)
@@ -78,7 +79,7 @@ def run_s2(args, world, rank, local):
     cb = eng.net_g.quantizer.vq.layers[0]._codebook
     cb.embed.normal_(generator=None)
     cb.inited.fill_(1.0)
-    if world > 1:
+    if reducer is not None:
         reducer.broadcast_params(eng.rt_g.arena.param)
         reducer.broadcast_params(eng.rt_d.arena.param)
     eng.build_optimizers()
@@ -98,6 +99,7 @@ def run_s2(args, world, rank, local):
         out = step()
     if world > 1:
         torch.distributed.barrier()
+    if reducer is not None:
         reducer.reset_stats()
         reducer.timing = dev.type == "cuda"        # HIP events around every wait for the side stream: the exposed part
     torch.cuda.synchronize()
@@ -109,8 +111,9 @@ def run_s2(args, world, rank, local):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     comm = None
-    if world > 1:
+    if reducer is not None:
         comm = reducer.comm_report(args.steps)      # this rank's view; the line is rank 0's
+    if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -123,9 +126,10 @@ def run_s2(args, world, rank, local):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"s2 SoVITS generator+discriminator GAN step, batch={B}/GPU, {args.clip_seconds} s 32 kHz "
                                f"clips (T={T} frames), configs/s2.json, random-init weights",
-                   "global_batch": world * B, "parallelism": reducer.describe() if reducer is not None else "dp1",
+                   "global_batch": world * B, "parallelism": (reducer.describe(eng.exchange_ranges()) if reducer is not None else "dp1")
+                                  + (", cut (data-parallel) program without collectives" if eng.cut_only else ""),
                    "launch": (f"hip-graph replay ({len(eng._program())} graphs/step"
-                              f"{', gradient reductions between them' if world > 1 else ''})") if eng.graphs_enabled else "eager"},
+                              f"{', gradient reductions between them' if reducer is not None else ''})") if eng.graphs_enabled else "eager"},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
@@ -149,7 +153,13 @@ def main():
     ap.add_argument("--clip-seconds", type=int, default=4)
     ap.add_argument("--graphs", type=int, default=1, help="1: replay the s2 step as HIP graphs (default), 0: eager launches")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs (use under rocprofv3)")
+    ap.add_argument("--dp-program", type=int, default=0, choices=[0, 1, 2],
+                    help="one GPU only. 1: run the data-parallel (cut, eleven-graph) program without collectives -- the cost of "
+                         "the decomposition itself next to the default three-phase program; 2: the same with the collectives "
+                         "issued on a one-rank RCCL group (side stream, between the graph replays)")
     args = ap.parse_args()
+    if args.dp_program and args.gpus == 1:
+        os.environ["EVT_DP_CUT" if args.dp_program == 1 else "EVT_DP_FORCE"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started bare (`python bench.py --gpus N`): become the launcher, one rank per GPU over RCCL on 127.0.0.1
         from easevoice_trainer_amd.dist import spawn_ranks
@@ -193,7 +203,7 @@ def main():
             res["s1"] = s1
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -28,20 +28,26 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None, rsag=None, rsag_min_bytes: int = 8 << 20):
-        """rsag (default: EVT_DP_RSAG = 0 | 1 | auto): a bucket as reduce-scatter + all-gather instead of one all-reduce.
+    def __init__(self, world_size: int, bucket_bytes: int = 64 << 20, group=None, rsag=None, rsag_min_bytes: int = 8 << 20,
+                 force=None):
+        """rsag (default: EVT_DP_RSAG = auto | 0 | 1): a bucket as reduce-scatter + all-gather instead of one all-reduce.
         On xGMI every GPU has a direct link to each of the other seven: a ring all-reduce is bound by ONE link per hop,
         while the two halves of reduce-scatter / all-gather move 1/world of the bucket to / from every peer at once; below a
         few MiB the second collective's latency costs more than the links give, so `auto` keeps all-reduce for buckets
         under rsag_min_bytes (and for worlds of two, where there is one link either way).  The results are the same sums
         (per element one reduction over the ranks either way); equality-tested against all_reduce on gloo
-        (tests/test_host_cpu.py).  Default 0 until the variant has met RCCL on more than one GPU.
+        (tests/test_host_cpu.py) and issued on RCCL by the one-rank self-test (tests/test_zz_rccl_selftest_gpu.py).
+        Default auto: reduce-scatter + all-gather from 3 ranks up (EVT_DP_RSAG=0 is the all-reduce fallback).
+        force (default: EVT_DP_FORCE=1): issue the collectives even in a world of one -- a one-rank RCCL group runs the
+        same launches on the same side stream between the same graph replays, so the stream / replay ordering of the
+        data-parallel program can be exercised (and its cost timed) on a single GPU: bench.py --dp-program 2.
         The reducer keeps count of what it issued (collectives, bytes, which kind) and -- with timing on -- of how long
         the compute stream had to wait for the side stream: bench.py prints both."""
         self.world = world_size
         self.group = group
+        self.force = (os.environ.get("EVT_DP_FORCE", "0") == "1") if force is None else bool(force)
         self.bucket_elems = max(1, bucket_bytes // 4)
-        mode = os.environ.get("EVT_DP_RSAG", "0") if rsag is None else rsag
+        mode = os.environ.get("EVT_DP_RSAG", "auto") if rsag is None else rsag
         self.rsag_mode = {True: "1", False: "0"}.get(mode, str(mode))
         if self.rsag_mode not in ("0", "1", "auto"):
             raise ValueError(f"EVT_DP_RSAG / rsag must be 0, 1 or auto, got {mode!r}")
@@ -57,10 +63,20 @@ class GradReducer:
     def rsag(self):
         return self.rsag_mode != "0"
 
+    @property
+    def active(self):
+        """whether collectives are issued at all: more than one rank, or a forced one-rank run"""
+        return self.world > 1 or self.force
+
     def _use_rsag(self, n):
         if self.rsag_mode == "1":
             return n >= self.world
         return self.rsag_mode == "auto" and self.world > 2 and n >= max(self.world, self.rsag_min_elems)
+
+    def plan(self, n):
+        """what all_reduce() issues for a flat range of n fp32 elements: [(bytes, "all-reduce" | "reduce-scatter + all-gather")]"""
+        return [((e - b) * 4, "reduce-scatter + all-gather" if self._use_rsag(e - b) else "all-reduce")
+                for b, e in self.buckets(n)]
 
     def _sum_bucket(self, t):
         """sum the 1-D contiguous bucket `t` over the group, in place"""
@@ -84,11 +100,23 @@ class GradReducer:
         if chunk * w < t.numel():                           # fewer than `world` leftover elements
             dist.all_reduce(t[chunk * w:], op=dist.ReduceOp.SUM, group=self.group)
 
-    def describe(self):
-        """how gradients are exchanged, for the bench line's config.parallelism"""
+    def describe(self, ranges=None):
+        """how gradients are exchanged, for the bench line's config.parallelism.  ranges: [(name, elements)] of the flat
+        ranges the step reduces one by one -> the plan per range (MiB, kind) is spelt out."""
         kind = {"0": "all-reduce", "1": "reduce-scatter + all-gather",
-                "auto": f"reduce-scatter + all-gather for buckets >= {self.rsag_min_elems * 4 >> 20} MiB, all-reduce below"}
-        return f"dp{self.world}, {kind[self.rsag_mode]}, buckets of {self.bucket_elems * 4 >> 20} MiB"
+                "auto": (f"reduce-scatter + all-gather for buckets >= {self.rsag_min_elems * 4 >> 20} MiB from 3 ranks up, "
+                         "all-reduce otherwise")}
+        s = f"dp{self.world}, {kind[self.rsag_mode]}, buckets of {self.bucket_elems * 4 >> 20} MiB"
+        if self.force and self.world == 1:
+            s += ", one-rank collectives forced"
+        if ranges:
+            parts = []
+            for name, n in ranges:
+                pl = self.plan(n)
+                kinds = sorted({k for _b, k in pl})
+                parts.append(f"{name} {n * 4 / (1 << 20):.1f} MiB = {len(pl)} x {' / '.join(kinds)}")
+            s += "; per range: " + "; ".join(parts)
+        return s
 
     def _side_stream(self, device):
         if self._stream is None and device.type == "cuda":
@@ -103,7 +131,7 @@ class GradReducer:
         """sum `flat` (1-D contiguous) over the group, in place.  async_op=True: enqueue on a side stream and return;
         call wait() before the optimiser reads the buffer.  average=True: the 1/world pass rides on the same stream right
         behind the collectives (off the compute stream when async)."""
-        if self.world == 1:
+        if not self.active:
             return
         assert flat.dim() == 1 and flat.is_contiguous()
         if flat.device.type == "cuda" and async_op:
@@ -150,14 +178,14 @@ class GradReducer:
 
     def broadcast_params(self, flat: torch.Tensor, src: int = 0):
         """one-time parameter broadcast from rank `src` (DDP's wrap-time broadcast)"""
-        if self.world == 1:
+        if not self.active:
             return
         for b, e in self.buckets(flat.numel()):
             dist.broadcast(flat[b:e], src=src, group=self.group)
 
     def all_reduce_scalars(self, t: torch.Tensor):
         """batched metric reduction (the reference does three separate sync_dist scalar all-reduces per step)"""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             t.div_(self.world)
         return t

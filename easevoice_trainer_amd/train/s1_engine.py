@@ -60,7 +60,7 @@ class S1Engine:
         # the DPO forward walks the block stack twice (chosen and rejected targets, t2s_model.py:393-429): a hook at a cut
         # block's input would fire in the rejected pass's backward while the chosen pass still has gradients to add to the
         # same arena range -> a range is only final after the whole backward, so DPO reduces the arena in one piece
-        overlap = stepping and not dpo and self.reducer is not None and self.reducer.world > 1 and bool(self._cuts)
+        overlap = stepping and not dpo and self.reducer is not None and self.reducer.active and bool(self._cuts)
         # the forward plants the tensor hooks at the cut blocks' inputs
         self.model.h.grad_hook_blocks = tuple(self._cuts) if overlap else ()
         try:
@@ -84,7 +84,7 @@ class S1Engine:
             p.grad = v
         stepped = False
         if stepping:
-            if self.reducer is not None and self.reducer.world > 1:
+            if self.reducer is not None and self.reducer.active:
                 self.reducer.all_reduce(self.arena.grad[:hi], async_op=self.arena.grad.is_cuda, average=True)
                 self.reducer.wait()
             self.optimizer.step()

@@ -56,14 +56,17 @@ class S2Engine:
         self.graphs_enabled = False
         # data parallelism: gradients are reduced sub-model by sub-model on a side stream while the backward of the next
         # sub-model runs (EVT_DP_OVERLAP=0: the two whole-arena reductions between the phases, nothing overlapped)
-        self.overlap = (reducer is not None and reducer.world > 1 and os.environ.get("EVT_DP_OVERLAP", "1") != "0")
+        self.overlap = (reducer is not None and reducer.active and os.environ.get("EVT_DP_OVERLAP", "1") != "0")
+        # EVT_DP_CUT=1: the cut program (eleven pieces) on one GPU WITHOUT collectives -- what the decomposition itself costs
+        # next to the three-phase program (bench.py --dp-program 1)
+        self.cut_only = (not self.overlap and os.environ.get("EVT_DP_CUT", "0") == "1")
         # one GPU, EVT_BOOK_PIPE=1: the same cuts, used to run each sub-model's bookkeeping (weight-norm gradient, AdamW,
         # refold) on a side stream under the backward of the next sub-model (ModelRuntime.book_piece).  Off by default:
         # measured round 4, the launches do overlap (kernel trace) and the step does not get shorter -- 24.7-24.8 ms
         # against 24.6-24.7 -- although it is 2.0 ms shorter without them: the backward next to them slows down by as much
-        self.pipe = ((reducer is None or reducer.world == 1) and self.device.type == "cuda"
+        self.pipe = ((reducer is None or not reducer.active) and self.device.type == "cuda" and not self.cut_only
                      and os.environ.get("EVT_BOOK_PIPE", "0") == "1")
-        if self.overlap or self.pipe:
+        if self.overlap or self.pipe or self.cut_only:
             self.net_g.split_backward = True
             nd = len(self.net_d.discriminators)
             self._d_ranges = [self.rt_d.arena.range_of_prefix(f"discriminators.{i}.") for i in range(nd)]
@@ -295,10 +298,12 @@ class S2Engine:
         for n, i in enumerate(order):
             st.d_losses[i].backward()
             rt_d.book_piece(self.optim_d, [self._d_rows[i]], [self._d_rows[i]], [self._d_ranges[i]], first=n == 0)
-        left = self._complement(self._d_ranges, rt_d.arena.numel)      # nothing in today's discriminators
+        # autograd-owned gradients reach the arena here, BEFORE the leftover ranges are updated (today's discriminators
+        # have neither: every parameter is a convolution of the bank inside one of the six ranges)
+        rt_d.gather_free_grads()
+        left = self._complement(self._d_ranges, rt_d.arena.numel)
         if left:
             rt_d.book_piece(self.optim_d, [], [], left, first=False)
-        rt_d.gather_free_grads()
         rt_d.book_join()
         # ---- generator step: D update and refold are done; losses, then the backward in its three parts ----
         self._phase_b(st, backward=False)
@@ -316,6 +321,18 @@ class S2Engine:
         rt_g.book_join()
         st.gss_g = rt_g.grad_sumsq()
 
+    def exchange_ranges(self):
+        """[(name, fp32 elements)] of the flat gradient ranges the data-parallel step reduces one by one, in issue order
+        (bench.py prints the collective plan per range through GradReducer.describe)"""
+        if not self.overlap:
+            return [("D arena", self.rt_d.arena.grad.numel()), ("G arena", self.rt_g.arena.grad.numel())]
+        out = [(f"D sub-discriminator {i}", hi - lo) for i, (lo, hi) in reversed(list(enumerate(self._d_ranges)))]
+        out.append(("G vocoder", self._dec_range[1] - self._dec_range[0]))
+        out.append(("G flow + posterior encoder", self._fq_range[1] - self._fq_range[0]))
+        for lo, hi in self._complement([self._dec_range, self._fq_range], self.rt_g.arena.grad.numel()):
+            out.append(("G rest", hi - lo))
+        return out
+
     def _reduce_async(self, flat, lo, hi):
         self.reducer.all_reduce(flat[lo:hi], async_op=True)
 
@@ -324,7 +341,7 @@ class S2Engine:
         piped=False: the caller needs the optimiser calls at their serial places (do_opt=False, hook_after_d)."""
         if self.pipe and piped:
             return [(self._phase_pipe, None)]
-        if not self.overlap and not self.pipe:
+        if not self.overlap and not self.pipe and not self.cut_only:
             return [(self._phase_a, lambda: self._reduce(self.rt_d.arena)),
                     (self._phase_b, lambda: self._reduce(self.rt_g.arena)), (self._phase_c, None)]
         # the cut program (the generator's graph is built with its cuts: only this order of backward calls walks all of it)

@@ -419,6 +419,7 @@ def test_s2_data_parallel_program_plumbing_cpu():
 
     class FakeReducer:
         world = 2
+        active = True
 
     hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
     eng = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
@@ -521,7 +522,7 @@ def test_bench_multi_rank_dry_run(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"].startswith("dp2, all-reduce") and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("dp2, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up") and d["config"]["global_batch"] == 4 and d["value"] > 0
     # the line explains its own gradient exchange: one all-reduce of the (toy) arena every fourth micro-step
     assert d["comm"]["all_reduce_per_step"] > 0 and d["comm"]["mib_per_step"] > 0 and d["comm"]["rs_ag_per_step"] == 0
     # a launch with the wrong world size is refused, not silently run as N independent jobs

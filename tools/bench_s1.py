@@ -122,12 +122,12 @@ def run(args, world, rank, local, extras=True):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(cfg["train"]["seed"])
     reducer = None
-    if world > 1:
+    if world > 1 or os.environ.get("EVT_DP_FORCE", "0") == "1":      # forced: one-rank collectives (bench.py --dp-program 2)
         from easevoice_trainer_amd.dist import GradReducer
 
         reducer = GradReducer(world)
     eng = S1Engine(cfg, dev, dtype, reducer=reducer)
-    if world > 1:
+    if reducer is not None:
         reducer.broadcast_params(eng.arena.param)
     B = args.s1_batch
     x_len, y_len = (256, 768) if os.environ.get("EVT_BENCH_TINY") != "1" else (8, 24)
@@ -138,6 +138,7 @@ def run(args, world, rank, local, extras=True):
         idx += 1
     if world > 1:
         torch.distributed.barrier()
+    if reducer is not None:
         reducer.reset_stats()
         reducer.timing = on_gpu
     sync()
@@ -149,7 +150,7 @@ def run(args, world, rank, local, extras=True):
         torch.distributed.barrier()
     sync()
     dt = time.perf_counter() - t0
-    comm = reducer.comm_report(args.steps) if world > 1 else None
+    comm = reducer.comm_report(args.steps) if reducer is not None else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

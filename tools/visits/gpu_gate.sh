@@ -10,6 +10,6 @@ echo -n "s2 new  "; run timeout 300 python bench.py --workload s2 --no-extras --
 echo -n "s2 base "; (cd ab_base && run timeout 300 python bench.py --workload s2 --no-extras --steps 20)
 echo -n "s2 new  "; run timeout 300 python bench.py --workload s2 --no-extras --steps 20
 } | tee $O/steps.txt
-bash tools/gpu_s2_graphstats.sh $(basename $O) > /dev/null 2>&1
+bash tools/visits/gpu_s2_graphstats.sh $(basename $O) > /dev/null 2>&1
 grep "gated\|window" $O/replay_kernels.txt | cut -c1-120
 grep -v amdgpu.ids $O/err.txt | tail -3

@@ -26,7 +26,7 @@ rm -rf $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
 timeout 200 python tools/trace_shapes.py --top 400 > $O/conv_time_by_shape.txt 2>&1
 timeout 100 python tools/bench_attn.py > $O/bench_attn_b32.json 2>/dev/null
 timeout 100 python tools/bench_conv.py --wonly --only "plain C,dP,dS 1024,WN in,FFN 192->768 k3 T200" --iters 20 > $O/bench_wgrad.txt 2>&1
-timeout 300 bash tools/gpu_s2_graphstats.sh $(basename $O) > /dev/null 2>&1          # kernel list of the replayed step
+timeout 300 bash tools/visits/gpu_s2_graphstats.sh $(basename $O) > /dev/null 2>&1          # kernel list of the replayed step
 timeout 300 python tools/glue_lines.py --top 120 2>&1 | grep -v amdgpu.ids > $O/glue_lines.txt
 timeout 120 python tools/bench_wgrad_gemm.py 2>&1 | grep -v amdgpu.ids > $O/bench_wgrad_gemm.txt
 echo "all $(( $(date +%s)-t0 ))s" >> $O/times.txt
