@@ -67,7 +67,7 @@ def run_s2(args, world, rank, local):
 
     dev = torch.device("cuda", local)
     hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     torch.manual_seed(hps["train"]["seed"])
     reducer = None
     if world > 1 or os.environ.get("EVT_DP_FORCE", "0") == "1":
@@ -133,6 +133,9 @@ def run_s2(args, world, rank, local):
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
+    if eng.scaler.enabled:
+        res["grad_scaler"] = dict(eng.scaler.state_dict(), optimizer_steps_applied=[eng.optim_d.sync_step_count(),
+                                                                                   eng.optim_g.sync_step_count()])
     if comm is not None:
         # gradient exchange per step on rank 0: collectives issued, MiB moved, and how long the compute stream stood
         # waiting for them (what the overlap with the backward did not hide)
@@ -147,7 +150,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="both", choices=["both", "s2", "s1"],
                     help="both (default): the s2 line with the s1 leg as its `s1` sub-object")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="f16: the reference's fp16_run mode (IEEE-half build of the library + device-side GradScaler), s2 leg")
     ap.add_argument("--batch", type=int, default=16, help="s2 batch per GPU (BASELINE config 2: 16)")
     ap.add_argument("--s1-batch", type=int, default=32, help="s1 batch per GPU (BASELINE config 3: 32)")
     ap.add_argument("--clip-seconds", type=int, default=4)
@@ -202,9 +206,19 @@ def main():
             res["metric"] = "audio-seconds/sec trained (s2) [value]; tokens/sec (s1) in `s1`"
             res["s1"] = s1
     if rank == 0:
+        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise come out at
+        # exit, AFTER the line below: flush it first, so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0) if os.environ.get("EVT_BENCH_HARD_EXIT") == "1" else None
 
 
 if __name__ == "__main__":

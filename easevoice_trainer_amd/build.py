@@ -1,4 +1,5 @@
-"""Builds libevt_hip.so (all csrc/*.hip, gfx950 only) in-tree with hipcc.
+"""Builds libevt_hip.so (all csrc/*.hip, gfx950 only; bfloat16 as the 16-bit type) and libevt_hip_f16.so (the same sources
+with -DEVT_HALF_F16: IEEE half, the reference's fp16_run mode) in-tree with hipcc.
 
 Incremental by CONTENT: an object is rebuilt when the hash of its source, the headers and the flags differs from the one
 recorded next to it (mtimes say nothing after a checkout).  hipcc cross-compiles without a GPU, so this runs in the build
@@ -16,6 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libevt_hip.so")
+LIB_F16 = os.path.join(HERE, "libevt_hip_f16.so")
+HALF_BUILDS = {"bf16": (OBJ, LIB, []), "f16": (os.path.join(HERE, "csrc", "_obj_f16"), LIB_F16, ["-DEVT_HALF_F16"])}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
@@ -44,7 +47,9 @@ def source_hash() -> str:
     return _sha(srcs + _headers())[:12]
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, half: str = "bf16") -> str:
+    """half: "bf16" -> libevt_hip.so, "f16" -> libevt_hip_f16.so (same sources, -DEVT_HALF_F16)"""
+    OBJ, LIB, half_flags = HALF_BUILDS[half]
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = _headers()
@@ -53,7 +58,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s[:-4] + ".o")
-        flags = [*FLAGS, *EXTRA_FLAGS.get(s, [])]
+        flags = [*FLAGS, *half_flags, *EXTRA_FLAGS.get(s, [])]
         if s == VERSION_SRC:
             flags.append(f'-DEVT_SRC_HASH="{shash}"')
         stamp = _sha([src] + hdrs, " ".join(flags))
@@ -86,5 +91,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_all(force: bool = False, verbose: bool = False):
+    return [build_lib(force, verbose, half) for half in ("bf16", "f16")]
+
+
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -70,22 +70,22 @@ __device__ __forceinline__ bool visible(int qi, int kj, int x_len, int xl, int y
 // two ds_read_b64_tr_b16 (transposing 16-bit LDS reads) -> one MFMA A fragment.  The builtin (not inline asm) lets the
 // compiler track the LDS counter, so all fragment reads of a key sub-block are in flight behind ONE wait.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr2(const bf16_t* p0, const bf16_t* p1) {
+__device__ __forceinline__ h16x8 tr2(const h16_t* p0, const h16_t* p1) {
   typedef __attribute__((address_space(3))) s16x4* lds_p;
-  union { struct { s16x4 lo, hi; } h; bf16x8 v; } r;
+  union { struct { s16x4 lo, hi; } h; h16x8 v; } r;
   r.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
   r.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
   return r.v;
 }
 
-__device__ __forceinline__ bf16x8 pack8(const float* p) {
-  union { bf16x8 v; bf16_t e[8]; } r;
+__device__ __forceinline__ h16x8 pack8(const float* p) {
+  union { h16x8 v; h16_t e[8]; } r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.e[i] = f2bf(p[i]);
+  for (int i = 0; i < 8; ++i) r.e[i] = f2h(p[i]);
   return r.v;
 }
 
-__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ h16x8 ld8(const h16_t* p) { return *reinterpret_cast<const h16x8*>(p); }
 
 constexpr int D = 32;
 constexpr int PITCH = D + 8;   // LDS row pitch in elements (80 B: 16-byte aligned, not a power of two)
@@ -179,8 +179,8 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // ---------------------------------------------------------------------------------------------------------
 template <bool JOINT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Ks[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Vs[2][64 * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   // 1-D grid, LONGEST BLOCKS FIRST: query block nqb-1 (walks every key) of all (b, h), then nqb-2, ... -- the short text
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
   const int b = bh / p.H, h = bh % p.H;
   const int qblk = ((p.L + 127) / 128 - 1 - blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
-  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
-  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
+  const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + b * p.sb + h * p.sh;
+  const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + b * p.sb + h * p.sh;
+  const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + b * p.sb + h * p.sh;
   const float sc2 = p.scale * LOG2E;
   const unsigned thr = p.drop_thr;
 
-  bf16x8 qf[2];
+  h16x8 qf[2];
   f32x4 ot[2][2];
   float m[2], ms[2], l[2];          // running maximum (raw scores), the same times scale*log2(e), running sum
   int qi[2], qt0[2];
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
   for (int kb = 0; kb < kmax; kb += 64, buf ^= 1) {
     const bool more = kb + 64 < kmax;
     if (more) EVT_TILE_LOAD(K, p.sl, V, p.sl, kb + 64);
-    const bf16_t* Kc = Ks[buf];
-    const bf16_t* Vc = Vs[buf];
+    const h16_t* Kc = Ks[buf];
+    const h16_t* Vc = Vs[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int k0 = kb + sb * 32;
@@ -234,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* vrow = Vc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-      const bf16x8 va0 = tr2(vrow, vrow + 16 * PITCH);
-      const bf16x8 va1 = tr2(vrow + 16, vrow + 16 * PITCH + 16);
+      const h16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
+      const h16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const h16_t* vrow = Vc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const h16x8 va0 = tr2(vrow, vrow + 16 * PITCH);
+      const h16x8 va1 = tr2(vrow + 16, vrow + 16 * PITCH + 16);
       const unsigned k0c = __umul24((unsigned)k0, DROP_KC);
       // both query tiles in ONE straight-line body (two independent dependency chains for the scheduler); the masked
       // variant (diagonal / padding tiles, a few percent of the work) evaluates visible() per score in both tiles --
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
         f32x4 sa[2], sb2[2];
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
-          sb2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
+          sa[t] = EVT_MFMA_16x16x32(ka0, qf[t], z, 0, 0, 0);
+          sb2[t] = EVT_MFMA_16x16x32(ka1, qf[t], z, 0, 0, 0);
         }
         float s[2][8];
 #pragma unroll
@@ -292,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
         }
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          const bf16x8 pf = pack8(s[t]);
-          ot[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, pf, ot[t][0], 0, 0, 0);
-          ot[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, pf, ot[t][1], 0, 0, 0);
+          const h16x8 pf = pack8(s[t]);
+          ot[t][0] = EVT_MFMA_16x16x32(va0, pf, ot[t][0], 0, 0, 0);
+          ot[t][1] = EVT_MFMA_16x16x32(va1, pf, ot[t][1], 0, 0, 0);
         }
       };
       using I0 = std::integral_constant<int, 0>;
@@ -313,16 +313,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
     if (more) EVT_TILE_STORE(Ks[buf ^ 1], Vs[buf ^ 1]);
     __syncthreads();
   }
-  bf16_t* O = reinterpret_cast<bf16_t*>(p.out) + b * p.ob + h * p.oh;
+  h16_t* O = reinterpret_cast<h16_t*>(p.out) + b * p.ob + h * p.oh;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (qi[t] >= p.L) continue;
     const float inv = l[t] > 0.f ? p.keep_scale / l[t] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      bf16_t o4[4];
+      h16_t o4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = f2bf(ot[t][mt][r] * inv);
+      for (int r = 0; r < 4; ++r) o4[r] = f2h(ot[t][mt][r] * inv);
       *reinterpret_cast<uint2*>(O + qi[t] * p.ol + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
     if (g == 0) p.lse[((long)b * p.H + h) * p.L + qi[t]] = (m[t] * sc2 + __log2f(l[t])) * LN2;
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(AP p) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool JOINT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Ks[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Vs[2][64 * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   // 1-D grid, LONGEST BLOCKS FIRST: query block nqb-1 (walks every key) of all (b, h), then nqb-2, ... -- the short text
@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
   const int b = bh / p.H, h = bh % p.H;
   const int qblk = ((p.L + 127) / 128 - 1 - blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
-  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
-  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
-  const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
+  const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + b * p.sb + h * p.sh;
+  const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + b * p.sb + h * p.sh;
+  const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + b * p.sb + h * p.sh;
+  const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + b * p.ob + h * p.oh;
   const float sc2 = p.scale * LOG2E;
   const unsigned thr = p.drop_thr;
   const float inv_ks = 1.f / p.keep_scale;
-  bf16x8 qf[2], dof[2];
+  h16x8 qf[2], dof[2];
   f32x4 dqt[2][2];
   float lse2[2], dlk[2];
   int qi[2], qt0[2];
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
   for (int kb = 0; kb < kmax; kb += 64, buf ^= 1) {
     const bool more = kb + 64 < kmax;
     if (more) EVT_TILE_LOAD(K, p.sl, V, p.sl, kb + 64);
-    const bf16_t* Kc = Ks[buf];
-    const bf16_t* Vc = Vs[buf];
+    const h16_t* Kc = Ks[buf];
+    const h16_t* Vc = Vs[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int k0 = kb + sb * 32;
@@ -391,13 +391,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(qt0[t], qt0[t] + 15, k0, k0 + 31, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16x8 va0 = ld8(Vc + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 va1 = ld8(Vc + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* krow = Kc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-      const bf16x8 kt0 = tr2(krow, krow + 16 * PITCH);
-      const bf16x8 kt1 = tr2(krow + 16, krow + 16 * PITCH + 16);
+      const h16x8 ka0 = ld8(Kc + (sb * 32 + n) * PITCH + g * 8);
+      const h16x8 ka1 = ld8(Kc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const h16x8 va0 = ld8(Vc + (sb * 32 + n) * PITCH + g * 8);
+      const h16x8 va1 = ld8(Vc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const h16_t* krow = Kc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const h16x8 kt0 = tr2(krow, krow + 16 * PITCH);
+      const h16x8 kt1 = tr2(krow + 16, krow + 16 * PITCH + 16);
       const unsigned k0c = __umul24((unsigned)k0, DROP_KC);
       auto body = [&](auto masked_tag, auto t0_tag, auto t1_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -406,10 +406,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
         f32x4 s0[2], s1[2], d0[2], d1[2];
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          s0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t], z, 0, 0, 0);
-          s1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t], z, 0, 0, 0);
-          d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, dof[t], z, 0, 0, 0);
-          d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, dof[t], z, 0, 0, 0);
+          s0[t] = EVT_MFMA_16x16x32(ka0, qf[t], z, 0, 0, 0);
+          s1[t] = EVT_MFMA_16x16x32(ka1, qf[t], z, 0, 0, 0);
+          d0[t] = EVT_MFMA_16x16x32(va0, dof[t], z, 0, 0, 0);
+          d1[t] = EVT_MFMA_16x16x32(va1, dof[t], z, 0, 0, 0);
         }
         float ds[2][8];
 #pragma unroll
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
         }
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          const bf16x8 dsf = pack8(ds[t]);
-          dqt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt0, dsf, dqt[t][0], 0, 0, 0);
-          dqt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt1, dsf, dqt[t][1], 0, 0, 0);
+          const h16x8 dsf = pack8(ds[t]);
+          dqt[t][0] = EVT_MFMA_16x16x32(kt0, dsf, dqt[t][0], 0, 0, 0);
+          dqt[t][1] = EVT_MFMA_16x16x32(kt1, dsf, dqt[t][1], 0, 0, 0);
         }
       };
       using I0 = std::integral_constant<int, 0>;
@@ -461,16 +461,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
     if (more) EVT_TILE_STORE(Ks[buf ^ 1], Vs[buf ^ 1]);
     __syncthreads();
   }
-  bf16_t* dQ = reinterpret_cast<bf16_t*>(p.dq) + b * p.sb + h * p.sh;
+  h16_t* dQ = reinterpret_cast<h16_t*>(p.dq) + b * p.sb + h * p.sh;
   const float fin = p.scale * p.keep_scale;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (qi[t] >= p.L) continue;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      bf16_t o4[4];
+      h16_t o4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = f2bf(dqt[t][mt][r] * fin);
+      for (int r = 0; r < 4; ++r) o4[r] = f2h(dqt[t][mt][r] * fin);
       *reinterpret_cast<uint2*>(dQ + qi[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
   }
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(AP p) {
 // the same squeeze on forward / dQ (5 waves, 96 registers) spills inside the loop and loses 30 % / 145 %
 template <bool JOINT>
 __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[2][64 * PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t Os[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Qs[2][64 * PITCH];
+  __shared__ __attribute__((aligned(16))) h16_t Os[2][64 * PITCH];
   __shared__ __attribute__((aligned(16))) float lse_s[2][64];
   __shared__ __attribute__((aligned(16))) float dl_s[2][64];
   __shared__ __attribute__((aligned(16))) unsigned row_s[2][64];
@@ -497,14 +497,14 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
   const int b = bh / p.H, h = bh % p.H;
   const int kblk = (blockIdx.x / BH) * 128;
   const int xl = p.x_lens[b], yl = p.y_lens[b];
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sb + h * p.sh;
-  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + b * p.sb + h * p.sh;
-  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + b * p.sb + h * p.sh;
-  const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.ob + h * p.oh;
+  const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + b * p.sb + h * p.sh;
+  const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + b * p.sb + h * p.sh;
+  const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + b * p.sb + h * p.sh;
+  const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + b * p.ob + h * p.oh;
   const float sc2 = p.scale * LOG2E;
   const unsigned thr = p.drop_thr;
   const float inv_ks = 1.f / p.keep_scale;
-  bf16x8 kf[2], vf[2];
+  h16x8 kf[2], vf[2];
   f32x4 dkt[2][2], dvt[2][2];
   int kj[2], kt0[2];
 #pragma unroll
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
   for (int qb = q_begin; qb < p.L; qb += 64, buf ^= 1) {
     const bool more = qb + 64 < p.L;
     if (more) { EVT_TILE_LOAD(Q, p.sl, dO, p.ol, qb + 64); load_rows(qb + 64); }
-    const bf16_t* Qc = Qs[buf];
-    const bf16_t* Oc = Os[buf];
+    const h16_t* Qc = Qs[buf];
+    const h16_t* Oc = Os[buf];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       const int q0 = qb + sb * 32;
@@ -550,14 +550,14 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) cls[t] = classify(q0, q0 + 31, kt0[t], kt0[t] + 15, p.L, p.x_len, xl, yl);
       if (cls[0] == TILE_EMPTY && cls[1] == TILE_EMPTY) continue;
-      const bf16x8 qa0 = ld8(Qc + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 qa1 = ld8(Qc + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16x8 oa0 = ld8(Oc + (sb * 32 + n) * PITCH + g * 8);
-      const bf16x8 oa1 = ld8(Oc + (sb * 32 + 16 + n) * PITCH + g * 8);
-      const bf16_t* qrow = Qc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-      const bf16_t* orow = Oc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-      const bf16x8 qt0 = tr2(qrow, qrow + 16 * PITCH), qt1 = tr2(qrow + 16, qrow + 16 * PITCH + 16);
-      const bf16x8 dt0 = tr2(orow, orow + 16 * PITCH), dt1 = tr2(orow + 16, orow + 16 * PITCH + 16);
+      const h16x8 qa0 = ld8(Qc + (sb * 32 + n) * PITCH + g * 8);
+      const h16x8 qa1 = ld8(Qc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const h16x8 oa0 = ld8(Oc + (sb * 32 + n) * PITCH + g * 8);
+      const h16x8 oa1 = ld8(Oc + (sb * 32 + 16 + n) * PITCH + g * 8);
+      const h16_t* qrow = Qc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const h16_t* orow = Oc + (sb * 32 + g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+      const h16x8 qt0 = tr2(qrow, qrow + 16 * PITCH), qt1 = tr2(qrow + 16, qrow + 16 * PITCH + 16);
+      const h16x8 dt0 = tr2(orow, orow + 16 * PITCH), dt1 = tr2(orow + 16, orow + 16 * PITCH + 16);
       float lq[8], dq8[8];
       unsigned hh[8];
       {
@@ -582,10 +582,10 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
         f32x4 s0[2], s1[2], d0[2], d1[2];
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          s0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[t], z, 0, 0, 0);
-          s1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[t], z, 0, 0, 0);
-          d0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa0, vf[t], z, 0, 0, 0);
-          d1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa1, vf[t], z, 0, 0, 0);
+          s0[t] = EVT_MFMA_16x16x32(qa0, kf[t], z, 0, 0, 0);
+          s1[t] = EVT_MFMA_16x16x32(qa1, kf[t], z, 0, 0, 0);
+          d0[t] = EVT_MFMA_16x16x32(oa0, vf[t], z, 0, 0, 0);
+          d1[t] = EVT_MFMA_16x16x32(oa1, vf[t], z, 0, 0, 0);
         }
         float pr[2][8], ds[2][8];
 #pragma unroll
@@ -610,11 +610,11 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
         }
 #pragma unroll
         for (int t = T0; t < T1; ++t) {
-          const bf16x8 pf = pack8(pr[t]), dsf = pack8(ds[t]);
-          dvt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pf, dvt[t][0], 0, 0, 0);
-          dvt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt1, pf, dvt[t][1], 0, 0, 0);
-          dkt[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsf, dkt[t][0], 0, 0, 0);
-          dkt[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt1, dsf, dkt[t][1], 0, 0, 0);
+          const h16x8 pf = pack8(pr[t]), dsf = pack8(ds[t]);
+          dvt[t][0] = EVT_MFMA_16x16x32(dt0, pf, dvt[t][0], 0, 0, 0);
+          dvt[t][1] = EVT_MFMA_16x16x32(dt1, pf, dvt[t][1], 0, 0, 0);
+          dkt[t][0] = EVT_MFMA_16x16x32(qt0, dsf, dkt[t][0], 0, 0, 0);
+          dkt[t][1] = EVT_MFMA_16x16x32(qt1, dsf, dkt[t][1], 0, 0, 0);
         }
       };
       using I0 = std::integral_constant<int, 0>;
@@ -633,17 +633,17 @@ __global__ __launch_bounds__(256, JOINT ? 2 : 3) void attn_bwd_dkv_bf16(AP p) {
     if (more) { EVT_TILE_STORE(Qs[buf ^ 1], Os[buf ^ 1]); store_rows(buf ^ 1); }
     __syncthreads();
   }
-  bf16_t* dK = reinterpret_cast<bf16_t*>(p.dk) + b * p.sb + h * p.sh;
-  bf16_t* dV = reinterpret_cast<bf16_t*>(p.dv) + b * p.sb + h * p.sh;
+  h16_t* dK = reinterpret_cast<h16_t*>(p.dk) + b * p.sb + h * p.sh;
+  h16_t* dV = reinterpret_cast<h16_t*>(p.dv) + b * p.sb + h * p.sh;
   const float fk = p.scale * p.keep_scale, fv = p.keep_scale;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (kj[t] >= p.L) continue;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      bf16_t a4[4], b4[4];
+      h16_t a4[4], b4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a4[r] = f2bf(dkt[t][mt][r] * fk); b4[r] = f2bf(dvt[t][mt][r] * fv); }
+      for (int r = 0; r < 4; ++r) { a4[r] = f2h(dkt[t][mt][r] * fk); b4[r] = f2h(dvt[t][mt][r] * fv); }
       *reinterpret_cast<uint2*>(dK + kj[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(a4);
       *reinterpret_cast<uint2*>(dV + kj[t] * p.sl + mt * 16 + g * 4) = *reinterpret_cast<uint2*>(b4);
     }
@@ -799,7 +799,7 @@ int g_attn_joint = getenv("EVT_ATTN_JOINT") ? atoi(getenv("EVT_ATTN_JOINT")) : 0
 
 int check(const evt_attn_params* a) {
   if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return EVT_EINVAL;
-  if (a->dtype == EVT_DT_BF16) {
+  if (a->dtype == EVT_DT_HALF) {
     if (a->D != 32) return EVT_ENOTSUP;
     if (a->q_stride_l % 8 || a->q_stride_h % 8 || a->q_stride_b % 8 || a->o_stride_l % 8 || a->o_stride_h % 8 ||
         a->o_stride_b % 8)
@@ -843,7 +843,7 @@ int evt_attn_prefixlm_fwd(const evt_attn_params* a, const void* q, const void* k
   AP p = make_ap(a);
   p.q = q; p.k = k; p.v = v; p.out = o; p.lse = lse; p.x_lens = x_lens; p.y_lens = y_lens;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == EVT_DT_BF16) {
+  if (a->dtype == EVT_DT_HALF) {
     if (g_attn_joint) hipLaunchKernelGGL(attn_fwd_bf16<true>, dim3(((a->L + 127) / 128) * a->B * a->H), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_bf16<false>, dim3(((a->L + 127) / 128) * a->B * a->H), dim3(256), 0, st, p);
   } else {
@@ -866,10 +866,10 @@ int evt_attn_prefixlm_bwd(const evt_attn_params* a, const void* q, const void* k
   p.dq = dq; p.dk = dk; p.dv = dv; p.x_lens = x_lens; p.y_lens = y_lens;
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)a->B * a->H * a->L;
-  const int lpr = a->D / (a->dtype == EVT_DT_BF16 ? 8 : 4);
+  const int lpr = a->D / (a->dtype == EVT_DT_HALF ? 8 : 4);
   const int dblocks = (int)((total * lpr + 255) / 256);
-  if (a->dtype == EVT_DT_BF16) {
-    hipLaunchKernelGGL(attn_delta<bf16_t>, dim3(dblocks), dim3(256), 0, st, p, a->D);
+  if (a->dtype == EVT_DT_HALF) {
+    hipLaunchKernelGGL(attn_delta<h16_t>, dim3(dblocks), dim3(256), 0, st, p, a->D);
     const dim3 grid(((a->L + 127) / 128) * a->B * a->H);
     if (g_attn_joint) {
       hipLaunchKernelGGL(attn_bwd_dkv_bf16<true>, grid, dim3(256), 0, st, p);

@@ -56,11 +56,11 @@ template <> struct Frag<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
 };
-template <> struct Frag<bf16_t> {
+template <> struct Frag<h16_t> {
   static constexpr int EPL = 8, KS = 32;
-  typedef bf16x8 type;
-  static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  typedef h16x8 type;
+  static __device__ __forceinline__ f32x4 mma(h16x8 a, h16x8 b, f32x4 c) {
+    return EVT_MFMA_16x16x32(a, b, c, 0, 0, 0);
   }
 };
 
@@ -398,7 +398,7 @@ using evt_conv::WgP;
 
 template <typename T> union FragBuf;
 template <> union FragBuf<float> { float v; float e[1]; };
-template <> union FragBuf<bf16_t> { bf16x8 v; bf16_t e[8]; };
+template <> union FragBuf<h16_t> { h16x8 v; h16_t e[8]; };
 
 template <typename T>
 __device__ __forceinline__ T fuse_elem(T v, bool has_act, T va, int kind, float aslope, float slope) {
@@ -528,21 +528,21 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
 //   * for TA < 64 output-channel tiles the spare waves split the positions instead of idling;
 //   * dbias (column sums of dy_eff) is accumulated from the staged A tile by the (chunk 0, tap group 0) blocks.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 lds_tr2(const bf16_t* p0, const bf16_t* p1) {
+__device__ __forceinline__ h16x8 lds_tr2(const h16_t* p0, const h16_t* p1) {
   const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1;
   uint2 lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(lo), "=&v"(hi)
                : "v"(a0), "v"(a1)
                : "memory");
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return r.v;
 }
 
 // four fragments (eight transpose reads) behind ONE wait: the MFMAs that consume them then issue back to back
-__device__ __forceinline__ void lds_tr2x4(const bf16_t* p0, const bf16_t* p1, const bf16_t* p2, const bf16_t* p3, int hi_off,
-                                          bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+__device__ __forceinline__ void lds_tr2x4(const h16_t* p0, const h16_t* p1, const h16_t* p2, const h16_t* p3, int hi_off,
+                                          h16x8& f0, h16x8& f1, h16x8& f2, h16x8& f3) {
   const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1, a2 = (unsigned)(uintptr_t)p2,
                  a3 = (unsigned)(uintptr_t)p3;
   const unsigned b0 = a0 + hi_off, b1 = a1 + hi_off, b2 = a2 + hi_off, b3 = a3 + hi_off;
@@ -555,7 +555,7 @@ __device__ __forceinline__ void lds_tr2x4(const bf16_t* p0, const bf16_t* p1, co
       : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
       : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
       : "memory");
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(l0.x, l0.y, h0.x, h0.y); f0 = r.v;
   r.u = make_uint4(l1.x, l1.y, h1.x, h1.y); f1 = r.v;
   r.u = make_uint4(l2.x, l2.y, h2.x, h2.y); f2 = r.v;
@@ -564,7 +564,7 @@ __device__ __forceinline__ void lds_tr2x4(const bf16_t* p0, const bf16_t* p1, co
 
 template <int CK, int TA>
 __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int KT = 4;
   constexpr int NCT = TA / 16;   // waves along the A channels
   constexpr int NPS = 4 / NCT;   // waves along the positions
@@ -636,24 +636,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(WgP p) {
     }
     __syncthreads();
     if (do_bias)
-      for (int r = brow; r < PK; r += 256 / TA) bsum += bf2f(As[r * PA + bcol]);
+      for (int r = brow; r < PK; r += 256 / TA) bsum += h2f(As[r * PA + bcol]);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kb = ps * 64 + ks * 32 + g8 * 8;  // first of this lane group's 8 positions
       const T* pa = As + (kb + (j16 >> 2)) * PA + ct * 16 + 4 * (j16 & 3);
-      const bf16x8 a = lds_tr2(pa, pa + 4 * PA);
+      const h16x8 a = lds_tr2(pa, pa + 4 * PA);
       // taps beyond ntap read rows that are staged (the B tile always covers KT taps) and are simply not accumulated
       const T* pb0 = Bs + ((kb + (j16 >> 2)) * p.s) * PB + 4 * (j16 & 3);
       const int hi = 4 * p.s * PB * (int)sizeof(T);
 #pragma unroll
       for (int j = 0; j < NTB; ++j) {
-        bf16x8 b0, b1, b2, b3;
+        h16x8 b0, b1, b2, b3;
         lds_tr2x4(pb0 + j * 16, pb0 + p.dil * PB + j * 16, pb0 + 2 * p.dil * PB + j * 16,
                   pb0 + 3 * p.dil * PB + j * 16, hi, b0, b1, b2, b3);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0][j], 0, 0, 0);
-        if (ntap > 1) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1][j], 0, 0, 0);
-        if (ntap > 2) acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[2][j], 0, 0, 0);
-        if (ntap > 3) acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b3, acc[3][j], 0, 0, 0);
+        acc[0][j] = EVT_MFMA_16x16x32(a, b0, acc[0][j], 0, 0, 0);
+        if (ntap > 1) acc[1][j] = EVT_MFMA_16x16x32(a, b1, acc[1][j], 0, 0, 0);
+        if (ntap > 2) acc[2][j] = EVT_MFMA_16x16x32(a, b2, acc[2][j], 0, 0, 0);
+        if (ntap > 3) acc[3][j] = EVT_MFMA_16x16x32(a, b3, acc[3][j], 0, 0, 0);
       }
     }
   }
@@ -936,7 +936,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline void pick_ck(int dtype, int b, int k, int stride_unused, int* ck, int* nchunk, int* kp) {
   (void)stride_unused;
   if (b % 32 == 0) { *ck = 32; *nchunk = b / 32; *kp = k; }
-  else if (b % 16 == 0) { *ck = 16; *nchunk = b / 16; *kp = (dtype == EVT_DT_BF16) ? ((k + 1) & ~1) : k; }
+  else if (b % 16 == 0) { *ck = 16; *nchunk = b / 16; *kp = (dtype == EVT_DT_HALF) ? ((k + 1) & ~1) : k; }
   else { *ck = b; *nchunk = 1; *kp = k; }
 }
 
@@ -1014,7 +1014,7 @@ int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st, b
   p.Y = A / (16 * MT);
   // Short sequences (a 64-position unit would be mostly padding): 16-position units from any sequence, NT per wave.
   // Long sequences: the largest contiguous unit that still gives the chip ~2 blocks per CU.
-  const bool split = p.Q < 56 && dtype == EVT_DT_BF16;
+  const bool split = p.Q < 56 && dtype == EVT_DT_HALF;
   int NT = 4;
   if (split) {
     const long units16 = (long)p.nseq * ceil_div(p.Q, 16);
@@ -1034,8 +1034,8 @@ int launch_igemm(int dtype, ConvP p, int A, int B, int nphase, hipStream_t st, b
     const long units = (long)p.nseq * p.U;
     p.P = (int)((units + (sp ? 4 * NT : 4) - 1) / (sp ? 4 * NT : 4));
     int rc;
-    if (dtype == EVT_DT_BF16)
-      rc = (CK == 32) ? launch_igemm_mt<bf16_t, 32>(p, MT, NT, nphase, sp, st) : launch_igemm_mt<bf16_t, 16>(p, MT, NT, nphase, sp, st);
+    if (dtype == EVT_DT_HALF)
+      rc = (CK == 32) ? launch_igemm_mt<h16_t, 32>(p, MT, NT, nphase, sp, st) : launch_igemm_mt<h16_t, 16>(p, MT, NT, nphase, sp, st);
     else
       rc = (CK == 32) ? launch_igemm_mt<float, 32>(p, MT, NT, nphase, sp, st) : launch_igemm_mt<float, 16>(p, MT, NT, nphase, sp, st);
     if (rc != EVT_ENOTSUP || NT == 1) return rc;  // ENOTSUP here = LDS too large: shrink the unit
@@ -1142,7 +1142,7 @@ int launch_wgrad(int dtype, WgP p, hipStream_t st) {
   if (split < 1) split = 1;
   if (split > 65535) split = 65535;
   p.nsplit = (int)split;
-  if (dtype == EVT_DT_BF16) return CK == 32 ? launch_wgrad_inst<bf16_t, 32>(p, st) : launch_wgrad_inst<bf16_t, 16>(p, st);
+  if (dtype == EVT_DT_HALF) return CK == 32 ? launch_wgrad_inst<h16_t, 32>(p, st) : launch_wgrad_inst<h16_t, 16>(p, st);
   return CK == 32 ? launch_wgrad_inst<float, 32>(p, st) : launch_wgrad_inst<float, 16>(p, st);
 }
 
@@ -1168,7 +1168,7 @@ int valid(const evt_conv1d_params* c) {
   if (!c || c->nseq <= 0 || c->lin <= 0 || c->cin <= 0 || c->cout <= 0 || c->k <= 0 || c->stride <= 0 ||
       c->dil <= 0 || c->groups <= 0 || c->pad < 0)
     return EVT_EINVAL;
-  if (c->dtype != EVT_DT_F32 && c->dtype != EVT_DT_BF16) return EVT_EINVAL;
+  if (c->dtype != EVT_DT_F32 && c->dtype != EVT_DT_HALF) return EVT_EINVAL;
   if (c->cin % c->groups || c->cout % c->groups) return EVT_EINVAL;
   if (c->transposed && (c->groups != 1 || c->dil != 1)) return EVT_ENOTSUP;
   if (evt_conv1d_lout(c) <= 0) return EVT_EINVAL;
@@ -1186,7 +1186,7 @@ int32_t evt_conv1d_lout(const evt_conv1d_params* c) {
 
 int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c) {
   if (!c || valid(c) != EVT_OK) return 0;
-  if (c->impl != EVT_IMPL_AUTO || c->dtype != EVT_DT_BF16 || c->transposed || !igemm_ok(c)) return 0;
+  if (c->impl != EVT_IMPL_AUTO || c->dtype != EVT_DT_HALF || c->transposed || !igemm_ok(c)) return 0;
   if (c->out_act == EVT_ACT_NONE || c->in_slope != 1.f) return 0;
   // same descriptor geometry evt_conv1d_bwd_data builds (K side = cout, output channels = cin)
   ConvP p{};
@@ -1264,7 +1264,7 @@ int evt_conv1d_fwd(const evt_conv1d_params* c, const void* x, const void* w_reg,
     p.x = x; p.w = w_reg; p.bias = bias; p.res = res; p.y = y;
     const long total = (long)c->nseq * lout * c->cout;
     const int blocks = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
-    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(conv_naive_fwd<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+    if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(conv_naive_fwd<h16_t>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_naive_fwd<float>, dim3(blocks), dim3(256), 0, st, p);
     return evt_check_launch();
   }
@@ -1330,7 +1330,7 @@ int evt_conv1d_bwd_data(const evt_conv1d_params* c, const void* dy, const void* 
     p.x = dy; p.y_in = ysv; p.w = w_reg; p.gate = gate; p.res = dx_add; p.y = dx;
     const long total = (long)c->nseq * c->lin * c->cin;
     const int blocks = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
-    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(conv_naive_bwd_data<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+    if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(conv_naive_bwd_data<h16_t>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_naive_bwd_data<float>, dim3(blocks), dim3(256), 0, st, p);
     return evt_check_launch();
   }
@@ -1417,12 +1417,12 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
   const bool ring_w = !deep_w && !halo_w && igemm_path && c->impl == EVT_IMPL_AUTO && evt_conv::wgrad_ring_eligible(p, c->dtype);
   // dbias is fused into the bf16 MFMA weight-gradient kernel when its A operand is dy (plain Conv1d)
   const bool cin1 = !grouped && c->impl != EVT_IMPL_NAIVE && evt_small_kind(c) == 2;   // fuses dbias as well
-  const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_BF16 && !c->transposed) || cin1);
+  const bool fuse_bias = dbias && ((igemm_path && c->dtype == EVT_DT_HALF && !c->transposed) || cin1);
   float* ws = sp ? sp->ws : nullptr;
   const long ws_floats = sp ? (long)sp->ws_floats : 0;
   if (dbias && !fuse_bias) {
     const long rows = (long)c->nseq * lout;
-    const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+    const int V = c->dtype == EVT_DT_HALF ? 8 : 4;
     int blocks;
     float* wsb = nullptr;
     if (c->cout % V == 0 && c->cout / V <= 256) {
@@ -1430,8 +1430,8 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
       if (rpb < 16) rpb = 16;
       blocks = (int)((rows + rpb - 1) / rpb);
       if (ws && blocks >= 2 && (long)blocks * c->cout <= ws_floats) wsb = ws;
-      if (c->dtype == EVT_DT_BF16)
-        hipLaunchKernelGGL(colsum_act2<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
+      if (c->dtype == EVT_DT_HALF)
+        hipLaunchKernelGGL(colsum_act2<h16_t>, dim3(blocks), dim3(256), 0, st, (const h16_t*)dy, (const h16_t*)ysv,
                            dbias, rows, c->cout, c->out_act, c->out_slope, (int)rpb, wsb);
       else
         hipLaunchKernelGGL(colsum_act2<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
@@ -1440,8 +1440,8 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
       const int rpb = 64;
       blocks = (int)((rows + rpb - 1) / rpb);
       if (ws && blocks >= 2 && (long)blocks * c->cout <= ws_floats) wsb = ws;
-      if (c->dtype == EVT_DT_BF16)
-        hipLaunchKernelGGL(colsum_act<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)ysv,
+      if (c->dtype == EVT_DT_HALF)
+        hipLaunchKernelGGL(colsum_act<h16_t>, dim3(blocks), dim3(256), 0, st, (const h16_t*)dy, (const h16_t*)ysv,
                            dbias, rows, c->cout, c->out_act, c->out_slope, rpb, wsb);
       else
         hipLaunchKernelGGL(colsum_act<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ysv,
@@ -1475,8 +1475,8 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
     if (split > maxsplit) split = maxsplit;
     if (split < 1) split = 1;
     p.nsplit = (int)split;
-    if (c->dtype == EVT_DT_BF16)
-      hipLaunchKernelGGL(conv_naive_bwd_weight<bf16_t>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
+    if (c->dtype == EVT_DT_HALF)
+      hipLaunchKernelGGL(conv_naive_bwd_weight<h16_t>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
     else
       hipLaunchKernelGGL(conv_naive_bwd_weight<float>, dim3((unsigned)elems, p.nsplit), dim3(256), 0, st, p);
     return evt_check_launch();
@@ -1493,7 +1493,7 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
     if (sp) sp->used = used_host;
     return rc;
   }
-  if (c->dtype == EVT_DT_BF16) {
+  if (c->dtype == EVT_DT_HALF) {
     p.dbias = fuse_bias ? dbias : nullptr;
     p.ws = ws; p.ws_floats = ws_floats;
     if (p.parts < 2) p.parts = 0;                  // one slab = no split possible: scratch rows (or atomics) instead
@@ -1503,8 +1503,8 @@ int evt_conv1d_bwd_weight_parts(const evt_conv1d_params* c, const void* x, const
     p.parts = 0;
     if (fuse_bias) {  // tile did not fit: the gather kernel has no fused bias
       const long rows = (long)c->nseq * lout;
-      hipLaunchKernelGGL(colsum_act<bf16_t>, dim3((int)((rows + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,
-                         (const bf16_t*)ysv, dbias, rows, c->cout, c->out_act, c->out_slope, 64, (float*)nullptr);
+      hipLaunchKernelGGL(colsum_act<h16_t>, dim3((int)((rows + 63) / 64)), dim3(256), 0, st, (const h16_t*)dy,
+                         (const h16_t*)ysv, dbias, rows, c->cout, c->out_act, c->out_slope, 64, (float*)nullptr);
       rc = evt_check_launch();
       if (rc) return rc;
     }

@@ -59,21 +59,21 @@ __device__ __forceinline__ void store_tile_staged(const ConvP& p, unsigned char*
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int cl = wr * 16 * MI + i * 16 + g * 4;
-      bf16_t outv[4];
+      h16_t outv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[i][r];
         if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
         else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
-        outv[r] = f2bf(v);
+        outv[r] = f2h(v);
       }
       *reinterpret_cast<uint2*>(smem + pl * PITCH + cl * 2) = *reinterpret_cast<uint2*>(outv);
     }
   }
   __syncthreads();
-  bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.gate);
+  h16_t* Y = reinterpret_cast<h16_t*>(p.y);
+  const h16_t* R = reinterpret_cast<const h16_t*>(p.res);
+  const h16_t* G = reinterpret_cast<const h16_t*>(p.gate);
   const int tid = threadIdx.x;
   const int c16 = tid % CPR, r0 = tid / CPR;
 #pragma unroll
@@ -91,15 +91,15 @@ __device__ __forceinline__ void store_tile_staged(const ConvP& p, unsigned char*
       uint4 gv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
       if (G) gv = *reinterpret_cast<const uint4*>(G + off);
       if (R) rv = *reinterpret_cast<const uint4*>(R + off);
-      bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
-      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rv);
+      h16_t* vp = reinterpret_cast<h16_t*>(&v);
+      const h16_t* gp = reinterpret_cast<const h16_t*>(&gv);
+      const h16_t* rp = reinterpret_cast<const h16_t*>(&rv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float f = bf2f(vp[e]);
-        if (G) f *= (bf2f(gp[e]) > 0.f ? 1.f : p.gate_slope);
-        if (R) f += bf2f(rp[e]);
-        vp[e] = f2bf(f);
+        float f = h2f(vp[e]);
+        if (G) f *= (h2f(gp[e]) > 0.f ? 1.f : p.gate_slope);
+        if (R) f += h2f(rp[e]);
+        vp[e] = f2h(f);
       }
     }
     *reinterpret_cast<uint4*>(Y + off) = v;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
   if (pb >= p.P) return;
   const int phase = blockIdx.y;
 
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const h16_t* X = reinterpret_cast<const h16_t*>(p.x);
+  const h16_t* W = reinterpret_cast<const h16_t*>(p.w) + (long)phase * p.w_phase_stride;
   const int total_units = p.nseq * p.Q;
 
   // ---- per-lane DMA sources: wave w stages rows [32w, 32w+32) of both tiles, 8 rows per instruction ----
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
     brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
     boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
   }
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page) + pslot * 8;
   unsigned char* my_a = smem + wave * 32 * 128;              // + buf*STAGE_BYTES + i*1024
   unsigned char* my_b = smem + BM * 128 + wave * 32 * 128;
 
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool ok = (unsigned)(brow[i] + rshift) < (unsigned)p.Lin;
-      const bf16_t* src = ok ? X + boff[i] + xsoff : zsrc;
+      const h16_t* src = ok ? X + boff[i] + xsoff : zsrc;
       glds16(src, my_b + buf * STAGE_BYTES + i * 1024);
     }
   };
@@ -190,15 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv_deep(ConvP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int so = ks ? so1 : so0;
-      bf16x8 a[4], b[4];
+      h16x8 a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + so);
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const h16x8*>(sa + i * 16 * 128 + so);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + so);
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const h16x8*>(sb + j * 16 * 128 + so);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = EVT_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
   const int pb = xcd + 8 * (slot / p.Y);
   if (pb >= p.P) return;
   const int phase = blockIdx.y;
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const h16_t* X = reinterpret_cast<const h16_t*>(p.x);
+  const h16_t* W = reinterpret_cast<const h16_t*>(p.w) + (long)phase * p.w_phase_stride;
   const int total_units = p.nseq * p.Q;
 
   // wave w stages rows [32w, 32w+32) of both tiles, 16 rows x 4 slots per instruction
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
     brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
     boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
   }
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page) + pslot * 8;
   unsigned char* my_a = smem + wave * 32 * 64;
   unsigned char* my_b = smem + BM * 64 + wave * 32 * 64;
   const int nst = p.nchunk * p.KHp;
@@ -281,15 +281,15 @@ __global__ __launch_bounds__(256, 4) void conv_deep32(ConvP p) {
     if (st + 1 < nst) issue(st + 1, buf ^ 1);
     const unsigned char* sa = smem + buf * STAGE32 + a_base;
     const unsigned char* sb = smem + buf * STAGE32 + b_base;
-    bf16x8 a[4], b[4];
+    h16x8 a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const h16x8*>(sa + i * 16 * 64);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const h16x8*>(sb + j * 16 * 64);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = EVT_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 
   store_tile_staged<BM, BN, 4, 4>(p, smem, acc, wr, wc, n, g, yi, pb, phase, total_units);
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
   if (pb >= p.P) return;
   const int phase = blockIdx.y;
 
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w) + (long)phase * p.w_phase_stride;
+  const h16_t* X = reinterpret_cast<const h16_t*>(p.x);
+  const h16_t* W = reinterpret_cast<const h16_t*>(p.w) + (long)phase * p.w_phase_stride;
   const int total_units = p.nseq * p.Q;
 
   // wave w stages rows [w*RM/4, (w+1)*RM/4) of A and [w*RN/4, ...) of B, 8 rows per instruction
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
     brow[i] = ok ? q * p.s_in + p.off_in : -(1 << 28);
     boff[i] = ((long)seq * p.Lin + brow[i]) * p.Cin + c * 8;
   }
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + pslot * 8;
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page) + pslot * 8;
   unsigned char* my_a = smem + wave * (RM / 4) * 128;
   unsigned char* my_b = smem + RM * 128 + wave * (RN / 4) * 128;
   const int nst = (p.nchunk >> 1) * p.KHp;
@@ -404,15 +404,15 @@ __global__ __launch_bounds__(256, 2) void conv_ring(ConvP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int so = ks ? so1 : so0;
-      bf16x8 a[MT], b[NT];
+      h16x8 a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + so);
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const h16x8*>(sa + i * 16 * 128 + so);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + so);
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const h16x8*>(sb + j * 16 * 128 + so);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = EVT_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("" ::: "memory");
   }
@@ -443,7 +443,7 @@ constexpr int WSTAGE = WA_BYTES + WKT * WB_BYTES;        // 36 KiB
 // All 18 transpose reads of one K = 32 step (4 A tiles, 5 tap tiles, low + high halves) behind ONE wait; the row /
 // tap / k-step displacements are instruction offsets, so the step needs five address registers.
 template <int KS>
-__device__ __forceinline__ void tr_load_step(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[WKT]) {
+__device__ __forceinline__ void tr_load_step(const unsigned (&aa)[4], unsigned ba, h16x8 (&a)[4], h16x8 (&b)[WKT]) {
   uint2 al[4], ah[4], bl[WKT], bh[WKT];
   if constexpr (KS == 0) {
     asm volatile(
@@ -498,7 +498,7 @@ __device__ __forceinline__ void tr_load_step(const unsigned (&aa)[4], unsigned b
         : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
         : "memory");
   }
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
   const int ntap = min(WKT, p.KHp - t0);
   const int a0 = atile * 128;
 
-  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const h16_t* Ag = reinterpret_cast<const h16_t*>(p.A);
+  const h16_t* Bg = reinterpret_cast<const h16_t*>(p.B);
   const int total_units = p.nseq * p.Q;
   const int nstages = (total_units + WPOS - 1) / WPOS;
   const int st_begin = blockIdx.y * stages_per_split;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 
   // ---- DMA roles: wave w stages rows [16w, 16w+16) of every tile ----
   // A: 4 instructions of 4 rows x 16 slots;  B: one instruction per tap, 16 rows x 4 slots
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page);
   int arow[4], acol[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = u0 + arow[i];
-      const bf16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
+      const h16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
       glds16(src, base + wave * 4096 + i * 1024);
     }
     const int u = u0 + brow;
@@ -573,12 +573,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
     const int seq = uok ? u / p.Q : 0;
     const int q = u - seq * p.Q;
     const int r0 = q * p.s + t0 * p.dil + p.off;
-    const bf16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
+    const h16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
 #pragma unroll
     for (int t = 0; t < WKT; ++t) {
       const int r = r0 + t * p.dil;
       const bool ok = uok && (unsigned)r < (unsigned)p.LB;
-      const bf16_t* src = ok ? rsrc + (long)t * p.dil * p.CB : zsrc;
+      const h16_t* src = ok ? rsrc + (long)t * p.dil * p.CB : zsrc;
       glds16(src, base + WA_BYTES + t * WB_BYTES + wave * 1024);
     }
   };
@@ -615,20 +615,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_deep(WgP p, int stages_per_split
 #pragma unroll
     for (int i = 0; i < 4; ++i) aa[i] = sbase + a_off[i];
     const unsigned ba = sbase + b_off;
-    bf16x8 a[4], b[WKT];
+    h16x8 a[4], b[WKT];
     tr_load_step<0>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < WKT; ++t)
       if (t < ntap)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
     if (do_bias) wg_bias_mma<4>(bacc, a, wc);
     tr_load_step<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < WKT; ++t)
       if (t < ntap)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
     if (do_bias) wg_bias_mma<4>(bacc, a, wc);
   }
   if (do_bias) wg_finish_bias_mma<4>(p, bacc, a0, wr, wc, g8, j16, blockIdx.y);
@@ -649,7 +649,7 @@ constexpr int GKT = 4;                                   // 32-channel chunks of
 constexpr int GSTAGE = WA_BYTES + GKT * WB_BYTES;        // 32 KiB
 
 template <int KS>
-__device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[GKT]) {
+__device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned ba, h16x8 (&a)[4], h16x8 (&b)[GKT]) {
   uint2 al[4], ah[4], bl[GKT], bh[GKT];
   if constexpr (KS == 0) {
     asm volatile(
@@ -698,7 +698,7 @@ __device__ __forceinline__ void tr_load_step_g(const unsigned (&aa)[4], unsigned
         : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
         : "memory");
   }
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -730,8 +730,8 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
   const int atile = tile / ngrp;
   const int a0 = atile * 128;
 
-  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const h16_t* Ag = reinterpret_cast<const h16_t*>(p.A);
+  const h16_t* Bg = reinterpret_cast<const h16_t*>(p.B);
   const int total_units = p.nseq * p.Q;
   const int nstages = (total_units + WPOS - 1) / WPOS;
   const int st_begin = split * stages_per_split;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
   if (st_begin >= st_end) return;
 
   // DMA roles as in wgrad_deep: wave w stages rows [16w, 16w+16) of every tile
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page);
   int arow[4], acol[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -756,12 +756,12 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = u0 + arow[i];
-      const bf16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
+      const h16_t* src = u < total_units ? Ag + (long)u * p.CA + acol[i] : zsrc;
       glds16(src, base + wave * 4096 + i * 1024);
     }
     const int u = u0 + brow;
     const bool uok = u < total_units;
-    const bf16_t* rsrc = Bg + (long)(uok ? u : 0) * p.CB + bcol;
+    const h16_t* rsrc = Bg + (long)(uok ? u : 0) * p.CB + bcol;
 #pragma unroll
     for (int t = 0; t < GKT; ++t) glds16(uok ? rsrc + t * 32 : zsrc, base + WA_BYTES + t * WB_BYTES + wave * 1024);
   };
@@ -779,9 +779,9 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
   bool mine[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) mine[i] = do_bias && (i % bgrp) == cg;
-  bf16x8 ones;
+  h16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = (evt_hn)1.0f;
   f32x4 bacc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -814,23 +814,23 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
 #pragma unroll
     for (int i = 0; i < 4; ++i) aa[i] = sbase + a_off[i];
     const unsigned ba = sbase + b_off;
-    bf16x8 a[4], b[GKT];
+    h16x8 a[4], b[GKT];
     tr_load_step_g<0>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < GKT; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (mine[i]) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
+      if (mine[i]) bacc[i] = EVT_MFMA_16x16x32(a[i], ones, bacc[i], 0, 0, 0);
     tr_load_step_g<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < GKT; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (mine[i]) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
+      if (mine[i]) bacc[i] = EVT_MFMA_16x16x32(a[i], ones, bacc[i], 0, 0, 0);
     asm volatile("" ::: "memory");
   }
   if (do_bias && j16 == 0) {
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
 template <int MA, int KT> struct TrStep;
 template <> struct TrStep<2, 1> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[1]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, h16x8 (&a)[2], h16x8 (&b)[1]) {
     uint2 al[2], ah[2], bl[1], bh[1];
     if constexpr (KS == 0) {
     asm volatile(
@@ -893,7 +893,7 @@ template <> struct TrStep<2, 1> {
         : "v"(aa[0]), "v"(aa[1]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -902,7 +902,7 @@ template <> struct TrStep<2, 1> {
 };
 template <> struct TrStep<2, 3> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[3]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, h16x8 (&a)[2], h16x8 (&b)[3]) {
     uint2 al[2], ah[2], bl[3], bh[3];
     if constexpr (KS == 0) {
     asm volatile(
@@ -937,7 +937,7 @@ template <> struct TrStep<2, 3> {
         : "v"(aa[0]), "v"(aa[1]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -946,7 +946,7 @@ template <> struct TrStep<2, 3> {
 };
 template <> struct TrStep<2, 5> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, bf16x8 (&a)[2], bf16x8 (&b)[5]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[2], unsigned ba, h16x8 (&a)[2], h16x8 (&b)[5]) {
     uint2 al[2], ah[2], bl[5], bh[5];
     if constexpr (KS == 0) {
     asm volatile(
@@ -989,7 +989,7 @@ template <> struct TrStep<2, 5> {
         : "v"(aa[0]), "v"(aa[1]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -998,7 +998,7 @@ template <> struct TrStep<2, 5> {
 };
 template <> struct TrStep<4, 1> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[1]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, h16x8 (&a)[4], h16x8 (&b)[1]) {
     uint2 al[4], ah[4], bl[1], bh[1];
     if constexpr (KS == 0) {
     asm volatile(
@@ -1033,7 +1033,7 @@ template <> struct TrStep<4, 1> {
         : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -1042,7 +1042,7 @@ template <> struct TrStep<4, 1> {
 };
 template <> struct TrStep<4, 3> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[3]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, h16x8 (&a)[4], h16x8 (&b)[3]) {
     uint2 al[4], ah[4], bl[3], bh[3];
     if constexpr (KS == 0) {
     asm volatile(
@@ -1085,7 +1085,7 @@ template <> struct TrStep<4, 3> {
         : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -1094,7 +1094,7 @@ template <> struct TrStep<4, 3> {
 };
 template <> struct TrStep<4, 5> {
   template <int KS>
-  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, bf16x8 (&a)[4], bf16x8 (&b)[5]) {
+  static __device__ __forceinline__ void load(const unsigned (&aa)[4], unsigned ba, h16x8 (&a)[4], h16x8 (&b)[5]) {
     uint2 al[4], ah[4], bl[5], bh[5];
     if constexpr (KS == 0) {
     asm volatile(
@@ -1145,7 +1145,7 @@ template <> struct TrStep<4, 5> {
         : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba)
         : "memory");
     }
-    union { uint4 u; bf16x8 v; } r;
+    union { uint4 u; h16x8 v; } r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { r.u = make_uint4(al[i].x, al[i].y, ah[i].x, ah[i].y); a[i] = r.v; }
 #pragma unroll
@@ -1187,15 +1187,15 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
   const int ntap = min(KT, p.KHp - t0);
   const int a0 = atile * 32 * MA;
 
-  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const h16_t* Ag = reinterpret_cast<const h16_t*>(p.A);
+  const h16_t* Bg = reinterpret_cast<const h16_t*>(p.B);
   const int total_units = p.nseq * p.Q;
   const int nstages = (total_units + WPOS - 1) / WPOS;
   const int st_begin = split * stages_per_split;
   const int nst = min(nstages, st_begin + stages_per_split) - st_begin;
   if (nst <= 0) return;
 
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page);
   int arow[MA], acol[MA];
 #pragma unroll
   for (int i = 0; i < MA; ++i) {
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
     const int seq = uok ? u / p.Q : 0;
     const int q = u - seq * p.Q;
     const int r0 = q * p.s + t0 * p.dil + p.off;
-    const bf16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
+    const h16_t* rsrc = Bg + ((long)seq * p.LB + r0) * p.CB + bcol;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       const int r = r0 + t * p.dil;
@@ -1262,20 +1262,20 @@ __global__ __launch_bounds__(256) void wgrad_ring(WgP p, int stages_per_split) {
 #pragma unroll
     for (int i = 0; i < MA; ++i) aa[i] = sbase + a_off[i];
     const unsigned ba = sbase + b_off;
-    bf16x8 a[MA], b[KT];
+    h16x8 a[MA], b[KT];
     TrStep<MA, KT>::template load<0>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
       if (t < ntap)
 #pragma unroll
-        for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < MA; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
     if (do_bias) wg_bias_mma<MA>(bacc, a, wc);
     TrStep<MA, KT>::template load<1>(aa, ba, a, b);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
       if (t < ntap)
 #pragma unroll
-        for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < MA; ++i) acc[i][t] = EVT_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
     if (do_bias) wg_bias_mma<MA>(bacc, a, wc);
     asm volatile("" ::: "memory");
   }
@@ -1293,7 +1293,7 @@ bool deep_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) 
 
 // which tile: 2 = 128 x 128 (conv_deep), 1 = 64 x 64 ring (conv_ring<2,2,4>), 0 = not eligible
 static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
-  if (dtype != EVT_DT_BF16) return 0;
+  if (dtype != EVT_DT_HALF) return 0;
   if (k_ch % 32 || out_ch % 64) return 0;
   if (p.xact || p.in_slope != 1.f) return 0;              // no load-side fusion on the DMA path
   if (p.nchunk * 32 != k_ch) return 0;                     // prepared image must be the ck = 32 layout
@@ -1309,7 +1309,7 @@ static int deep_kind(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
 
 int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStream_t st) {
   ConvP p = p_in;
-  const int kind = deep_kind(p, EVT_DT_BF16, out_ch, k_ch, nphase);
+  const int kind = deep_kind(p, EVT_DT_HALF, out_ch, k_ch, nphase);
   if (kind == 0) return EVT_ENOTSUP;
   if (kind == 1) {
     p.Y = out_ch / 64;
@@ -1377,7 +1377,7 @@ void wgrad_pick_split(const WgP& p, long tiles, int nstages, long target, int mi
 }
 
 bool wgrad_deep_eligible(const WgP& p, int dtype) {
-  if (dtype != EVT_DT_BF16) return false;
+  if (dtype != EVT_DT_HALF) return false;
   if (p.CA % 128 || p.CB % 32) return false;
   if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
   if (p.LA != p.Q) return false;                            // A rows are addressed by the flat position
@@ -1393,7 +1393,7 @@ bool wgrad_deep_eligible(const WgP& p, int dtype) {
 
 int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
   WgP p = p_in;
-  if (!wgrad_deep_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  if (!wgrad_deep_eligible(p, EVT_DT_HALF)) return EVT_ENOTSUP;
   p.nchunk = p.CB / 32;
   p.ntapgrp = (p.KHp + WKT - 1) / WKT;
   const long tiles = (long)(p.CA / 128) * p.nchunk * p.ntapgrp;
@@ -1423,7 +1423,7 @@ int launch_wgrad_deep(const WgP& p_in, hipStream_t st) {
 
 bool wgrad_gemm_eligible(const WgP& p, int dtype) {
   static const bool off = getenv("EVT_NO_WGRAD_GEMM") != nullptr;    // A/B switch for measurements
-  if (off || dtype != EVT_DT_BF16) return false;
+  if (off || dtype != EVT_DT_HALF) return false;
   if (p.KH != 1 || p.KHp != 1 || p.s != 1 || p.off != 0) return false;
   if (p.CA % 128 || p.CB % 128) return false;
   if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
@@ -1437,7 +1437,7 @@ static int launch_wgrad_gemm_grid(const WgP& p, long tiles, int per, hipStream_t
 
 int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
   WgP p = p_in;
-  if (!wgrad_gemm_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  if (!wgrad_gemm_eligible(p, EVT_DT_HALF)) return EVT_ENOTSUP;
   p.nchunk = p.CB / 32;
   p.ntapgrp = 1;
   const long tiles = (long)(p.CA / 128) * (p.CB / 128);
@@ -1509,7 +1509,7 @@ static int launch_ring_inst(const WgP& p, int per, hipStream_t st) {
 
 bool wgrad_ring_eligible(const WgP& p, int dtype) {
   static const bool no_ring = getenv("EVT_NO_RING") != nullptr;
-  if (no_ring || dtype != EVT_DT_BF16) return false;
+  if (no_ring || dtype != EVT_DT_HALF) return false;
   if (p.CA % 64 || p.CB % 32) return false;
   if (p.Aact || p.Bact || p.a_slope != 1.f || p.b_slope != 1.f) return false;
   if (p.LA != p.Q) return false;
@@ -1520,7 +1520,7 @@ bool wgrad_ring_eligible(const WgP& p, int dtype) {
 
 int launch_wgrad_ring(const WgP& p_in, hipStream_t st) {
   WgP p = p_in;
-  if (!wgrad_ring_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  if (!wgrad_ring_eligible(p, EVT_DT_HALF)) return EVT_ENOTSUP;
   const int KT = p.KHp <= 1 ? 1 : (p.KHp <= 3 ? 3 : 5);
   p.nchunk = p.CB / 32;
   p.ntapgrp = (p.KHp + KT - 1) / KT;

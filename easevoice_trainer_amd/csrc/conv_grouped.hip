@@ -20,16 +20,16 @@ template <> struct GFrag<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
 };
-template <> struct GFrag<bf16_t> {
+template <> struct GFrag<h16_t> {
   static constexpr int EPL = 8, KS = 32;
-  typedef bf16x8 type;
-  static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  typedef h16x8 type;
+  static __device__ __forceinline__ f32x4 mma(h16x8 a, h16x8 b, f32x4 c) {
+    return EVT_MFMA_16x16x32(a, b, c, 0, 0, 0);
   }
 };
 template <typename T> union GBuf;
 template <> union GBuf<float> { float v; float e[1]; };
-template <> union GBuf<bf16_t> { bf16x8 v; bf16_t e[8]; };
+template <> union GBuf<h16_t> { h16x8 v; h16_t e[8]; };
 
 constexpr int KPAD = 192;   // padded K (taps*4 or taps*16)
 constexpr int WP = KPAD + 8;  // weight row pitch in elements (16-byte aligned, odd multiple of 16 B)
@@ -329,19 +329,19 @@ __global__ __launch_bounds__(256) void grouped_bwd_weight(GP p) {
 // MFMA operands -- 8 consecutive positions of one column -- come from ds_read_b64_tr_b16: the row address is per lane,
 // so the overlapping-window view B[pos][kidx] = xs[16*pos + kidx] is just an address (the gather version issued 8
 // two-byte LDS reads per fragment and 2-byte global loads to stage).
-__device__ __forceinline__ bf16x8 g_tr2(const bf16_t* p0, const bf16_t* p1) {
+__device__ __forceinline__ h16x8 g_tr2(const h16_t* p0, const h16_t* p1) {
   const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1;
   uint2 lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return r.v;
 }
 
 // four fragments (eight transpose reads) behind ONE wait
-__device__ __forceinline__ void g_tr2x4(const bf16_t* p0, const bf16_t* p1, const bf16_t* p2, const bf16_t* p3, int hi_off,
-                                        bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+__device__ __forceinline__ void g_tr2x4(const h16_t* p0, const h16_t* p1, const h16_t* p2, const h16_t* p3, int hi_off,
+                                        h16x8& f0, h16x8& f1, h16x8& f2, h16x8& f3) {
   const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1, a2 = (unsigned)(uintptr_t)p2,
                  a3 = (unsigned)(uintptr_t)p3;
   const unsigned b0 = a0 + hi_off, b1 = a1 + hi_off, b2 = a2 + hi_off, b3 = a3 + hi_off;
@@ -354,7 +354,7 @@ __device__ __forceinline__ void g_tr2x4(const bf16_t* p0, const bf16_t* p1, cons
       : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
       : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
       : "memory");
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(l0.x, l0.y, h0.x, h0.y); f0 = r.v;
   r.u = make_uint4(l1.x, l1.y, h1.x, h1.y); f1 = r.v;
   r.u = make_uint4(l2.x, l2.y, h2.x, h2.y); f2 = r.v;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void g_tr2x4(const bf16_t* p0, const bf16_t* p1, cons
 }
 
 __global__ __launch_bounds__(256) void grouped_bwd_weight_tr(GP p) {
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int NTB = 11;                     // 11 tiles of 16 cover K = 164 (176)
   constexpr int R = 4 * (PT - 1) + 44;        // rows touched by 64 positions x 44 (padded) taps
   constexpr int GARR = R * 4 + 32;            // flat per-group x array (+ slack for the padded taps of the last rows)
@@ -395,23 +395,23 @@ __global__ __launch_bounds__(256) void grouped_bwd_weight_tr(GP p) {
     for (int kk = 0; kk < PT / 32; ++kk) {
       const int kb = kk * 32 + g8 * 8;        // first of this lane group's 8 positions
       const T* pa = dsA + (kb + (n >> 2)) * 16 + 4 * (n & 3);
-      const bf16x8 a = g_tr2(pa, pa + 4 * 16);
+      const h16x8 a = g_tr2(pa, pa + 4 * 16);
       const T* pb = xsA + 16 * (kb + (n >> 2)) + 4 * (n & 3);
 #pragma unroll
       for (int j0 = 0; j0 < 8; j0 += 4) {
-        bf16x8 b0, b1, b2, b3;
+        h16x8 b0, b1, b2, b3;
         g_tr2x4(pb + j0 * 16, pb + (j0 + 1) * 16, pb + (j0 + 2) * 16, pb + (j0 + 3) * 16, 4 * 16 * 2, b0, b1, b2, b3);
-        acc[j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[j0], 0, 0, 0);
-        acc[j0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[j0 + 1], 0, 0, 0);
-        acc[j0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[j0 + 2], 0, 0, 0);
-        acc[j0 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b3, acc[j0 + 3], 0, 0, 0);
+        acc[j0] = EVT_MFMA_16x16x32(a, b0, acc[j0], 0, 0, 0);
+        acc[j0 + 1] = EVT_MFMA_16x16x32(a, b1, acc[j0 + 1], 0, 0, 0);
+        acc[j0 + 2] = EVT_MFMA_16x16x32(a, b2, acc[j0 + 2], 0, 0, 0);
+        acc[j0 + 3] = EVT_MFMA_16x16x32(a, b3, acc[j0 + 3], 0, 0, 0);
       }
       {   // tiles 8..10 (+ a re-read of tile 10 to fill the batch)
-        bf16x8 b0, b1, b2, b3;
+        h16x8 b0, b1, b2, b3;
         g_tr2x4(pb + 8 * 16, pb + 9 * 16, pb + 10 * 16, pb + 10 * 16, 4 * 16 * 2, b0, b1, b2, b3);
-        acc[8] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[8], 0, 0, 0);
-        acc[9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[9], 0, 0, 0);
-        acc[10] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[10], 0, 0, 0);
+        acc[8] = EVT_MFMA_16x16x32(a, b0, acc[8], 0, 0, 0);
+        acc[9] = EVT_MFMA_16x16x32(a, b1, acc[9], 0, 0, 0);
+        acc[10] = EVT_MFMA_16x16x32(a, b2, acc[10], 0, 0, 0);
       }
     }
   }
@@ -465,13 +465,13 @@ extern "C" int evt_grouped_fwd(const evt_conv1d_params* c, const void* x, const 
   p.pad = c->pad; p.groups = c->groups; p.in_slope = c->in_slope; p.out_act = c->out_act; p.out_slope = c->out_slope;
   p.cog = c->cout / c->groups;
   p.tiles_per_seq = cdiv(p.lout, PT);
-  const int sz = c->dtype == EVT_DT_BF16 ? 2 : 4;
+  const int sz = c->dtype == EVT_DT_HALF ? 2 : 4;
   const size_t lds = (size_t)(4 * 16 * WP + 4 * ((4 * (PT - 1) + KPAD / 4) * 4 + 16)) * sz;
   dim3 grid(persistent_blocks((long)p.nseq * p.tiles_per_seq, c->groups / 4), c->groups / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (c->dtype == EVT_DT_BF16) {
-    if (set_lds(&grouped_fwd<bf16_t>, lds)) return EVT_ELAUNCH;
-    hipLaunchKernelGGL(grouped_fwd<bf16_t>, grid, dim3(256), lds, st, p);
+  if (c->dtype == EVT_DT_HALF) {
+    if (set_lds(&grouped_fwd<h16_t>, lds)) return EVT_ELAUNCH;
+    hipLaunchKernelGGL(grouped_fwd<h16_t>, grid, dim3(256), lds, st, p);
   } else {
     if (set_lds(&grouped_fwd<float>, lds)) return EVT_ELAUNCH;
     hipLaunchKernelGGL(grouped_fwd<float>, grid, dim3(256), lds, st, p);
@@ -488,13 +488,13 @@ extern "C" int evt_grouped_bwd_data(const evt_conv1d_params* c, const void* dy, 
   p.cog = c->cout / c->groups;
   const int nq = (c->lin - 1 + c->pad) / 4 + 1;   // q' in [0, nq)
   p.tiles_per_seq = cdiv(nq, PT);
-  const int sz = c->dtype == EVT_DT_BF16 ? 2 : 4;
+  const int sz = c->dtype == EVT_DT_HALF ? 2 : 4;
   const size_t lds = (size_t)(4 * 16 * WP + 4 * ((PT + KPAD / 16 - 1) * 16 + 16)) * sz;
   dim3 grid(persistent_blocks((long)p.nseq * p.tiles_per_seq, c->groups / 4), c->groups / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (c->dtype == EVT_DT_BF16) {
-    if (set_lds(&grouped_bwd_data<bf16_t>, lds)) return EVT_ELAUNCH;
-    hipLaunchKernelGGL(grouped_bwd_data<bf16_t>, grid, dim3(256), lds, st, p);
+  if (c->dtype == EVT_DT_HALF) {
+    if (set_lds(&grouped_bwd_data<h16_t>, lds)) return EVT_ELAUNCH;
+    hipLaunchKernelGGL(grouped_bwd_data<h16_t>, grid, dim3(256), lds, st, p);
   } else {
     if (set_lds(&grouped_bwd_data<float>, lds)) return EVT_ELAUNCH;
     hipLaunchKernelGGL(grouped_bwd_data<float>, grid, dim3(256), lds, st, p);
@@ -517,11 +517,11 @@ extern "C" int evt_grouped_bwd_weight(const evt_conv1d_params* c, const void* x,
   if (split > total) split = total;
   if (split < 1) split = 1;
   p.nsplit = (int)split;
-  const int sz = c->dtype == EVT_DT_BF16 ? 2 : 4;
+  const int sz = c->dtype == EVT_DT_HALF ? 2 : 4;
   const size_t lds = (size_t)4 * (PT * 16 + (4 * (PT - 1) + 44) * 4 + 32) * sz;
   dim3 grid(p.nsplit, c->groups / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (c->dtype == EVT_DT_BF16) {
+  if (c->dtype == EVT_DT_HALF) {
     const size_t lds_tr = (size_t)(4 * PT * 16 + 4 * ((4 * (PT - 1) + 44) * 4 + 32)) * 2;
     if (set_lds(&grouped_bwd_weight_tr, lds_tr)) return EVT_ELAUNCH;
     hipLaunchKernelGGL(grouped_bwd_weight_tr, grid, dim3(256), lds_tr, st, p);

@@ -26,11 +26,11 @@ __global__ __launch_bounds__(256) void conv_narrow(ConvP p, int units_per_seq, l
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   unsigned char* xs = smem + wave * region_rows * XROW;
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.w);
+  const h16_t* X = reinterpret_cast<const h16_t*>(p.x);
+  const h16_t* W = reinterpret_cast<const h16_t*>(p.w);
 
   // A fragments: row co = i*16 + n of the prepared image [co][1 chunk][KHp][CI] -> K index (tap, ci) is contiguous
-  bf16x8 af[MT][NK];
+  h16x8 af[MT][NK];
   const int ktot = p.KHp * CI;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv_narrow(ConvP p, int units_per_seq, l
       const int kk = ks * 32 + g * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (kk < ktot) v = *reinterpret_cast<const uint4*>(W + (long)(i * 16 + n) * ktot + kk);
-      union { uint4 u; bf16x8 f; } c; c.u = v; af[i][ks] = c.f;
+      union { uint4 u; h16x8 f; } c; c.u = v; af[i][ks] = c.f;
     }
   float bias[MT][4];
 #pragma unroll
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_narrow(ConvP p, int units_per_seq, l
   auto load_unit = [&](long u) {
     const int seq = (int)(u / units_per_seq);
     const int row0 = (int)(u - (long)seq * units_per_seq) * 64 + p.off_in;
-    const bf16_t* xg = X + (long)seq * p.Lin * CI;
+    const h16_t* xg = X + (long)seq * p.Lin * CI;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = lane + i * 64;
@@ -90,21 +90,21 @@ __global__ __launch_bounds__(256) void conv_narrow(ConvP p, int units_per_seq, l
       const int kk = ks * 32 + g * 8;
       const int tap = kk / CI, ci = kk - tap * CI;
       const unsigned char* base = xs + (n + tap * p.dil) * XROW + ci * 2;
-      bf16x8 b[4];
+      h16x8 b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + j * 16 * XROW);
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const h16x8*>(base + j * 16 * XROW);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = EVT_MFMA_16x16x32(af[i][ks], b[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
 
     // epilogue: lane holds channels i*16 + g*4 .. +3 of position q0 + j*16 + n
     const long sbase = (long)seq * p.Lout * p.Cout;
-    bf16_t* yg = reinterpret_cast<bf16_t*>(p.y) + sbase;
-    const bf16_t* rg = p.res ? reinterpret_cast<const bf16_t*>(p.res) + sbase : nullptr;
-    const bf16_t* gg = p.gate ? reinterpret_cast<const bf16_t*>(p.gate) + sbase : nullptr;
+    h16_t* yg = reinterpret_cast<h16_t*>(p.y) + sbase;
+    const h16_t* rg = p.res ? reinterpret_cast<const h16_t*>(p.res) + sbase : nullptr;
+    const h16_t* gg = p.gate ? reinterpret_cast<const h16_t*>(p.gate) + sbase : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = q0 + j * 16 + n;
@@ -115,17 +115,17 @@ __global__ __launch_bounds__(256) void conv_narrow(ConvP p, int units_per_seq, l
         uint2 gv = make_uint2(0, 0), rv = make_uint2(0, 0);
         if (gg) gv = *reinterpret_cast<const uint2*>(gg + off);
         if (rg) rv = *reinterpret_cast<const uint2*>(rg + off);
-        const bf16_t* pg = reinterpret_cast<const bf16_t*>(&gv);
-        const bf16_t* pr = reinterpret_cast<const bf16_t*>(&rv);
-        bf16_t outv[4];
+        const h16_t* pg = reinterpret_cast<const h16_t*>(&gv);
+        const h16_t* pr = reinterpret_cast<const h16_t*>(&rv);
+        h16_t outv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + bias[i][r];
           if (p.out_act == EVT_ACT_LRELU) v = lrelu_f(v, p.out_slope);
           else if (p.out_act == EVT_ACT_TANH) v = tanhf(v);
-          if (gg) v *= (bf2f(pg[r]) > 0.f ? 1.f : p.gate_slope);
-          if (rg) v += bf2f(pr[r]);
-          outv[r] = f2bf(v);
+          if (gg) v *= (h2f(pg[r]) > 0.f ? 1.f : p.gate_slope);
+          if (rg) v += h2f(pr[r]);
+          outv[r] = f2h(v);
         }
         *reinterpret_cast<uint2*>(yg + off) = *reinterpret_cast<uint2*>(outv);
       }
@@ -160,7 +160,7 @@ int launch_inst(const ConvP& p, hipStream_t st) {
 
 bool narrow_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase) {
   static const bool off = getenv("EVT_NO_NARROW") != nullptr;   // A/B switch for measurements
-  if (off || dtype != EVT_DT_BF16 || nphase != 1) return false;
+  if (off || dtype != EVT_DT_HALF || nphase != 1) return false;
   if (p.xact || p.in_slope != 1.f) return false;
   if (p.s_in != 1 || p.s_out != 1 || p.off_out != 0) return false;
   if (!((k_ch == 16 && out_ch == 16) || (k_ch == 32 && out_ch == 32))) return false;
@@ -174,7 +174,7 @@ bool narrow_eligible(const ConvP& p, int dtype, int out_ch, int k_ch, int nphase
 }
 
 int launch_conv_narrow(const ConvP& p, int out_ch, int k_ch, int nphase, hipStream_t st) {
-  if (!narrow_eligible(p, EVT_DT_BF16, out_ch, k_ch, nphase)) return EVT_ENOTSUP;
+  if (!narrow_eligible(p, EVT_DT_HALF, out_ch, k_ch, nphase)) return EVT_ENOTSUP;
   const int nk = (p.KHp * k_ch + 31) / 32;
   if (k_ch == 16) {
     if (nk == 2) return launch_inst<16, 1, 2>(p, st);

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_xs(SP p, int rows_per_bl
 
 extern "C" int evt_small_kind(const evt_conv1d_params* c) {
   if (c->transposed || c->groups != 1) return 0;
-  const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = c->dtype == EVT_DT_HALF ? 8 : 4;
   if (c->cout == 1 && c->cin % V == 0 && (long)c->k * c->cin <= 4096) return 1;   // dot-product conv
   if (c->cin == 1 && c->cout % 8 == 0 && c->cout <= 32 && 256 % c->cout == 0 && c->cout * (c->k + 1) <= 256)
     return 2;  // single-channel input
@@ -505,7 +505,7 @@ extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const vo
                              void* stream) {
   SP p = make_sp(c);
   p.x = x; p.w = w_reg; p.bias = bias; p.y = y;
-  const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = c->dtype == EVT_DT_HALF ? 8 : 4;
   const int pieces = c->k * (c->cin / V);
   int G = 1;
   while (G < pieces && G < 64) G <<= 1;
@@ -517,7 +517,7 @@ extern "C" int evt_cout1_fwd(const evt_conv1d_params* c, const void* x, const vo
   const size_t lds = (size_t)c->k * c->cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cout1_fwd");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_fwd<bf16_t>, dim3((int)blocks), dim3(256), lds, st, p);
+  if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cout1_fwd<h16_t>, dim3((int)blocks), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(cout1_fwd<float>, dim3((int)blocks), dim3(256), lds, st, p);
   return evt_check_launch();
 }
@@ -543,7 +543,7 @@ extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, c
   }
   p.pos_per_block = (int)ppb;
   int blocks = (int)((total + ppb - 1) / ppb);
-  const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = c->dtype == EVT_DT_HALF ? 8 : 4;
   hipStream_t st = (hipStream_t)stream;
   static const bool xs_off = getenv("EVT_NO_COUT1_XS") != nullptr;          // A/B switch
   int ppr2 = 1;
@@ -557,7 +557,7 @@ extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, c
     blocks = (int)((rows + rpb - 1) / rpb);
     evt_set_last_tag("cout1_bwd_weight_xs<k%d>", c->k);
 #define XS(T, K_) hipLaunchKernelGGL((cout1_bwd_weight_xs<T, K_>), dim3(blocks), dim3(256), lds_xs, st, p, (int)rpb)
-    if (c->dtype == EVT_DT_BF16) { if (c->k == 3) XS(bf16_t, 3); else XS(bf16_t, 7); }
+    if (c->dtype == EVT_DT_HALF) { if (c->k == 3) XS(h16_t, 3); else XS(h16_t, 7); }
     else { if (c->k == 3) XS(float, 3); else XS(float, 7); }
 #undef XS
   } else {
@@ -565,7 +565,7 @@ extern "C" int evt_cout1_bwd_weight(const evt_conv1d_params* c, const void* x, c
     while (pp < c->k * (c->cin / V) && pp < 256) pp <<= 1;
     const size_t lds = (size_t)(256 / pp) * c->k * c->cin * sizeof(float);    // one partial per position lane
     evt_set_last_tag("cout1_bwd_weight");
-    if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p);
+    if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cout1_bwd_weight<h16_t>, dim3(blocks), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(cout1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p);
   }
   int rc = evt_check_launch();
@@ -600,7 +600,7 @@ extern "C" int evt_cin1_bwd_weight(const evt_conv1d_params* c, const void* x, co
   const size_t lds = ((size_t)C1_TQ * c->cout + seg) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cin1_bwd_weight");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cin1_bwd_weight<bf16_t>, dim3(blocks), dim3(256), lds, st, p, dbias);
+  if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cin1_bwd_weight<h16_t>, dim3(blocks), dim3(256), lds, st, p, dbias);
   else hipLaunchKernelGGL(cin1_bwd_weight<float>, dim3(blocks), dim3(256), lds, st, p, dbias);
   int rc = evt_check_launch();
   if (rc || !p.ws) return rc;
@@ -622,7 +622,7 @@ extern "C" int evt_cin1_fwd(const evt_conv1d_params* c, const void* x, const voi
   const size_t lds = ((size_t)c->k * c->cout + seg) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cin1_fwd");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cin1_fwd<bf16_t>, dim3(blocks), dim3(256), lds, st, p);
+  if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cin1_fwd<h16_t>, dim3(blocks), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(cin1_fwd<float>, dim3(blocks), dim3(256), lds, st, p);
   return evt_check_launch();
 }
@@ -637,7 +637,7 @@ extern "C" int evt_cin1_bwd_data(const evt_conv1d_params* c, const void* dy, con
   if (lds > 64 * 1024) return EVT_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cin1_bwd_data");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cin1_bwd_data<bf16_t>, dim3(blocks), dim3(256), lds, st, p, gate, dx_add);
+  if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cin1_bwd_data<h16_t>, dim3(blocks), dim3(256), lds, st, p, gate, dx_add);
   else hipLaunchKernelGGL(cin1_bwd_data<float>, dim3(blocks), dim3(256), lds, st, p, gate, dx_add);
   return evt_check_launch();
 }
@@ -646,14 +646,14 @@ extern "C" int evt_cout1_bwd_data(const evt_conv1d_params* c, const void* dy, co
                                   const void* gate, const void* dx_add, void* dx, void* stream) {
   SP p = make_sp(c);
   p.dy = dy; p.y_in = c->out_act != EVT_ACT_NONE ? y : nullptr; p.w = w_reg; p.y = dx;
-  const int V = c->dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = c->dtype == EVT_DT_HALF ? 8 : 4;
   const long total = (long)p.nseq * p.lin * (p.cin / V);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   const size_t lds = (size_t)c->k * c->cin * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   evt_set_last_tag("cout1_bwd_data");
-  if (c->dtype == EVT_DT_BF16) hipLaunchKernelGGL(cout1_bwd_data<bf16_t>, dim3((int)blocks), dim3(256), lds, st, p, gate, dx_add);
+  if (c->dtype == EVT_DT_HALF) hipLaunchKernelGGL(cout1_bwd_data<h16_t>, dim3((int)blocks), dim3(256), lds, st, p, gate, dx_add);
   else hipLaunchKernelGGL(cout1_bwd_data<float>, dim3((int)blocks), dim3(256), lds, st, p, gate, dx_add);
   return evt_check_launch();
 }

@@ -13,7 +13,7 @@
 namespace {
 
 __device__ __forceinline__ void store_w(void* base, long idx, float w, int dtype) {
-  if (dtype == EVT_DT_BF16) reinterpret_cast<bf16_t*>(base)[idx] = f2bf(w);
+  if (dtype == EVT_DT_HALF) reinterpret_cast<h16_t*>(base)[idx] = f2h(w);
   else reinterpret_cast<float*>(base)[idx] = w;
 }
 
@@ -360,11 +360,16 @@ __global__ void adamw_flat_kernel(float* p, const float* g, float* m, float* v, 
   }
 }
 
-__global__ void counter_inc_kernel(int* c) { *c += 1; }
+__global__ void counter_inc_kernel(int* c, const float* skip) {
+  if (skip && *skip != 0.f) return;
+  *c += 1;
+}
 
 // same update, bias corrections from a step number held in device memory (graph-replayable: no per-step host argument)
 __global__ void adamw_flat_dev_kernel(float* p, const float* g, float* m, float* v, const evt_adamw_seg* segs, int nseg,
-                                      float b1, float b2, float eps, const int* stepp, float gscale, long lo, long hi) {
+                                      float b1, float b2, float eps, const int* stepp, float gscale, long lo, long hi,
+                                      const float* skip) {
+  if (skip && *skip != 0.f) return;      // GradScaler.step on an overflow: the optimiser is not stepped at all
   const float stepf = (float)*stepp;
   const float bc1 = 1.f - powf(b1, stepf);
   const float bc2_sqrt = sqrtf(1.f - powf(b2, stepf));
@@ -383,6 +388,49 @@ __global__ void adamw_flat_dev_kernel(float* p, const float* g, float* m, float*
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     pv -= (lr / bc1) * (mv / denom);
     p[i] = pv;
+  }
+}
+
+// GradScaler.unscale_: g *= 1 / scale, any non-finite element raises the flag (the flag is only ever written with 1)
+__global__ __launch_bounds__(256) void unscale_check_kernel(float* g, long n, const float* scale, float* found) {
+  const float inv = (float)(1.0 / (double)*scale);
+  bool bad = false;
+  const long n4 = n >> 2;
+  float4* g4 = reinterpret_cast<float4*>(g);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = g4[i];
+    bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    g4[i] = v;
+  }
+  for (long i = (n4 << 2) + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = g[i];
+    bad |= !isfinite(v);
+    g[i] = v * inv;
+  }
+  if (bad) *found = 1.f;
+}
+
+struct ScalerFlags { float* f[4]; };
+__global__ void scaler_update_kernel(float* scale, int* tracker, ScalerFlags fl, int nflags, float growth, float backoff,
+                                     int interval) {
+  bool found = false;
+  for (int i = 0; i < nflags; ++i) {
+    found |= *fl.f[i] != 0.f;
+    *fl.f[i] = 0.f;
+  }
+  if (found) {
+    *scale = *scale * backoff;
+    *tracker = 0;
+  } else {
+    const int ok = *tracker + 1;
+    if (ok == interval) {
+      const float ns = *scale * growth;
+      if (isfinite(ns)) *scale = ns;
+      *tracker = 0;
+    } else {
+      *tracker = ok;
+    }
   }
 }
 
@@ -424,7 +472,8 @@ void evt_debug_kernel_tags(int32_t enable) { g_tags_on = enable != 0; }
 #ifndef EVT_SRC_HASH
 #define EVT_SRC_HASH "unknown"
 #endif
-const char* evt_version(void) { return "evt-hip 0.2 (gfx950) src=" EVT_SRC_HASH; }
+const char* evt_version(void) { return "evt-hip 0.3 (gfx950, half = " EVT_HALF_NAME ") src=" EVT_SRC_HASH; }
+int32_t evt_half_dtype(void) { return EVT_DT_HALF; }
 
 int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream) {
   if (!items || !row_index || nrows <= 0) return EVT_EINVAL;
@@ -443,9 +492,9 @@ int evt_add3_scale(int32_t dtype, const void* a, const void* b, const void* c, f
                    void* stream) {
   if (!a || !out || n <= 0) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(add3_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a,
-                       (const bf16_t*)b, (const bf16_t*)c, scale, (bf16_t*)out, (long)n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(add3_scale_kernel<h16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const h16_t*)a,
+                       (const h16_t*)b, (const h16_t*)c, scale, (h16_t*)out, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(add3_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b,
                        (const float*)c, scale, (float*)out, (long)n);
@@ -457,9 +506,9 @@ int evt_leaky_relu(int32_t dtype, const void* x, float slope, void* out, int64_t
   if (!x || !out || n <= 0) return EVT_EINVAL;
   if (((uintptr_t)x | (uintptr_t)out) & 15) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(lrelu_kernel<bf16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const bf16_t*)x, slope,
-                       (bf16_t*)out, (long)n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(lrelu_kernel<h16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const h16_t*)x, slope,
+                       (h16_t*)out, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(lrelu_kernel<float>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (const float*)x, slope,
                        (float*)out, (long)n);
@@ -472,9 +521,9 @@ int evt_dact_mul(int32_t dtype, const void* dy, const void* y, int32_t act_kind,
   if (!dy || !y || !out || n <= 0) return EVT_EINVAL;
   if (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(dact_mul_kernel<bf16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)y, act_kind, slope, (bf16_t*)out, (long)n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(dact_mul_kernel<h16_t>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, st, (const h16_t*)dy,
+                       (const h16_t*)y, act_kind, slope, (h16_t*)out, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(dact_mul_kernel<float>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (const float*)dy,
                        (const float*)y, act_kind, slope, (float*)out, (long)n);
@@ -487,9 +536,9 @@ int evt_gated_act_fwd(int32_t dtype, const void* xin, const void* g, void* acts,
   if (!xin || !acts || nseq <= 0 || len <= 0 || H <= 0) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)nseq * len * H;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(gated_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)xin,
-                       (const bf16_t*)g, (bf16_t*)acts, nseq, len, H);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(gated_fwd_kernel<h16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const h16_t*)xin,
+                       (const h16_t*)g, (h16_t*)acts, nseq, len, H);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(gated_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)xin,
                        (const float*)g, (float*)acts, nseq, len, H);
@@ -507,18 +556,18 @@ int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void*
     int tch = (int)(((long)nseq * len + 511) / 512);
     if (tch < 4) tch = 4;
     const int blocks = nseq * ((len + tch - 1) / tch);
-    if (dtype == EVT_DT_BF16)
-      hipLaunchKernelGGL(gated_bwd_dg_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)xin, (const bf16_t*)g,
-                         (const bf16_t*)dacts, (bf16_t*)dxin, dg, nseq, len, H, tch);
+    if (dtype == EVT_DT_HALF)
+      hipLaunchKernelGGL(gated_bwd_dg_kernel<h16_t>, dim3(blocks), dim3(256), 0, st, (const h16_t*)xin, (const h16_t*)g,
+                         (const h16_t*)dacts, (h16_t*)dxin, dg, nseq, len, H, tch);
     else if (dtype == EVT_DT_F32)
       hipLaunchKernelGGL(gated_bwd_dg_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)xin, (const float*)g,
                          (const float*)dacts, (float*)dxin, dg, nseq, len, H, tch);
     else return EVT_EINVAL;
     return evt_check_launch();
   }
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(gated_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)xin,
-                       (const bf16_t*)g, (const bf16_t*)dacts, (bf16_t*)dxin, dg, nseq, len, H);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(gated_bwd_kernel<h16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const h16_t*)xin,
+                       (const h16_t*)g, (const h16_t*)dacts, (h16_t*)dxin, dg, nseq, len, H);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(gated_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)xin,
                        (const float*)g, (const float*)dacts, (float*)dxin, dg, nseq, len, H);
@@ -529,8 +578,8 @@ int evt_gated_act_bwd(int32_t dtype, const void* xin, const void* g, const void*
 #define SEG_LAUNCH(MODE, BWD, TARGET, OUT, DLOSS)                                                                   \
   do {                                                                                                             \
     if (nseg > SEG_MAX) return EVT_ENOTSUP;                                                                        \
-    if (dtype == EVT_DT_BF16)                                                                                      \
-      hipLaunchKernelGGL((seg_flat_kernel<bf16_t, MODE, BWD>), dim3(512), dim3(256), 0, st, segs, nseg, TARGET, OUT, DLOSS); \
+    if (dtype == EVT_DT_HALF)                                                                                      \
+      hipLaunchKernelGGL((seg_flat_kernel<h16_t, MODE, BWD>), dim3(512), dim3(256), 0, st, segs, nseg, TARGET, OUT, DLOSS); \
     else if (dtype == EVT_DT_F32)                                                                                  \
       hipLaunchKernelGGL((seg_flat_kernel<float, MODE, BWD>), dim3(512), dim3(256), 0, st, segs, nseg, TARGET, OUT, DLOSS);  \
     else return EVT_EINVAL;                                                                                        \
@@ -579,9 +628,41 @@ int evt_adamw_flat_dev(float* param, const float* grad, float* exp_avg, float* e
                        int32_t* step_counter, float grad_scale, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || !step_counter || n <= 0)
     return EVT_EINVAL;
-  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, (const float*)nullptr);
   hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, 0L, (long)n);
+                     exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, 0L, (long)n,
+                     (const float*)nullptr);
+  return evt_check_launch();
+}
+
+int evt_adamw_flat_dev_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                               int32_t* step_counter, float grad_scale, const float* skip, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || !step_counter || n <= 0)
+    return EVT_EINVAL;
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, skip);
+  hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, 0L, (long)n, skip);
+  return evt_check_launch();
+}
+
+int evt_scaler_unscale(float* grad, int64_t n, const float* scale, float* found_inf, void* stream) {
+  if (!grad || !scale || !found_inf || n <= 0 || ((uintptr_t)grad & 15)) return EVT_EINVAL;
+  hipLaunchKernelGGL(unscale_check_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, grad, (long)n,
+                     scale, found_inf);
+  return evt_check_launch();
+}
+
+int evt_scaler_update(float* scale, int32_t* growth_tracker, float* const* found_inf, int32_t nflags, float growth_factor,
+                      float backoff_factor, int32_t growth_interval, void* stream) {
+  if (!scale || !growth_tracker || !found_inf || nflags <= 0 || nflags > 4 || growth_interval <= 0) return EVT_EINVAL;
+  ScalerFlags fl{};
+  for (int i = 0; i < nflags; ++i) {
+    if (!found_inf[i]) return EVT_EINVAL;
+    fl.f[i] = found_inf[i];
+  }
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale, growth_tracker, fl, nflags,
+                     growth_factor, backoff_factor, growth_interval);
   return evt_check_launch();
 }
 
@@ -590,10 +671,11 @@ int evt_adamw_flat_dev_range(float* param, const float* grad, float* exp_avg, fl
                              int32_t* step_counter, int32_t bump, float grad_scale, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segs || nseg <= 0 || nseg > 64 || !step_counter || lo < 0 || hi <= lo)
     return EVT_EINVAL;
-  if (bump) hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  if (bump)
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, (const float*)nullptr);
   hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(grid_for(hi - lo)), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, segs, nseg, beta1, beta2, eps, (const int*)step_counter, grad_scale, (long)lo,
-                     (long)hi);
+                     (long)hi, (const float*)nullptr);
   return evt_check_launch();
 }
 

@@ -494,8 +494,8 @@ static inline dim3 ew_grid(long nv) {
 // the instantiation for the pair.
 template <typename F>
 static int mixed_dispatch(int32_t dtype, int32_t wide_dtype, F&& f) {
-  if (dtype == EVT_DT_BF16 && wide_dtype == EVT_DT_BF16) f((bf16_t*)nullptr, (bf16_t*)nullptr);
-  else if (dtype == EVT_DT_BF16 && wide_dtype == EVT_DT_F32) f((bf16_t*)nullptr, (float*)nullptr);
+  if (dtype == EVT_DT_HALF && wide_dtype == EVT_DT_HALF) f((h16_t*)nullptr, (h16_t*)nullptr);
+  else if (dtype == EVT_DT_HALF && wide_dtype == EVT_DT_F32) f((h16_t*)nullptr, (float*)nullptr);
   else if (dtype == EVT_DT_F32 && wide_dtype == EVT_DT_F32) f((float*)nullptr, (float*)nullptr);
   else return EVT_EINVAL;
   return evt_check_launch();
@@ -520,7 +520,7 @@ int evt_res_dropout_ln_fwd(int32_t dtype, const void* x, const void* y, const fl
   const int blocks = (int)((rows + 3) / 4);
 #define RDL_FWD(T, E) hipLaunchKernelGGL((res_drop_ln_fwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, \
                                          gamma, beta, lens, rows_per_seq, p, seed_dev, site, (T*)out, mean, rstd, (long)rows, C, eps)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) RDL_FWD(bf16_t, 1); else RDL_FWD(bf16_t, 2); }
+  if (dtype == EVT_DT_HALF) { if (C <= 512) RDL_FWD(h16_t, 1); else RDL_FWD(h16_t, 2); }
   else if (dtype == EVT_DT_F32) { if (C <= 512) RDL_FWD(float, 2); else RDL_FWD(float, 4); }
   else return EVT_EINVAL;
 #undef RDL_FWD
@@ -546,9 +546,9 @@ int evt_res_dropout_ln_bwd(int32_t dtype, const void* x, const void* y, const fl
 #define RDL_BWD(T, E, W) hipLaunchKernelGGL((res_drop_ln_bwd<T, E, W>), dim3(blocks), dim3(64 * W), 0, st, (const T*)x,      \
                                             (const T*)y, gamma, (const T*)dout, mean, rstd, lens, rows_per_seq, p, seed_dev, \
                                             site, (T*)dx, (T*)dy, dgamma, dbeta, (long)rows, C, (int)rpb)
-  if (dtype == EVT_DT_BF16) {
-    if (C <= 512) { if (wide) RDL_BWD(bf16_t, 1, 8); else RDL_BWD(bf16_t, 1, 4); }
-    else { if (wide) RDL_BWD(bf16_t, 2, 8); else RDL_BWD(bf16_t, 2, 4); }
+  if (dtype == EVT_DT_HALF) {
+    if (C <= 512) { if (wide) RDL_BWD(h16_t, 1, 8); else RDL_BWD(h16_t, 1, 4); }
+    else { if (wide) RDL_BWD(h16_t, 2, 8); else RDL_BWD(h16_t, 2, 4); }
   } else if (dtype == EVT_DT_F32) {
     if (C <= 512) RDL_BWD(float, 2, 4); else RDL_BWD(float, 4, 4);
   } else return EVT_EINVAL;
@@ -561,8 +561,8 @@ int evt_reparam_fwd(int32_t dtype, const void* stats, const float* eps, const in
                     int64_t rows, int32_t C, float* z, float* m, float* logs, void* stream) {
   if (!stats || !eps || !z || !m || !logs || rows <= 0 || C <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(reparam_fwd<bf16_t>, ew_grid(rows * C), dim3(256), 0, st, (const bf16_t*)stats, eps, lens, rows_per_seq,
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(reparam_fwd<h16_t>, ew_grid(rows * C), dim3(256), 0, st, (const h16_t*)stats, eps, lens, rows_per_seq,
                        (long)rows, C, z, m, logs);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(reparam_fwd<float>, ew_grid(rows * C), dim3(256), 0, st, (const float*)stats, eps, lens, rows_per_seq,
@@ -575,9 +575,9 @@ int evt_reparam_bwd(int32_t dtype, const float* dz, const float* dm, const float
                     const int32_t* lens, int32_t rows_per_seq, int64_t rows, int32_t C, void* dstats, void* stream) {
   if (!eps || !logs || !dstats || rows <= 0 || C <= 0 || (lens && rows_per_seq <= 0)) return EVT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(reparam_bwd<bf16_t>, ew_grid(rows * C), dim3(256), 0, st, dz, dm, dlogs, eps, logs, lens, rows_per_seq,
-                       (long)rows, C, (bf16_t*)dstats);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(reparam_bwd<h16_t>, ew_grid(rows * C), dim3(256), 0, st, dz, dm, dlogs, eps, logs, lens, rows_per_seq,
+                       (long)rows, C, (h16_t*)dstats);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(reparam_bwd<float>, ew_grid(rows * C), dim3(256), 0, st, dz, dm, dlogs, eps, logs, lens, rows_per_seq,
                        (long)rows, C, (float*)dstats);
@@ -636,9 +636,9 @@ int evt_coupling_flip_fwd(int32_t dtype, const float* x, const void* stats, cons
   long blocks = (rows * 2 * h + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(coupling_flip_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, x, (const bf16_t*)stats, lens,
-                       rows_per_seq, (long)rows, h, y, (bf16_t*)x0n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(coupling_flip_fwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, x, (const h16_t*)stats, lens,
+                       rows_per_seq, (long)rows, h, y, (h16_t*)x0n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(coupling_flip_fwd<float>, dim3((int)blocks), dim3(256), 0, st, x, (const float*)stats, lens,
                        rows_per_seq, (long)rows, h, y, (float*)x0n);
@@ -652,9 +652,9 @@ int evt_coupling_flip_bwd(int32_t dtype, const float* dy, const void* dx0n, cons
   long blocks = (rows * 2 * h + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(coupling_flip_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, dy, (const bf16_t*)dx0n, lens,
-                       rows_per_seq, (long)rows, h, dx, (bf16_t*)dstats);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(coupling_flip_bwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, dy, (const h16_t*)dx0n, lens,
+                       rows_per_seq, (long)rows, h, dx, (h16_t*)dstats);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(coupling_flip_bwd<float>, dim3((int)blocks), dim3(256), 0, st, dy, (const float*)dx0n, lens,
                        rows_per_seq, (long)rows, h, dx, (float*)dstats);
@@ -667,15 +667,15 @@ int evt_wn_residual_fwd(int32_t dtype, const void* x, const void* rs, const void
                         void* stream) {
   if (!rs || !acc_out || rows <= 0 || H <= 0 || (!last && (!x || !x_out))) return EVT_EINVAL;
   if (lens && rows_per_seq <= 0) return EVT_EINVAL;
-  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = dtype == EVT_DT_HALF ? 8 : 4;
   if (H % V) return EVT_ENOTSUP;
   const long total = rows * (H / V);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(wn_residual_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)rs,
-                       (const bf16_t*)acc, lens, rows_per_seq, (bf16_t*)x_out, (bf16_t*)acc_out, (long)rows, H, last);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(wn_residual_fwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, (const h16_t*)x, (const h16_t*)rs,
+                       (const h16_t*)acc, lens, rows_per_seq, (h16_t*)x_out, (h16_t*)acc_out, (long)rows, H, last);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(wn_residual_fwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (const float*)rs,
                        (const float*)acc, lens, rows_per_seq, (float*)x_out, (float*)acc_out, (long)rows, H, last);
@@ -687,15 +687,15 @@ int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out,
                         int32_t rows_per_seq, void* dx, void* drs, int64_t rows, int32_t H, int32_t last, void* stream) {
   if (!drs || rows <= 0 || H <= 0 || (!last && !dx)) return EVT_EINVAL;
   if (lens && rows_per_seq <= 0) return EVT_EINVAL;
-  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = dtype == EVT_DT_HALF ? 8 : 4;
   if (H % V) return EVT_ENOTSUP;
   const long total = rows * (H / V);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(wn_residual_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)dx_out,
-                       (const bf16_t*)dacc_out, lens, rows_per_seq, (bf16_t*)dx, (bf16_t*)drs, (long)rows, H, last);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(wn_residual_bwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, (const h16_t*)dx_out,
+                       (const h16_t*)dacc_out, lens, rows_per_seq, (h16_t*)dx, (h16_t*)drs, (long)rows, H, last);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(wn_residual_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)dx_out,
                        (const float*)dacc_out, lens, rows_per_seq, (float*)dx, (float*)drs, (long)rows, H, last);
@@ -706,15 +706,15 @@ int evt_wn_residual_bwd(int32_t dtype, const void* dx_out, const void* dacc_out,
 int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* seed_dev, uint32_t site,
                          const int32_t* lens, int32_t rows_per_seq, int32_t C, void* y, int64_t n, void* stream) {
   if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
-  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = dtype == EVT_DT_HALF ? 8 : 4;
   if (lens && (rows_per_seq <= 0 || C <= 0 || C % V)) return EVT_EINVAL;
   if (n % V || (((uintptr_t)x | (uintptr_t)y) & 15)) return EVT_EINVAL;
   long blocks = (n / V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(relu_dropout_fwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, p, seed_dev, site,
-                       lens, rows_per_seq, C, (bf16_t*)y, (long)n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(relu_dropout_fwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, (const h16_t*)x, p, seed_dev, site,
+                       lens, rows_per_seq, C, (h16_t*)y, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(relu_dropout_fwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, p, seed_dev, site,
                        lens, rows_per_seq, C, (float*)y, (long)n);
@@ -725,15 +725,15 @@ int evt_relu_dropout_fwd(int32_t dtype, const void* x, float p, const uint32_t* 
 int evt_relu_dropout_bwd(int32_t dtype, const void* x, const void* dy, float p, const uint32_t* seed_dev, uint32_t site,
                          const int32_t* lens, int32_t rows_per_seq, int32_t C, void* dx, int64_t n, void* stream) {
   if (!x || !dy || !dx || n <= 0 || p < 0.f || p >= 1.f) return EVT_EINVAL;
-  const int V = dtype == EVT_DT_BF16 ? 8 : 4;
+  const int V = dtype == EVT_DT_HALF ? 8 : 4;
   if (lens && (rows_per_seq <= 0 || C <= 0 || C % V)) return EVT_EINVAL;
   if (n % V || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return EVT_EINVAL;
   long blocks = (n / V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(relu_dropout_bwd<bf16_t>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       p, seed_dev, site, lens, rows_per_seq, C, (bf16_t*)dx, (long)n);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(relu_dropout_bwd<h16_t>, dim3((int)blocks), dim3(256), 0, st, (const h16_t*)x, (const h16_t*)dy,
+                       p, seed_dev, site, lens, rows_per_seq, C, (h16_t*)dx, (long)n);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(relu_dropout_bwd<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, p,
                        seed_dev, site, lens, rows_per_seq, C, (float*)dx, (long)n);

@@ -3,10 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits; all bf16 tensors cross the C ABI as uint16 storage
+// The library is built twice from these sources (easevoice_trainer_amd/build.py): libevt_hip.so with bfloat16 as its 16-bit
+// floating type and libevt_hip_f16.so (-DEVT_HALF_F16) with IEEE half -- the reference's `fp16_run` autocast type
+// (src/train/sovits.py:459-525).  A build serves EVT_DT_F32 and ITS half code (EVT_DT_HALF); the other half code is
+// EVT_ENOTSUP.  Everything below the C ABI is written against `h16_t` (raw 16-bit storage), `evt_hn` (the native
+// arithmetic type of that storage) and the conversions h2f / f2h; the 16-bit LDS transposes, LDS-DMA and fragment
+// layouts are the same for both types, the MFMA opcode differs (EVT_MFMA_16x16x32).
+typedef uint16_t h16_t;  // raw bits of the build's 16-bit float; all 16-bit tensors cross the C ABI as uint16 storage
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define EVT_OK 0
 #define EVT_EINVAL 22
@@ -15,26 +20,66 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define EVT_DT_F32 0
 #define EVT_DT_BF16 1
+#define EVT_DT_F16 2
+
+#ifdef EVT_HALF_F16
+typedef _Float16 evt_hn;
+#define EVT_DT_HALF EVT_DT_F16
+#define EVT_HALF_NAME "f16"
+#define EVT_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#else
+typedef __bf16 evt_hn;
+#define EVT_DT_HALF EVT_DT_BF16
+#define EVT_HALF_NAME "bf16"
+#define EVT_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#endif
+typedef evt_hn h16x8 __attribute__((ext_vector_type(8)));
 
 #define EVT_ACT_NONE 0
 #define EVT_ACT_LRELU 1
 #define EVT_ACT_TANH 2
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
-// round-to-nearest-even, NaN preserved (same rounding torch uses for float -> bfloat16).  The native __bf16 cast lets
-// the compiler emit gfx950's v_cvt_pk_bf16_f32 (two conversions per instruction) instead of six integer ops per value.
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  const __bf16 h = (__bf16)f;
-  return __builtin_bit_cast(bf16_t, h);
+// 16-bit -> fp32: exact for both types.  bfloat16 is the upper half of the fp32 pattern (one shift); half goes through
+// the native conversion (v_cvt_f32_f16).
+__device__ __forceinline__ float h2f(h16_t v) {
+#ifdef EVT_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, v);
+#else
+  return __uint_as_float(((uint32_t)v) << 16);
+#endif
 }
+
+// fp32 -> 16-bit, round-to-nearest-even, NaN preserved (the rounding torch uses for float -> bfloat16 / float16; a half
+// result beyond 65504 is +-inf, which is what the GradScaler of the fp16 mode looks for).  The native casts let the
+// compiler emit gfx950's v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free v_cvt_f16_f32 instead of integer sequences.
+__device__ __forceinline__ h16_t f2h(float f) {
+  const evt_hn h = (evt_hn)f;
+  return __builtin_bit_cast(h16_t, h);
+}
+
+// the two values of a packed pair (one dword of a 16-bit tensor: element 2i in the low half, 2i + 1 in the high half)
+__device__ __forceinline__ float h2f_lo(uint32_t d) {
+#ifdef EVT_HALF_F16
+  return h2f((h16_t)(d & 0xFFFFu));
+#else
+  return __uint_as_float(d << 16);
+#endif
+}
+__device__ __forceinline__ float h2f_hi(uint32_t d) {
+#ifdef EVT_HALF_F16
+  return h2f((h16_t)(d >> 16));
+#else
+  return __uint_as_float(d & 0xFFFF0000u);
+#endif
+}
+__device__ __forceinline__ uint32_t f2h_pack(float lo, float hi) { return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16); }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
-template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ float to_f<h16_t>(h16_t v) { return h2f(v); }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
-template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ h16_t from_f<h16_t>(float v) { return f2h(v); }
 
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 

@@ -133,11 +133,11 @@ extern "C" {
 
 int evt_ncl_to_nlc(int32_t dtype, const float* src, void* dst, int32_t B, int32_t C, int32_t T, int32_t Cp, void* stream) {
   if (!src || !dst || B <= 0 || C <= 0 || T <= 0 || Cp < C) return EVT_EINVAL;
-  if (dtype != EVT_DT_F32 && dtype != EVT_DT_BF16) return EVT_EINVAL;
+  if (dtype != EVT_DT_F32 && dtype != EVT_DT_HALF) return EVT_EINVAL;
   const dim3 grid((T + 31) / 32, (Cp + 31) / 32, B);
   evt_set_last_tag("ncl_to_nlc");
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(ncl_to_nlc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, T, Cp);
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(ncl_to_nlc_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (h16_t*)dst, C, T, Cp);
   else
     hipLaunchKernelGGL(ncl_to_nlc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, T, Cp);
   return evt_check_launch();

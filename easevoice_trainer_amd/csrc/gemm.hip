@@ -19,7 +19,7 @@ namespace {
 
 int make(const evt_gemm_params* g, evt_conv1d_params* c, int out_act) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return EVT_EINVAL;
-  if (g->dtype != EVT_DT_BF16 && g->dtype != EVT_DT_F32) return EVT_EINVAL;
+  if (g->dtype != EVT_DT_HALF && g->dtype != EVT_DT_F32) return EVT_EINVAL;
   if (g->K % 8 || g->N % 8) return EVT_ENOTSUP;          // 16-byte rows (callers pad N, e.g. the 1025-wide vocabulary)
   c->dtype = g->dtype;
   c->nseq = 1;

@@ -37,12 +37,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct G256 {
-  const bf16_t* a;      // [NO][K] weight-side rows
-  const bf16_t* b;      // [M][K] token-side rows
-  bf16_t* out;          // [M][NO]
+  const h16_t* a;      // [NO][K] weight-side rows
+  const h16_t* b;      // [M][K] token-side rows
+  h16_t* out;          // [M][NO]
   const float* bias;    // [NO] or null
-  const bf16_t* gate;   // [M][NO] or null
-  const bf16_t* add;    // [M][NO] or null
+  const h16_t* gate;   // [M][NO] or null
+  const h16_t* add;    // [M][NO] or null
   const unsigned* seed_dev;
   int M, NO, K;
   int relu;
@@ -66,7 +66,7 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {   // lowbias32 finaliser
 
 // one quadrant of the wave's accumulators: M-tiles 4*QA .. 4*QA+3, N-tiles 2*QB, 2*QB+1, both k sub-steps
 template <int QA, int QB>
-__device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&bfr)[2][2]) {
+__device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[8][4], const h16x8 (&af)[4][2], const h16x8 (&bfr)[2][2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -74,11 +74,11 @@ __device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[8][4], const bf16x8 (&
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[QA * 4 + i][QB * 2 + j] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[QA * 4 + i][QB * 2 + j], 0, 0, 0);
+            EVT_MFMA_16x16x32(af[i][ks], bfr[j][ks], acc[QA * 4 + i][QB * 2 + j], 0, 0, 0);
 }
 
 // ablation variants: the fragment registers stay live (and their ds_reads issued) without the matrix pipe
-__device__ __forceinline__ void keep_frags(const bf16x8 (&af)[4][2], const bf16x8 (&bfr)[2][2]) {
+__device__ __forceinline__ void keep_frags(const h16x8 (&af)[4][2], const h16x8 (&bfr)[2][2]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(af[i][0])); asm volatile("" ::"v"(af[i][1])); }
 #pragma unroll
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   float* bias_l = reinterpret_cast<float*>(smem + LDS_MAIN);
   if (p.bias && wave < 4)      // LDS-DMA like the operands (a register load + ds_write would stall the tile's start)
     __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + yi * 256 + wave * 64 + lane), (lptr_t)(bias_l + wave * 64), 4, 0, 0);
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g256_zero_page) + pslot * 8;
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g256_zero_page) + pslot * 8;
   unsigned char* my = smem + wave * 2048;                  // + buf * KTB + region * PIECE + i * 1024
   const int nt = p.K >> 6;
 
@@ -161,27 +161,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   const int a_row = (wr * 64 + n) * 128;                   // + (i & 3) * 16 * 128
   const int b_row = (wc * 32 + n) * 128;                   // + (j & 1) * 16 * 128
 
-  bf16x8 af[4][2], bfr[2][2];
+  h16x8 af[4][2], bfr[2][2];
   if (VAR & 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { af[i][0] = af[i][1] = bf16x8{}; }
+    for (int i = 0; i < 4; ++i) { af[i][0] = af[i][1] = h16x8{}; }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { bfr[j][0] = bfr[j][1] = bf16x8{}; }
+    for (int j = 0; j < 2; ++j) { bfr[j][0] = bfr[j][1] = h16x8{}; }
   }
   auto load_a = [&](const unsigned char* piece) {
     if (VAR & 4) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      af[i][0] = *reinterpret_cast<const bf16x8*>(piece + a_row + i * 2048 + so0);
-      af[i][1] = *reinterpret_cast<const bf16x8*>(piece + a_row + i * 2048 + so1);
+      af[i][0] = *reinterpret_cast<const h16x8*>(piece + a_row + i * 2048 + so0);
+      af[i][1] = *reinterpret_cast<const h16x8*>(piece + a_row + i * 2048 + so1);
     }
   };
   auto load_b = [&](const unsigned char* piece) {
     if (VAR & 4) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bfr[j][0] = *reinterpret_cast<const bf16x8*>(piece + b_row + j * 2048 + so0);
-      bfr[j][1] = *reinterpret_cast<const bf16x8*>(piece + b_row + j * 2048 + so1);
+      bfr[j][0] = *reinterpret_cast<const h16x8*>(piece + b_row + j * 2048 + so0);
+      bfr[j][1] = *reinterpret_cast<const h16x8*>(piece + b_row + j * 2048 + so1);
     }
   };
 
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
       const int co = yi * 256 + wr * 128 + i * 16 + g * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bv = *reinterpret_cast<const f32x4*>(bias_l + wr * 128 + i * 16 + g * 4);
-      bf16_t outv[4];
+      h16_t outv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
           const unsigned hsh = mix32((unsigned)idx ^ key ^ (unsigned)(idx >> 32) * 0xC2B2AE35u);
           v = hsh >= p.thr ? v * p.keep : 0.f;
         }
-        outv[r] = f2bf(v);
+        outv[r] = f2h(v);
       }
       *reinterpret_cast<uint2*>(ep + (j * 16 + n) * EP_PITCH + (i * 16 + g * 4) * 2) = *reinterpret_cast<uint2*>(outv);
     }
@@ -284,15 +284,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
       uint4 gv = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
       if (p.gate) gv = *reinterpret_cast<const uint4*>(p.gate + off);
       if (p.add) av = *reinterpret_cast<const uint4*>(p.add + off);
-      bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
-      const bf16_t* gp = reinterpret_cast<const bf16_t*>(&gv);
-      const bf16_t* ap = reinterpret_cast<const bf16_t*>(&av);
+      h16_t* vp = reinterpret_cast<h16_t*>(&v);
+      const h16_t* gp = reinterpret_cast<const h16_t*>(&gv);
+      const h16_t* ap = reinterpret_cast<const h16_t*>(&av);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float f = bf2f(vp[e]);
-        if (p.gate) f = bf2f(gp[e]) > 0.f ? f * p.gate_pos : 0.f;
-        if (p.add) f += bf2f(ap[e]);
-        vp[e] = f2bf(f);
+        float f = h2f(vp[e]);
+        if (p.gate) f = h2f(gp[e]) > 0.f ? f * p.gate_pos : 0.f;
+        if (p.add) f += h2f(ap[e]);
+        vp[e] = f2h(f);
       }
     }
     *reinterpret_cast<uint4*>(p.out + off) = v;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
 int g_variant = 0;     // measurement switch (evt_debug_gemm256_variant); 0 = the product kernel
 
 bool eligible(const evt_gemm_params* g, int kred, int nout) {
-  if (g->dtype != EVT_DT_BF16) return false;
+  if (g->dtype != EVT_DT_HALF) return false;
   if (nout % 256 || kred % 64 || kred < 128) return false;
   if ((long)g->M * kred >= (1L << 31) || (long)nout * kred >= (1L << 31)) return false;
   if (g->M < 2048) return false;                             // few token tiles: the 128 / 64 tiles fill the chip better
@@ -318,12 +318,12 @@ bool eligible(const evt_gemm_params* g, int kred, int nout) {
 int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int nout, const float* bias, int relu,
            const evt_gemm_epilogue* e, void* out, hipStream_t st) {
   G256 p{};
-  p.a = (const bf16_t*)a; p.b = (const bf16_t*)b; p.out = (bf16_t*)out; p.bias = bias;
+  p.a = (const h16_t*)a; p.b = (const h16_t*)b; p.out = (h16_t*)out; p.bias = bias;
   p.M = g->M; p.NO = nout; p.K = kred; p.relu = relu;
   p.keep = 1.f; p.gate_pos = 1.f;
   if (e) {
     if (e->dropout_p < 0.f || e->dropout_p >= 1.f) return EVT_EINVAL;
-    p.gate = (const bf16_t*)e->gate; p.add = (const bf16_t*)e->add; p.gate_pos = e->gate_pos;
+    p.gate = (const h16_t*)e->gate; p.add = (const h16_t*)e->add; p.gate_pos = e->gate_pos;
     p.seed_dev = e->seed_dev; p.site = e->site;
     if (e->dropout_p > 0.f) {
       p.thr = (unsigned)fminf(e->dropout_p * 4294967296.f, 4294967040.f);

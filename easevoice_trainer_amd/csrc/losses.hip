@@ -11,10 +11,10 @@
 namespace {
 
 __device__ __forceinline__ float ld_any(const void* p, int dt, long i) {
-  return dt == EVT_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+  return dt == EVT_DT_HALF ? h2f(reinterpret_cast<const h16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
 }
 __device__ __forceinline__ void st_any(void* p, int dt, long i, float v) {
-  if (dt == EVT_DT_BF16) reinterpret_cast<bf16_t*>(p)[i] = f2bf(v); else reinterpret_cast<float*>(p)[i] = v;
+  if (dt == EVT_DT_HALF) reinterpret_cast<h16_t*>(p)[i] = f2h(v); else reinterpret_cast<float*>(p)[i] = v;
 }
 
 struct KlArgs {
@@ -74,7 +74,7 @@ int kl_args(KlArgs& a, const evt_kl_params* p, const void* zp, const void* lq, c
             const int32_t* lens) {
   if (!p || !zp || !lq || !mp || !lp || p->B <= 0 || p->T <= 0 || p->C <= 0) return EVT_EINVAL;
   const int dts[4] = {p->dt_z_p, p->dt_logs_q, p->dt_m_p, p->dt_logs_p};
-  for (int d : dts) if (d != EVT_DT_F32 && d != EVT_DT_BF16) return EVT_EINVAL;
+  for (int d : dts) if (d != EVT_DT_F32 && d != EVT_DT_HALF) return EVT_EINVAL;
   a.zp = zp; a.lq = lq; a.mp = mp; a.lp = lp;
   a.dzp = a.dlq = a.dmp = a.dlp = nullptr;
   a.dt_zp = dts[0]; a.dt_lq = dts[1]; a.dt_mp = dts[2]; a.dt_lp = dts[3];

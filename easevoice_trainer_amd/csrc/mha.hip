@@ -60,22 +60,22 @@ __device__ __forceinline__ float drop_mult(const RP& p, unsigned row, int kj) {
   return mix32(row + (unsigned)kj * 0xC2B2AE35u) >= p.thr ? p.keep_scale : 0.f;
 }
 
-__device__ __forceinline__ bf16x8 tr2(const bf16_t* p0, const bf16_t* p1) {
+__device__ __forceinline__ h16x8 tr2(const h16_t* p0, const h16_t* p1) {
   const unsigned a0 = (unsigned)(uintptr_t)p0, a1 = (unsigned)(uintptr_t)p1;
   uint2 lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-  union { uint4 u; bf16x8 v; } r;
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return r.v;
 }
-__device__ __forceinline__ bf16x8 pack8(const float* p) {
-  union { bf16x8 v; bf16_t e[8]; } r;
+__device__ __forceinline__ h16x8 pack8(const float* p) {
+  union { h16x8 v; h16_t e[8]; } r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.e[i] = f2bf(p[i]);
+  for (int i = 0; i < 8; ++i) r.e[i] = f2h(p[i]);
   return r.v;
 }
-__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ h16x8 ld8(const h16_t* p) { return *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ int slot32(int g, int e) { return e < 4 ? g * 4 + e : 16 + g * 4 + (e - 4); }
 
 __device__ __forceinline__ float quad_max(float v) {
@@ -99,7 +99,7 @@ constexpr int RB = 17;   // pitch (floats) of the per-query band arrays [16 quer
 
 // stage `nrows` rows of a [.][ld] bf16 matrix (head slice of D columns) into an LDS tile; rows outside [0, limit) -> 0
 template <int D, int PITCH>
-__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long ld, int row0, int nrows, int limit) {
+__device__ __forceinline__ void stage_rows(h16_t* dst, const h16_t* src, long ld, int row0, int nrows, int limit) {
   constexpr int PPR = D / 8;
   for (int i = threadIdx.x; i < nrows * PPR; i += 256) {
     const int r = i / PPR, c8 = i - r * PPR;
@@ -110,10 +110,10 @@ __device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long 
 }
 // the fp32 [R][D] embedding of this head -> bf16 LDS tile of `nrows` rows (rows >= R zero)
 template <int D, int PITCH>
-__device__ __forceinline__ void stage_emb(bf16_t* dst, const float* src, int R, int nrows) {
+__device__ __forceinline__ void stage_emb(h16_t* dst, const float* src, int R, int nrows) {
   for (int i = threadIdx.x; i < nrows * D; i += 256) {
     const int r = i / D, c = i - r * D;
-    dst[r * PITCH + c] = r < R ? f2bf(src[r * D + c]) : (bf16_t)0;
+    dst[r * PITCH + c] = r < R ? f2h(src[r * D + c]) : (h16_t)0;
   }
 }
 
@@ -124,14 +124,14 @@ template <int DK, bool REL>
 __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
   constexpr int D = 32 * DK, PITCH = D + 8, NDT = D / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [64][PITCH]
-  bf16_t* Ks = Qs + 64 * PITCH;                            // [32][PITCH]
-  bf16_t* Vs = Ks + 32 * PITCH;                            // [32][PITCH]
-  bf16_t* Eks = Vs + 32 * PITCH;                           // REL: [16][PITCH]
-  bf16_t* Evs = Eks + 16 * PITCH;                          // REL: [32][PITCH]
+  h16_t* Qs = reinterpret_cast<h16_t*>(smem);            // [64][PITCH]
+  h16_t* Ks = Qs + 64 * PITCH;                            // [32][PITCH]
+  h16_t* Vs = Ks + 32 * PITCH;                            // [32][PITCH]
+  h16_t* Eks = Vs + 32 * PITCH;                           // REL: [16][PITCH]
+  h16_t* Evs = Eks + 16 * PITCH;                          // REL: [32][PITCH]
   float* qe_l = reinterpret_cast<float*>(Evs + 32 * PITCH);   // REL: [4][16][RB]
   float* sb_l = qe_l + 4 * 16 * RB;                        // REL: [4][16][RB] raw band scores
-  bf16_t* rw_l = reinterpret_cast<bf16_t*>(sb_l + 4 * 16 * RB);   // REL: [4][16][40]
+  h16_t* rw_l = reinterpret_cast<h16_t*>(sb_l + 4 * 16 * RB);   // REL: [4][16][40]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
   const int qb0 = blockIdx.x * 64;
   const int lenq = p.lens_q ? min(p.lens_q[b], p.Tq) : p.Tq;
   const int lenk = p.lens_k ? min(p.lens_k[b], p.Tk) : p.Tk;
-  bf16_t* O = (bf16_t*)p.out + (long)b * p.Tq * p.ldo + h * D;
+  h16_t* O = (h16_t*)p.out + (long)b * p.Tq * p.ldo + h * D;
   float* LSE = p.lse + (long)bh * p.Tq;
   if (qb0 >= lenq) {   // block of padded queries: zeros
     for (int i = tid; i < 64 * (D / 8); i += 256) {
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
     if (tid < 64 && qb0 + tid < p.Tq) LSE[qb0 + tid] = 0.f;
     return;
   }
-  const bf16_t* Q = (const bf16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
-  const bf16_t* K = (const bf16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* Q = (const h16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
+  const h16_t* K = (const h16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* V = (const h16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
   const int hr = REL ? h % p.Hr : 0;
   stage_rows<D, PITCH>(Qs, Q, p.ldq, qb0, 64, lenq);
   if constexpr (REL) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
   __syncthreads();
 
   const int q0 = qb0 + wave * 16, qi = q0 + n;
-  bf16x8 qf[DK];
+  h16x8 qf[DK];
 #pragma unroll
   for (int s = 0; s < DK; ++s) qf[s] = ld8(Qs + (wave * 16 + n) * PITCH + s * 32 + g * 8);
   float* qe = qe_l + wave * 16 * RB;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < DK; ++s)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Eks + n * PITCH + s * 32 + g * 8), qf[s], acc, 0, 0, 0);
+      acc = EVT_MFMA_16x16x32(ld8(Eks + n * PITCH + s * 32 + g * 8), qf[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { qe[n * RB + g * 4 + r] = acc[r] * p.scale; sb[n * RB + g * 4 + r] = -INFINITY; }
   }
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < DK; ++s) {
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Ks + n * PITCH + s * 32 + g * 8), qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Ks + (16 + n) * PITCH + s * 32 + g * 8), qf[s], s1, 0, 0, 0);
+      s0 = EVT_MFMA_16x16x32(ld8(Ks + n * PITCH + s * 32 + g * 8), qf[s], s0, 0, 0, 0);
+      s1 = EVT_MFMA_16x16x32(ld8(Ks + (16 + n) * PITCH + s * 32 + g * 8), qf[s], s1, 0, 0, 0);
     }
     const bool band = REL && (k0 <= q0 + 15 + p.w) && (k0 + 31 >= q0 - p.w);   // wave-uniform
     float sc[8];
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) sc[e] *= drop_mult(p, drow, k0 + slot32(g, e));
     }
-    const bf16x8 pf = pack8(sc);
-    const bf16_t* vrow = Vs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16x8 pf = pack8(sc);
+    const h16_t* vrow = Vs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-      ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(vrow + dt * 16, vrow + 16 * PITCH + dt * 16), pf, ot[dt], 0, 0, 0);
+      ot[dt] = EVT_MFMA_16x16x32(tr2(vrow + dt * 16, vrow + 16 * PITCH + dt * 16), pf, ot[dt], 0, 0, 0);
     }
   }
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;      // an item without a single live key: zeros
@@ -239,30 +239,30 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16(RP p) {
   if constexpr (REL) {
     // relative values: the band probabilities with the final statistics, one MFMA step against Ev
     __syncthreads();
-    bf16_t* rw = rw_l + wave * 16 * 40;
+    h16_t* rw = rw_l + wave * 16 * 40;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = g * 4 + r;
       const float s = sb[n * RB + rr];
       float pv = 0.f;
       if (rr < p.R && s > -INFINITY) pv = __expf(s - m_run) * inv * drop_mult(p, drow, qi + rr - p.w);
-      rw[n * 40 + rr] = f2bf(pv);
-      rw[n * 40 + 16 + rr] = (bf16_t)0;
+      rw[n * 40 + rr] = f2h(pv);
+      rw[n * 40 + 16 + rr] = (h16_t)0;
     }
     __syncthreads();
-    const bf16x8 rf = ld8(rw + n * 40 + g * 8);
-    const bf16_t* erow = Evs + (g * 8 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16x8 rf = ld8(rw + n * 40 + g * 8);
+    const h16_t* erow = Evs + (g * 8 + (n >> 2)) * PITCH + 4 * (n & 3);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
-      ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(erow + dt * 16, erow + 4 * PITCH + dt * 16), rf, ot[dt], 0, 0, 0);
+      ot[dt] = EVT_MFMA_16x16x32(tr2(erow + dt * 16, erow + 4 * PITCH + dt * 16), rf, ot[dt], 0, 0, 0);
   }
   if (qi < p.Tq) {
     const bool live = qi < lenq;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      bf16_t o4[4];
+      h16_t o4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = live ? f2bf(ot[dt][r]) : (bf16_t)0;
+      for (int r = 0; r < 4; ++r) o4[r] = live ? f2h(ot[dt][r]) : (h16_t)0;
       *reinterpret_cast<uint2*>(O + (long)qi * p.ldo + dt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
     if (g == 0) LSE[qi] = (live && l_run > 0.f) ? m_run + __logf(l_run) : 0.f;
@@ -276,18 +276,18 @@ template <int DK, bool REL>
 __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
   constexpr int D = 32 * DK, PITCH = D + 8, NDT = D / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);            // [64][PITCH]
-  bf16_t* dOs = Qs + 64 * PITCH;                           // [64][PITCH]
-  bf16_t* Ks = dOs + 64 * PITCH;                           // [32][PITCH]
-  bf16_t* Vs = Ks + 32 * PITCH;                            // [32][PITCH]
+  h16_t* Qs = reinterpret_cast<h16_t*>(smem);            // [64][PITCH]
+  h16_t* dOs = Qs + 64 * PITCH;                           // [64][PITCH]
+  h16_t* Ks = dOs + 64 * PITCH;                           // [32][PITCH]
+  h16_t* Vs = Ks + 32 * PITCH;                            // [32][PITCH]
   float* dl_l = reinterpret_cast<float*>(Vs + 32 * PITCH); // [64] delta
-  bf16_t* Eks = reinterpret_cast<bf16_t*>(dl_l + 64);      // REL: [32][PITCH] (rows >= R zero)
-  bf16_t* Evs = Eks + 32 * PITCH;                          // REL: [16][PITCH]
+  h16_t* Eks = reinterpret_cast<h16_t*>(dl_l + 64);      // REL: [32][PITCH] (rows >= R zero)
+  h16_t* Evs = Eks + 32 * PITCH;                          // REL: [16][PITCH]
   float* qe_l = reinterpret_cast<float*>(Evs + 16 * PITCH);   // REL: [64][RB]
   float* de_l = qe_l + 64 * RB;                            // REL: [64][RB]  dO . Ev[r]
   float* ds_l = de_l + 64 * RB;                            // REL: [64][RB]  dS on the band
   float* pb_l = ds_l + 64 * RB;                            // REL: [64][RB]  dropped P on the band
-  bf16_t* dw_l = reinterpret_cast<bf16_t*>(pb_l + 64 * RB);   // REL: [4][16][40]
+  h16_t* dw_l = reinterpret_cast<h16_t*>(pb_l + 64 * RB);   // REL: [4][16][40]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
   const int qb0 = blockIdx.x * 64;
   const int lenq = p.lens_q ? min(p.lens_q[b], p.Tq) : p.Tq;
   const int lenk = p.lens_k ? min(p.lens_k[b], p.Tk) : p.Tk;
-  bf16_t* dQ = (bf16_t*)p.dq + (long)b * p.Tq * p.ldq + h * D;
+  h16_t* dQ = (h16_t*)p.dq + (long)b * p.Tq * p.ldq + h * D;
   float* DL = p.delta + (long)bh * p.Tq;
   if (qb0 >= lenq) {
     for (int i = tid; i < 64 * (D / 8); i += 256) {
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
     if (tid < 64 && qb0 + tid < p.Tq) DL[qb0 + tid] = 0.f;
     return;
   }
-  const bf16_t* Q = (const bf16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
-  const bf16_t* K = (const bf16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
-  const bf16_t* Og = (const bf16_t*)p.o + (long)b * p.Tq * p.ldo + h * D;
-  const bf16_t* dOg = (const bf16_t*)p.d_o + (long)b * p.Tq * p.ldo + h * D;
+  const h16_t* Q = (const h16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
+  const h16_t* K = (const h16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* V = (const h16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* Og = (const h16_t*)p.o + (long)b * p.Tq * p.ldo + h * D;
+  const h16_t* dOg = (const h16_t*)p.d_o + (long)b * p.Tq * p.ldo + h * D;
   const int hr = REL ? h % p.Hr : 0;
   stage_rows<D, PITCH>(Qs, Q, p.ldq, qb0, 64, lenq);
   stage_rows<D, PITCH>(dOs, dOg, p.ldo, qb0, 64, lenq);
@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
     if (qb0 + r < lenq) {
       for (int c8 = part; c8 < D / 8; c8 += 4) {
         const uint4 ov = *reinterpret_cast<const uint4*>(Og + (long)(qb0 + r) * p.ldo + c8 * 8);
-        const bf16_t* po = reinterpret_cast<const bf16_t*>(&ov);
-        const bf16_t* pd = dOs + r * PITCH + c8 * 8;
+        const h16_t* po = reinterpret_cast<const h16_t*>(&ov);
+        const h16_t* pd = dOs + r * PITCH + c8 * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += bf2f(po[e]) * bf2f(pd[e]);
+        for (int e = 0; e < 8; ++e) acc += h2f(po[e]) * h2f(pd[e]);
       }
     }
     acc += __shfl_xor(acc, 1, 64);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
   }
   const int q0 = qb0 + wave * 16, qi = q0 + n;
   const int ql = wave * 16 + n;       // row inside the block tiles
-  bf16x8 qf[DK], dof[DK];
+  h16x8 qf[DK], dof[DK];
 #pragma unroll
   for (int s = 0; s < DK; ++s) {
     qf[s] = ld8(Qs + ql * PITCH + s * 32 + g * 8);
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < DK; ++s) {
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Eks + n * PITCH + s * 32 + g * 8), qf[s], a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Evs + n * PITCH + s * 32 + g * 8), dof[s], a2, 0, 0, 0);
+      a1 = EVT_MFMA_16x16x32(ld8(Eks + n * PITCH + s * 32 + g * 8), qf[s], a1, 0, 0, 0);
+      a2 = EVT_MFMA_16x16x32(ld8(Evs + n * PITCH + s * 32 + g * 8), dof[s], a2, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { qe_l[ql * RB + g * 4 + r] = a1[r] * p.scale; de_l[ql * RB + g * 4 + r] = a2[r]; }
@@ -371,10 +371,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < DK; ++s) {
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Ks + n * PITCH + s * 32 + g * 8), qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Ks + (16 + n) * PITCH + s * 32 + g * 8), qf[s], s1, 0, 0, 0);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Vs + n * PITCH + s * 32 + g * 8), dof[s], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Vs + (16 + n) * PITCH + s * 32 + g * 8), dof[s], d1, 0, 0, 0);
+      s0 = EVT_MFMA_16x16x32(ld8(Ks + n * PITCH + s * 32 + g * 8), qf[s], s0, 0, 0, 0);
+      s1 = EVT_MFMA_16x16x32(ld8(Ks + (16 + n) * PITCH + s * 32 + g * 8), qf[s], s1, 0, 0, 0);
+      d0 = EVT_MFMA_16x16x32(ld8(Vs + n * PITCH + s * 32 + g * 8), dof[s], d0, 0, 0, 0);
+      d1 = EVT_MFMA_16x16x32(ld8(Vs + (16 + n) * PITCH + s * 32 + g * 8), dof[s], d1, 0, 0, 0);
     }
     const bool band = REL && (k0 <= q0 + 15 + p.w) && (k0 + 31 >= q0 - p.w);
     float ds[8];
@@ -397,34 +397,34 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
       }
       ds[e] = dsv;
     }
-    const bf16x8 dsf = pack8(ds);
-    const bf16_t* krow = Ks + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16x8 dsf = pack8(ds);
+    const h16_t* krow = Ks + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
-      dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(krow + dt * 16, krow + 16 * PITCH + dt * 16), dsf, dqt[dt], 0, 0, 0);
+      dqt[dt] = EVT_MFMA_16x16x32(tr2(krow + dt * 16, krow + 16 * PITCH + dt * 16), dsf, dqt[dt], 0, 0, 0);
   }
   if constexpr (REL) {
     // band part of dQ: dS[i, i+r-w] * Ek[r]
     __syncthreads();
-    bf16_t* dw = dw_l + wave * 16 * 40;
+    h16_t* dw = dw_l + wave * 16 * 40;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      dw[n * 40 + g * 4 + r] = f2bf(ds_l[ql * RB + g * 4 + r]);
-      dw[n * 40 + 16 + g * 4 + r] = (bf16_t)0;
+      dw[n * 40 + g * 4 + r] = f2h(ds_l[ql * RB + g * 4 + r]);
+      dw[n * 40 + 16 + g * 4 + r] = (h16_t)0;
     }
     __syncthreads();
-    const bf16x8 rf = ld8(dw + n * 40 + g * 8);
-    const bf16_t* erow = Eks + (g * 8 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16x8 rf = ld8(dw + n * 40 + g * 8);
+    const h16_t* erow = Eks + (g * 8 + (n >> 2)) * PITCH + 4 * (n & 3);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
-      dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(erow + dt * 16, erow + 4 * PITCH + dt * 16), rf, dqt[dt], 0, 0, 0);
+      dqt[dt] = EVT_MFMA_16x16x32(tr2(erow + dt * 16, erow + 4 * PITCH + dt * 16), rf, dqt[dt], 0, 0, 0);
   }
   if (qi < p.Tq) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      bf16_t o4[4];
+      h16_t o4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = qi < lenq ? f2bf(dqt[dt][r] * p.scale) : (bf16_t)0;
+      for (int r = 0; r < 4; ++r) o4[r] = qi < lenq ? f2h(dqt[dt][r] * p.scale) : (h16_t)0;
       *reinterpret_cast<uint2*>(dQ + (long)qi * p.ldq + dt * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
     }
   }
@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_bf16(RP p) {
       const int r = i / D, c = i - r * D;
       float a1 = 0.f, a2 = 0.f;
       for (int q = 0; q < 64; ++q) {
-        a1 += ds_l[q * RB + r] * bf2f(Qs[q * PITCH + c]);
-        a2 += pb_l[q * RB + r] * bf2f(dOs[q * PITCH + c]);
+        a1 += ds_l[q * RB + r] * h2f(Qs[q * PITCH + c]);
+        a2 += pb_l[q * RB + r] * h2f(dOs[q * PITCH + c]);
       }
       atomicAdd(dek + i, a1 * p.scale);
       atomicAdd(dev + i, a2);
@@ -453,14 +453,14 @@ template <int DK, bool REL>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
   constexpr int D = 32 * DK, PITCH = D + 8, NDT = D / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);            // [64][PITCH]
-  bf16_t* Vs = Ks + 64 * PITCH;                            // [64][PITCH]
-  bf16_t* Qs = Vs + 64 * PITCH;                            // [32][PITCH]
-  bf16_t* dOs = Qs + 32 * PITCH;                           // [32][PITCH]
+  h16_t* Ks = reinterpret_cast<h16_t*>(smem);            // [64][PITCH]
+  h16_t* Vs = Ks + 64 * PITCH;                            // [64][PITCH]
+  h16_t* Qs = Vs + 64 * PITCH;                            // [32][PITCH]
+  h16_t* dOs = Qs + 32 * PITCH;                           // [32][PITCH]
   float* ls_l = reinterpret_cast<float*>(dOs + 32 * PITCH);   // [32] lse
   float* dl_l = ls_l + 32;                                 // [32] delta
-  bf16_t* Eks = reinterpret_cast<bf16_t*>(dl_l + 32);      // REL: [16][PITCH]
-  bf16_t* Evs = Eks + 16 * PITCH;                          // REL: [16][PITCH]
+  h16_t* Eks = reinterpret_cast<h16_t*>(dl_l + 32);      // REL: [16][PITCH]
+  h16_t* Evs = Eks + 16 * PITCH;                          // REL: [16][PITCH]
   float* qe_l = reinterpret_cast<float*>(Evs + 16 * PITCH);   // REL: [32][RB]
   float* de_l = qe_l + 32 * RB;                            // REL: [32][RB]
 
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
   const int kb0 = blockIdx.x * 64;
   const int lenq = p.lens_q ? min(p.lens_q[b], p.Tq) : p.Tq;
   const int lenk = p.lens_k ? min(p.lens_k[b], p.Tk) : p.Tk;
-  bf16_t* dKg = (bf16_t*)p.dk + (long)b * p.Tk * p.ldk + h * D;
-  bf16_t* dVg = (bf16_t*)p.dv + (long)b * p.Tk * p.ldk + h * D;
+  h16_t* dKg = (h16_t*)p.dk + (long)b * p.Tk * p.ldk + h * D;
+  h16_t* dVg = (h16_t*)p.dv + (long)b * p.Tk * p.ldk + h * D;
   if (kb0 >= lenk) {
     for (int i = tid; i < 64 * (D / 8); i += 256) {
       const int r = i / (D / 8), c8 = i - r * (D / 8);
@@ -482,10 +482,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
     }
     return;
   }
-  const bf16_t* Q = (const bf16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
-  const bf16_t* K = (const bf16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
-  const bf16_t* dOg = (const bf16_t*)p.d_o + (long)b * p.Tq * p.ldo + h * D;
+  const h16_t* Q = (const h16_t*)p.q + (long)b * p.Tq * p.ldq + h * D;
+  const h16_t* K = (const h16_t*)p.k + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* V = (const h16_t*)p.v + (long)b * p.Tk * p.ldk + h * D;
+  const h16_t* dOg = (const h16_t*)p.d_o + (long)b * p.Tq * p.ldo + h * D;
   const int hr = REL ? h % p.Hr : 0;
   stage_rows<D, PITCH>(Ks, K, p.ldk, kb0, 64, lenk);
   stage_rows<D, PITCH>(Vs, V, p.ldk, kb0, 64, lenk);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
   }
   __syncthreads();
   const int k0w = kb0 + wave * 16, kj = k0w + n;     // my key (MFMA column)
-  bf16x8 kf[DK], vf[DK];
+  h16x8 kf[DK], vf[DK];
 #pragma unroll
   for (int s = 0; s < DK; ++s) {
     kf[s] = ld8(Ks + (wave * 16 + n) * PITCH + s * 32 + g * 8);
@@ -521,11 +521,11 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
     if constexpr (REL) {
       if (band) {
         const int tl = wave & 1;
-        const bf16_t* As = (wave < 2 ? Qs : dOs) + (tl * 16 + n) * PITCH + g * 8;      // A: m = query
-        const bf16_t* Bs = (wave < 2 ? Eks : Evs) + n * PITCH + g * 8;                  // B: n = offset r
+        const h16_t* As = (wave < 2 ? Qs : dOs) + (tl * 16 + n) * PITCH + g * 8;      // A: m = query
+        const h16_t* Bs = (wave < 2 ? Eks : Evs) + n * PITCH + g * 8;                  // B: n = offset r
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < DK; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(As + s * 32), ld8(Bs + s * 32), acc, 0, 0, 0);
+        for (int s = 0; s < DK; ++s) acc = EVT_MFMA_16x16x32(ld8(As + s * 32), ld8(Bs + s * 32), acc, 0, 0, 0);
         float* dst = wave < 2 ? qe_l : de_l;          // result: lane (n = r, g) holds query tl*16 + g*4 + rr
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[(tl * 16 + g * 4 + r) * RB + n] = wave < 2 ? acc[r] * p.scale : acc[r];
@@ -535,10 +535,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < DK; ++s) {
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Qs + n * PITCH + s * 32 + g * 8), kf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(Qs + (16 + n) * PITCH + s * 32 + g * 8), kf[s], s1, 0, 0, 0);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(dOs + n * PITCH + s * 32 + g * 8), vf[s], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld8(dOs + (16 + n) * PITCH + s * 32 + g * 8), vf[s], d1, 0, 0, 0);
+      s0 = EVT_MFMA_16x16x32(ld8(Qs + n * PITCH + s * 32 + g * 8), kf[s], s0, 0, 0, 0);
+      s1 = EVT_MFMA_16x16x32(ld8(Qs + (16 + n) * PITCH + s * 32 + g * 8), kf[s], s1, 0, 0, 0);
+      d0 = EVT_MFMA_16x16x32(ld8(dOs + n * PITCH + s * 32 + g * 8), vf[s], d0, 0, 0, 0);
+      d1 = EVT_MFMA_16x16x32(ld8(dOs + (16 + n) * PITCH + s * 32 + g * 8), vf[s], d1, 0, 0, 0);
     }
     float pd[8], ds[8];
 #pragma unroll
@@ -556,24 +556,24 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_bf16(RP p) {
       pd[e] = pr * mult;
       ds[e] = pr * (dp * mult - dl_l[qloc]);
     }
-    const bf16x8 pf = pack8(pd), dsf = pack8(ds);
-    const bf16_t* orow = dOs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
-    const bf16_t* qrow = Qs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16x8 pf = pack8(pd), dsf = pack8(ds);
+    const h16_t* orow = dOs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
+    const h16_t* qrow = Qs + (g * 4 + (n >> 2)) * PITCH + 4 * (n & 3);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(orow + dt * 16, orow + 16 * PITCH + dt * 16), pf, dvt[dt], 0, 0, 0);
-      dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr2(qrow + dt * 16, qrow + 16 * PITCH + dt * 16), dsf, dkt[dt], 0, 0, 0);
+      dvt[dt] = EVT_MFMA_16x16x32(tr2(orow + dt * 16, orow + 16 * PITCH + dt * 16), pf, dvt[dt], 0, 0, 0);
+      dkt[dt] = EVT_MFMA_16x16x32(tr2(qrow + dt * 16, qrow + 16 * PITCH + dt * 16), dsf, dkt[dt], 0, 0, 0);
     }
   }
   if (kj < p.Tk) {
     const bool live = kj < lenk;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      bf16_t k4[4], v4[4];
+      h16_t k4[4], v4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        k4[r] = live ? f2bf(dkt[dt][r] * p.scale) : (bf16_t)0;
-        v4[r] = live ? f2bf(dvt[dt][r]) : (bf16_t)0;
+        k4[r] = live ? f2h(dkt[dt][r] * p.scale) : (h16_t)0;
+        v4[r] = live ? f2h(dvt[dt][r]) : (h16_t)0;
       }
       *reinterpret_cast<uint2*>(dKg + (long)kj * p.ldk + dt * 16 + g * 4) = *reinterpret_cast<uint2*>(k4);
       *reinterpret_cast<uint2*>(dVg + (long)kj * p.ldk + dt * 16 + g * 4) = *reinterpret_cast<uint2*>(v4);
@@ -789,8 +789,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_f32(RP p, int tqp) {
 
 int check(const evt_mha_params* a) {
   if (!a || a->B <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->H <= 0 || a->D <= 0) return EVT_EINVAL;
-  if (a->dtype != EVT_DT_BF16 && a->dtype != EVT_DT_F32) return EVT_EINVAL;
-  if (a->dtype == EVT_DT_BF16 ? (a->D % 32 != 0) : (a->D % 4 != 0)) return EVT_ENOTSUP;
+  if (a->dtype != EVT_DT_HALF && a->dtype != EVT_DT_F32) return EVT_EINVAL;
+  if (a->dtype == EVT_DT_HALF ? (a->D % 32 != 0) : (a->D % 4 != 0)) return EVT_ENOTSUP;
   if (a->D > 128) return EVT_ENOTSUP;
   if (a->window >= 0) {
     if (2 * a->window + 1 > 16) return EVT_ENOTSUP;
@@ -798,7 +798,7 @@ int check(const evt_mha_params* a) {
   }
   const int64_t hd = (int64_t)a->H * a->D;
   if (a->ldq < hd || a->ldk < hd || a->ldo < hd) return EVT_EINVAL;
-  const int al = a->dtype == EVT_DT_BF16 ? 8 : 4;                      // 16-byte row pieces
+  const int al = a->dtype == EVT_DT_HALF ? 8 : 4;                      // 16-byte row pieces
   if (a->ldq % al || a->ldk % al || a->ldo % al) return EVT_EINVAL;
   if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return EVT_EINVAL;
   if (!(a->scale > 0.f)) return EVT_EINVAL;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void mpd_fold_kernel(FoldP p) {
     const bool second = b >= p.n0;
     const void* s = second ? p.src1 : p.src0;
     const long at = (long)(second ? b - p.n0 : b) * p.T + t;
-    const float v = (second ? p.bf1 : p.bf0) ? bf2f(reinterpret_cast<const bf16_t*>(s)[at])
+    const float v = (second ? p.bf1 : p.bf0) ? h2f(reinterpret_cast<const h16_t*>(s)[at])
                                              : reinterpret_cast<const float*>(s)[at];
     reinterpret_cast<TO*>(p.out[i])[r] = from_f<TO>(v);
   }
@@ -92,11 +92,11 @@ int evt_mpd_fold(int32_t src0_dtype, const void* src0, int32_t n0, int32_t src1_
                  const int32_t* periods, int32_t nper, void* const* outs, int32_t out_dtype, void* stream) {
   if (!src0 || n0 <= 0 || n1 < 0 || (n1 > 0 && !src1) || T < 2 || !periods || !outs || nper <= 0 || nper > MAXP)
     return EVT_EINVAL;
-  if ((src0_dtype != EVT_DT_F32 && src0_dtype != EVT_DT_BF16) || (n1 > 0 && src1_dtype != EVT_DT_F32 && src1_dtype != EVT_DT_BF16))
+  if ((src0_dtype != EVT_DT_F32 && src0_dtype != EVT_DT_HALF) || (n1 > 0 && src1_dtype != EVT_DT_F32 && src1_dtype != EVT_DT_HALF))
     return EVT_EINVAL;
   FoldP p{};
   p.src0 = src0; p.src1 = src1; p.n0 = n0; p.n1 = n1; p.T = T; p.nper = nper;
-  p.bf0 = src0_dtype == EVT_DT_BF16; p.bf1 = src1_dtype == EVT_DT_BF16;
+  p.bf0 = src0_dtype == EVT_DT_HALF; p.bf1 = src1_dtype == EVT_DT_HALF;
   long at = 0;
   for (int i = 0; i < nper; ++i) {
     if (periods[i] < 1 || periods[i] >= T || !outs[i]) return EVT_EINVAL;
@@ -109,7 +109,7 @@ int evt_mpd_fold(int32_t src0_dtype, const void* src0, int32_t n0, int32_t src1_
   const dim3 g(grid_for(at)), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == EVT_DT_F32) hipLaunchKernelGGL((mpd_fold_kernel<float>), g, b, 0, st, p);
-  else if (out_dtype == EVT_DT_BF16) hipLaunchKernelGGL((mpd_fold_kernel<bf16_t>), g, b, 0, st, p);
+  else if (out_dtype == EVT_DT_HALF) hipLaunchKernelGGL((mpd_fold_kernel<h16_t>), g, b, 0, st, p);
   else return EVT_EINVAL;
   return evt_check_launch();
 }
@@ -127,9 +127,9 @@ int evt_mpd_unfold(int32_t grad_dtype, const void* const* douts, const int32_t* 
   const dim3 g(grid_for((long)n * T)), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (grad_dtype == EVT_DT_F32 && dsrc_dtype == EVT_DT_F32) hipLaunchKernelGGL((mpd_unfold_kernel<float, float>), g, b, 0, st, p);
-  else if (grad_dtype == EVT_DT_BF16 && dsrc_dtype == EVT_DT_BF16) hipLaunchKernelGGL((mpd_unfold_kernel<bf16_t, bf16_t>), g, b, 0, st, p);
-  else if (grad_dtype == EVT_DT_BF16 && dsrc_dtype == EVT_DT_F32) hipLaunchKernelGGL((mpd_unfold_kernel<bf16_t, float>), g, b, 0, st, p);
-  else if (grad_dtype == EVT_DT_F32 && dsrc_dtype == EVT_DT_BF16) hipLaunchKernelGGL((mpd_unfold_kernel<float, bf16_t>), g, b, 0, st, p);
+  else if (grad_dtype == EVT_DT_HALF && dsrc_dtype == EVT_DT_HALF) hipLaunchKernelGGL((mpd_unfold_kernel<h16_t, h16_t>), g, b, 0, st, p);
+  else if (grad_dtype == EVT_DT_HALF && dsrc_dtype == EVT_DT_F32) hipLaunchKernelGGL((mpd_unfold_kernel<h16_t, float>), g, b, 0, st, p);
+  else if (grad_dtype == EVT_DT_F32 && dsrc_dtype == EVT_DT_HALF) hipLaunchKernelGGL((mpd_unfold_kernel<float, h16_t>), g, b, 0, st, p);
   else return EVT_EINVAL;
   return evt_check_launch();
 }

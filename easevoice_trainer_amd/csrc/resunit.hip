@@ -26,8 +26,8 @@ namespace {
 using namespace evt_ru;
 
 struct RUP {
-  const bf16_t* x; const bf16_t* w1; const bf16_t* w2; const float* b1; const float* b2;
-  bf16_t* xa; bf16_t* mid; bf16_t* y;
+  const h16_t* x; const h16_t* w1; const h16_t* w2; const float* b1; const float* b2;
+  h16_t* xa; h16_t* mid; h16_t* y;
   int nseq, L, k, dil;
   float slope;
   int xrows;            // staged input rows per unit
@@ -73,7 +73,7 @@ __device__ __forceinline__ void resunit_fwd_body(const RUP& p, unsigned char* sm
   auto load_unit = [&](long u) {
     const int seq = (int)(u / p.ups);
     const int row0 = (int)(u - (long)seq * p.ups) * 64 - H2 - h1;
-    const bf16_t* xg = p.x + (long)seq * p.L * CI;
+    const h16_t* xg = p.x + (long)seq * p.L * CI;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int idx = lane + i * 64;
@@ -122,12 +122,12 @@ __device__ __forceinline__ void resunit_fwd_body(const RUP& p, unsigned char* sm
         const bool inside = m >= 0 && m < p.L;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          bf16_t o4[4];
+          h16_t o4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[i][j][r] + b1[i][r];
             v = v > 0.f ? v : v * p.slope;
-            o4[r] = f2bf(inside ? v : 0.f);
+            o4[r] = f2h(inside ? v : 0.f);
           }
           *reinterpret_cast<uint2*>(ms + chan_off<CI>(pos, i * 16 + g * 4)) = *reinterpret_cast<uint2*>(o4);
           if (p.mid && inside && pos >= H2 && pos < H2 + 64)
@@ -161,10 +161,10 @@ __device__ __forceinline__ void resunit_fwd_body(const RUP& p, unsigned char* sm
         if (q >= p.L) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const bf16_t* pr = reinterpret_cast<const bf16_t*>(&rv[j][i]);
-          bf16_t o4[4];
+          const h16_t* pr = reinterpret_cast<const h16_t*>(&rv[j][i]);
+          h16_t o4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(acc[i][j][r] + b2[i][r] + bf2f(pr[r]));
+          for (int r = 0; r < 4; ++r) o4[r] = f2h(acc[i][j][r] + b2[i][r] + h2f(pr[r]));
           *reinterpret_cast<uint2*>(p.y + sbase + (long)q * CI + i * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
         }
       }
@@ -233,7 +233,7 @@ int launch(const RUP& p, size_t lds, hipStream_t st) {
 }
 
 bool job_ok(const evt_resunit_params* a) {
-  if (!a || a->dtype != EVT_DT_BF16) return false;
+  if (!a || a->dtype != EVT_DT_HALF) return false;
   if (a->C != 16 && a->C != 32) return false;
   if (a->k != 3 && a->k != 7 && a->k != 11) return false;
   if (a->dil < 1 || a->dil > 5 || a->nseq <= 0 || a->L < 64) return false;
@@ -254,8 +254,8 @@ int evt_resunit_fwd(const evt_resunit_params* a, const void* x, const void* w1_r
   if (!evt_resunit_supported(a)) return EVT_ENOTSUP;
   if (!x || !w1_reg || !w2_reg || !y) return EVT_EINVAL;
   RUP p{};
-  p.x = (const bf16_t*)x; p.w1 = (const bf16_t*)w1_reg; p.w2 = (const bf16_t*)w2_reg; p.b1 = b1; p.b2 = b2;
-  p.xa = (bf16_t*)xa; p.mid = (bf16_t*)mid_a; p.y = (bf16_t*)y;
+  p.x = (const h16_t*)x; p.w1 = (const h16_t*)w1_reg; p.w2 = (const h16_t*)w2_reg; p.b1 = b1; p.b2 = b2;
+  p.xa = (h16_t*)xa; p.mid = (h16_t*)mid_a; p.y = (h16_t*)y;
   p.nseq = a->nseq; p.L = a->L; p.k = a->k; p.dil = a->dil; p.slope = a->slope;
   const size_t lds = fwd_geometry(p, a->C);
   if (!lds) return EVT_ENOTSUP;
@@ -285,8 +285,8 @@ int evt_resunit_fwd_multi(const evt_resunit_fwd_job* jobs, int32_t njobs, void* 
     const int slot = jb.p.k == 3 ? 0 : (jb.p.k == 7 ? 1 : 2);
     if (cost[slot] != 0) return EVT_ENOTSUP;              // one job per kernel size
     RUP& p = pm.job[slot];
-    p.x = (const bf16_t*)jb.x; p.w1 = (const bf16_t*)jb.w1_reg; p.w2 = (const bf16_t*)jb.w2_reg; p.b1 = jb.b1; p.b2 = jb.b2;
-    p.xa = (bf16_t*)jb.xa; p.mid = (bf16_t*)jb.mid_a; p.y = (bf16_t*)jb.y;
+    p.x = (const h16_t*)jb.x; p.w1 = (const h16_t*)jb.w1_reg; p.w2 = (const h16_t*)jb.w2_reg; p.b1 = jb.b1; p.b2 = jb.b2;
+    p.xa = (h16_t*)jb.xa; p.mid = (h16_t*)jb.mid_a; p.y = (h16_t*)jb.y;
     p.nseq = jb.p.nseq; p.L = jb.p.L; p.k = jb.p.k; p.dil = jb.p.dil; p.slope = jb.p.slope;
     const size_t l = fwd_geometry(p, C);
     if (!l) return EVT_ENOTSUP;

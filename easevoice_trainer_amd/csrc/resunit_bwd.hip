@@ -41,8 +41,8 @@ namespace {
 using namespace evt_ru;
 
 struct RBP {
-  const bf16_t* dy; const bf16_t* xa; const bf16_t* mid; const bf16_t* w1; const bf16_t* w2;   // w: ALT images
-  bf16_t* dx; bf16_t* dmid;          // dmid: optional copy of the unit's own rows of dmid (null: not written)
+  const h16_t* dy; const h16_t* xa; const h16_t* mid; const h16_t* w1; const h16_t* w2;   // w: ALT images
+  h16_t* dx; h16_t* dmid;          // dmid: optional copy of the unit's own rows of dmid (null: not written)
   float* part; long part_stride;     // partial rows (one per block) or null: no weight gradients
   int nseq, L, dil;
   float slope, dy_scale;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void wgrad_conv(f32x4 (&acc)[MT][KR][MT], float (&bs)
       if (t == H2) bs[a] += sum8(fa[s % D][a]);
 #pragma unroll
       for (int b = 0; b < MT; ++b)
-        acc[a][t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(fa[s % D][a]), as_bf(bq[ks][b]), acc[a][t][b], 0, 0, 0);
+        acc[a][t][b] = EVT_MFMA_16x16x32(as_h8(fa[s % D][a]), as_h8(bq[ks][b]), acc[a][t][b], 0, 0, 0);
     }
     if (s + D < S) issue(s + D);
   }
@@ -228,14 +228,14 @@ __device__ __forceinline__ void resunit_bwd_body(const RBP& p, unsigned char* sm
         const bool inside = pos >= 0 && pos < p.L && m < 64 + 2 * h1;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const float g0 = __uint_as_float(gv[j][i][0] << 16), g1 = __uint_as_float(gv[j][i][0] & 0xFFFF0000u);
-          const float g2 = __uint_as_float(gv[j][i][1] << 16), g3 = __uint_as_float(gv[j][i][1] & 0xFFFF0000u);
+          const float g0 = h2f_lo(gv[j][i][0]), g1 = h2f_hi(gv[j][i][0]);
+          const float g2 = h2f_lo(gv[j][i][1]), g3 = h2f_hi(gv[j][i][1]);
           const float gg[4] = {g0, g1, g2, g3};
-          bf16_t o4[4];
+          h16_t o4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope);
-            o4[r] = f2bf(inside ? v : 0.f);
+            o4[r] = f2h(inside ? v : 0.f);
           }
           *reinterpret_cast<uint2*>(dml + chan_off<CI>(m, i * 16 + g * 4)) = *reinterpret_cast<uint2*>(o4);
           if (p.dmid && inside && m >= h1 && m < h1 + 64)
@@ -276,13 +276,13 @@ __device__ __forceinline__ void resunit_bwd_body(const RBP& p, unsigned char* sm
         if (q >= p.L) continue;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const float gg[4] = {__uint_as_float(gv[j][i][0] << 16), __uint_as_float(gv[j][i][0] & 0xFFFF0000u),
-                               __uint_as_float(gv[j][i][1] << 16), __uint_as_float(gv[j][i][1] & 0xFFFF0000u)};
-          const float dd[4] = {__uint_as_float(dv[j][i][0] << 16), __uint_as_float(dv[j][i][0] & 0xFFFF0000u),
-                               __uint_as_float(dv[j][i][1] << 16), __uint_as_float(dv[j][i][1] & 0xFFFF0000u)};
-          bf16_t o4[4];
+          const float gg[4] = {h2f_lo(gv[j][i][0]), h2f_hi(gv[j][i][0]),
+                               h2f_lo(gv[j][i][1]), h2f_hi(gv[j][i][1])};
+          const float dd[4] = {h2f_lo(dv[j][i][0]), h2f_hi(dv[j][i][0]),
+                               h2f_lo(dv[j][i][1]), h2f_hi(dv[j][i][1])};
+          h16_t o4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) + dd[r]);
+          for (int r = 0; r < 4; ++r) o4[r] = f2h(acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) + dd[r]);
           *reinterpret_cast<uint2*>(p.dx + sbase + (long)q * CI + i * 16 + g * 4) = *reinterpret_cast<uint2*>(o4);
         }
       }
@@ -518,8 +518,8 @@ int evt_resunit_bwd_multi(const evt_resunit_bwd_job* jobs, int32_t njobs, float*
     Geo geo;
     geometry(C, jb.p.k, jb.p.dil, wg, &geo);
     RBP& p = pm.job[slot];
-    p.dy = (const bf16_t*)jb.dy; p.xa = (const bf16_t*)jb.xa; p.mid = (const bf16_t*)jb.mid_a;
-    p.w1 = (const bf16_t*)jb.w1_alt; p.w2 = (const bf16_t*)jb.w2_alt; p.dx = (bf16_t*)jb.dx; p.dmid = (bf16_t*)jb.dmid;
+    p.dy = (const h16_t*)jb.dy; p.xa = (const h16_t*)jb.xa; p.mid = (const h16_t*)jb.mid_a;
+    p.w1 = (const h16_t*)jb.w1_alt; p.w2 = (const h16_t*)jb.w2_alt; p.dx = (h16_t*)jb.dx; p.dmid = (h16_t*)jb.dmid;
     p.nseq = jb.p.nseq; p.L = jb.p.L; p.dil = jb.p.dil; p.slope = jb.p.slope; p.dy_scale = jb.dy_scale;
     p.ups = (jb.p.L + 63) / 64;
     p.total = (long)jb.p.nseq * p.ups;

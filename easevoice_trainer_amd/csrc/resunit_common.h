@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ __forceinline__ void tie(u32x4& v) { asm volatile("" : "+v"(v)::"memory"); }
 __device__ __forceinline__ void tie(u32x2& v) { asm volatile("" : "+v"(v)::"memory"); }
-__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ h16x8 as_h8(const u32x4& v) { return __builtin_bit_cast(h16x8, v); }
 
 // byte offset of the 16-byte piece `pc` of row `row` inside a region
 template <int CI> __device__ __forceinline__ int piece_off(int row, int pc) {
@@ -58,22 +58,22 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* p) {
 __device__ __forceinline__ float sum8(const u32x4& v) {          // sum of the eight bf16 of a fragment
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s += __uint_as_float(v[i] << 16) + __uint_as_float(v[i] & 0xFFFF0000u);
+  for (int i = 0; i < 4; ++i) s += h2f_lo(v[i]) + h2f_hi(v[i]);
   return s;
 }
 
 __device__ __forceinline__ uint32_t lrelu2(uint32_t d, float slope) {      // two packed bf16
-  float a = __uint_as_float(d << 16), b = __uint_as_float(d & 0xFFFF0000u);
+  float a = h2f_lo(d), b = h2f_hi(d);
   a = a > 0.f ? a : a * slope;
   b = b > 0.f ? b : b * slope;
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  return f2h_pack(a, b);
 }
 __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope) {
   return make_uint4(lrelu2(v.x, slope), lrelu2(v.y, slope), lrelu2(v.z, slope), lrelu2(v.w, slope));
 }
 __device__ __forceinline__ uint32_t scale2(uint32_t d, float s) {      // two packed bf16 times s
-  const float a = __uint_as_float(d << 16) * s, b = __uint_as_float(d & 0xFFFF0000u) * s;
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  const float a = h2f_lo(d) * s, b = h2f_hi(d) * s;
+  return f2h_pack(a, b);
 }
 __device__ __forceinline__ uint4 scale8(uint4 v, float s) {
   return make_uint4(scale2(v.x, s), scale2(v.y, s), scale2(v.z, s), scale2(v.w, s));
@@ -111,13 +111,13 @@ __device__ __forceinline__ void conv_stage(f32x4 (&acc)[MT][NT], const unsigned 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(fa[s][i]), as_bf(fb[s][j]), acc[i][j], 0, 0, 0);
+        acc[i][j] = EVT_MFMA_16x16x32(as_h8(fa[s][i]), as_h8(fb[s][j]), acc[i][j], 0, 0, 0);
   }
 }
 
 // both weight images of a unit (prepared [rows = CI][KTOT] bf16) -> LDS, pitch KTOT * 2 + 16 bytes; whole block
 template <int CI, int KTOT>
-__device__ __forceinline__ void load_weights(unsigned char* wl1, unsigned char* wl2, const bf16_t* w1, const bf16_t* w2) {
+__device__ __forceinline__ void load_weights(unsigned char* wl1, unsigned char* wl2, const h16_t* w1, const h16_t* w2) {
   constexpr int WPITCH = KTOT * 2 + 16;
   for (int idx = threadIdx.x; idx < CI * (KTOT / 8); idx += 256) {
     const int co = idx / (KTOT / 8), part = idx - co * (KTOT / 8);

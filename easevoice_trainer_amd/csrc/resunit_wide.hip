@@ -29,14 +29,14 @@ namespace {
 using namespace evt_ru;
 
 struct WUP {
-  const bf16_t* in;      // forward: x (leaky-relu applied on load); backward: dy
-  const bf16_t* g1;      // backward: mid_a (gate of the first convolution's output); forward: null
-  const bf16_t* g2;      // backward: xa (gate of the second convolution's output); forward: null
-  const bf16_t* wA; const bf16_t* wB;   // images of the first / second convolution (fwd: REG1, REG2; bwd: ALT2, ALT1)
+  const h16_t* in;      // forward: x (leaky-relu applied on load); backward: dy
+  const h16_t* g1;      // backward: mid_a (gate of the first convolution's output); forward: null
+  const h16_t* g2;      // backward: xa (gate of the second convolution's output); forward: null
+  const h16_t* wA; const h16_t* wB;   // images of the first / second convolution (fwd: REG1, REG2; bwd: ALT2, ALT1)
   const float* bA; const float* bB;     // forward biases; backward null
-  bf16_t* in_act;        // forward: xa = lrelu(x) out (own rows) or null
-  bf16_t* outA;          // forward: mid_a, backward: dmid (own rows) or null
-  bf16_t* outB;          // forward: y, backward: dx
+  h16_t* in_act;        // forward: xa = lrelu(x) out (own rows) or null
+  h16_t* outA;          // forward: mid_a, backward: dmid (own rows) or null
+  h16_t* outB;          // forward: y, backward: dx
   int nseq, L, k, dilA, dilB;
   float slope, in_scale;
   int tps;               // tiles per sequence
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
     }
 
   // one cooperative pass: `rows` rows of `src` starting at position pos0 -> region `dst` (zero outside the sequence)
-  auto stage = [&](const bf16_t* src, unsigned char* dst, const int rows, const int pos0, auto xform) {
+  auto stage = [&](const h16_t* src, unsigned char* dst, const int rows, const int pos0, auto xform) {
     const int npieces = rows * SPR;
     for (int base = 0; base < npieces; base += 256 * 8) {
       uint4 v[8];
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
   // flight per block; deeper rings measured alike, see evt_resunit_wide_fwd); K steps behind the last one re-load the last
   // fragment (clamped index) so that no load sits behind a branch
   u32x4 fa[R][MTW];
-  const bf16_t* wrow[MTW];
-  auto set_w = [&](const bf16_t* w) {
+  const h16_t* wrow[MTW];
+  auto set_w = [&](const h16_t* w) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) wrow[i] = w + (long)((wm * MTW + i) * 16 + n) * ktot + g * 8;
   };
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) fa[s][i] = *reinterpret_cast<const u32x4*>(wrow[i] + kc * 32);
   };
-  auto prologue_a = [&](const bf16_t* w) {
+  auto prologue_a = [&](const h16_t* w) {
     set_w(w);
 #pragma unroll
     for (int i = 0; i < R - 2; ++i) issue_a(i, i);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
         tie(fb[j]);
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(fa[sa][i]), as_bf(fb[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = EVT_MFMA_16x16x32(as_h8(fa[sa][i]), as_h8(fb[j]), acc[i][j], 0, 0, 0);
         fb[j] = *reinterpret_cast<const u32x4*>(nb + j * 16 * PITCH);
       }
     };
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
       if (i < rest) step(i);
   };
   auto unpack4 = [](const u32x2 v, float (&o)[4]) {
-    o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xFFFF0000u);
-    o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xFFFF0000u);
+    o[0] = h2f_lo(v[0]); o[1] = h2f_hi(v[0]);
+    o[2] = h2f_lo(v[1]); o[3] = h2f_hi(v[1]);
   };
 
   prologue_a(p.wA);
@@ -223,18 +223,18 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
       for (int i = 0; i < MTW; ++i) {
         const int c = (wm * MTW + i) * 16 + g * 4;
         unsigned char* mp = ms + m * PITCH + wslot<C>(m, c >> 3) * 16 + (c & 7) * 2;
-        bf16_t o4[4];
+        h16_t o4[4];
         if constexpr (BWD) {
           float gg[4];
           unpack4(*reinterpret_cast<const u32x2*>(mp), gg);          // mid_a, staged where dmid goes
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(inside ? acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) : 0.f);
+          for (int r = 0; r < 4; ++r) o4[r] = f2h(inside ? acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) : 0.f);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[i][j][r] + biasA[i][r];
             v = v > 0.f ? v : v * p.slope;
-            o4[r] = f2bf(inside ? v : 0.f);
+            o4[r] = f2h(inside ? v : 0.f);
           }
         }
         *reinterpret_cast<uint2*>(mp) = *reinterpret_cast<uint2*>(o4);
@@ -263,18 +263,18 @@ __global__ __launch_bounds__(256, 2) void resunit_wide(WUP p) {
       for (int i = 0; i < MTW; ++i) {
         const int c = (wm * MTW + i) * 16 + g * 4;
         float rr[4];
-        bf16_t o4[4];
+        h16_t o4[4];
         if constexpr (BWD) {
           float gg[4];
           const int r0 = hA + hB + o;                                // the (scaled) dy row of this position
           unpack4(*reinterpret_cast<const u32x2*>(xs + r0 * PITCH + wslot<C>(r0, c >> 3) * 16 + (c & 7) * 2), rr);
           unpack4(*reinterpret_cast<const u32x2*>(rs + o * PITCH + wslot<C>(o, c >> 3) * 16 + (c & 7) * 2), gg);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) + rr[r]);
+          for (int r = 0; r < 4; ++r) o4[r] = f2h(acc[i][j][r] * (gg[r] > 0.f ? 1.f : p.slope) + rr[r]);
         } else {
           unpack4(*reinterpret_cast<const u32x2*>(rs + o * PITCH + wslot<C>(o, c >> 3) * 16 + (c & 7) * 2), rr);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(acc[i][j][r] + biasB[i][r] + rr[r]);
+          for (int r = 0; r < 4; ++r) o4[r] = f2h(acc[i][j][r] + biasB[i][r] + rr[r]);
         }
         *reinterpret_cast<uint2*>(p.outB + sbase + (long)q * C + c) = *reinterpret_cast<uint2*>(o4);
       }
@@ -307,7 +307,7 @@ int launch(WUP p, hipStream_t st) {
 }
 
 bool wide_ok(const evt_resunit_params* a) {
-  if (!a || a->dtype != EVT_DT_BF16) return false;
+  if (!a || a->dtype != EVT_DT_HALF) return false;
   if (a->C != 64 && a->C != 128) return false;
   if (a->k != 3 && a->k != 7 && a->k != 11) return false;
   if (a->dil < 1 || a->dil > 5 || a->nseq <= 0 || a->L < 64) return false;
@@ -328,8 +328,8 @@ int evt_resunit_wide_fwd(const evt_resunit_params* a, const void* x, const void*
   if (!evt_resunit_wide_supported(a)) return EVT_ENOTSUP;
   if (!x || !w1_reg || !w2_reg || !y) return EVT_EINVAL;
   WUP p{};
-  p.in = (const bf16_t*)x; p.wA = (const bf16_t*)w1_reg; p.wB = (const bf16_t*)w2_reg; p.bA = b1; p.bB = b2;
-  p.in_act = (bf16_t*)xa; p.outA = (bf16_t*)mid_a; p.outB = (bf16_t*)y;
+  p.in = (const h16_t*)x; p.wA = (const h16_t*)w1_reg; p.wB = (const h16_t*)w2_reg; p.bA = b1; p.bB = b2;
+  p.in_act = (h16_t*)xa; p.outA = (h16_t*)mid_a; p.outB = (h16_t*)y;
   p.nseq = a->nseq; p.L = a->L; p.k = a->k; p.dilA = a->dil; p.dilB = 1; p.slope = a->slope; p.in_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   // Tile shape, measured on the B = 16 shapes (us per launch, k = 3 / 7 / 11; tools/bench_resunit.py --wide-fwd):
@@ -353,9 +353,9 @@ int evt_resunit_wide_bwd_data(const evt_resunit_params* a, const void* dy, float
   if (!evt_resunit_wide_supported(a)) return EVT_ENOTSUP;
   if (!dy || !xa || !mid_a || !w1_alt || !w2_alt || !dx) return EVT_EINVAL;
   WUP p{};
-  p.in = (const bf16_t*)dy; p.g1 = (const bf16_t*)mid_a; p.g2 = (const bf16_t*)xa;
-  p.wA = (const bf16_t*)w2_alt; p.wB = (const bf16_t*)w1_alt;
-  p.outA = (bf16_t*)dmid; p.outB = (bf16_t*)dx;
+  p.in = (const h16_t*)dy; p.g1 = (const h16_t*)mid_a; p.g2 = (const h16_t*)xa;
+  p.wA = (const h16_t*)w2_alt; p.wB = (const h16_t*)w1_alt;
+  p.outA = (h16_t*)dmid; p.outB = (h16_t*)dx;
   p.nseq = a->nseq; p.L = a->L; p.k = a->k; p.dilA = 1; p.dilB = a->dil; p.slope = a->slope; p.in_scale = dy_scale;
   hipStream_t st = (hipStream_t)stream;
   const int need = 2 * a->dil * ((a->k - 1) / 2);       // rows of the intermediate tile beyond the own positions

@@ -624,7 +624,7 @@ int evt_dec_gemv(int32_t wdtype, const void* W, const float* bias, const float* 
   if (r && (!ln_g || !ln_b)) return EVT_EINVAL;
   if (B > kMaxB || K % 512 || (size_t)B * K * 4 > 64 * 1024) return EVT_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
-  if (wdtype == EVT_DT_BF16) return launch_gemv<bf16_t>(W, bias, a, r, ln_g, ln_b, ln_eps, x_out, y, B, N, K, relu, st);
+  if (wdtype == EVT_DT_HALF) return launch_gemv<h16_t>(W, bias, a, r, ln_g, ln_b, ln_eps, x_out, y, B, N, K, relu, st);
   if (wdtype == EVT_DT_F32) return launch_gemv<float>(W, bias, a, r, ln_g, ln_b, ln_eps, x_out, y, B, N, K, relu, st);
   return EVT_EINVAL;
 }
@@ -635,8 +635,8 @@ int evt_dec_attn(int32_t cdtype, const float* qkv, void* kcache, void* vcache, c
   if (D != 32 || (size_t)Lmax * 4 > 60 * 1024) return EVT_ENOTSUP;
   const size_t shm = (size_t)Lmax * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (cdtype == EVT_DT_BF16)
-    hipLaunchKernelGGL((dec_attn<bf16_t, 32>), dim3(B * H), dim3(256), shm, st, qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+  if (cdtype == EVT_DT_HALF)
+    hipLaunchKernelGGL((dec_attn<h16_t, 32>), dim3(B * H), dim3(256), shm, st, qkv, (h16_t*)kcache, (h16_t*)vcache,
                        (const int*)ctr, out, H, Lmax, (const int*)x_lens, x_len);
   else if (cdtype == EVT_DT_F32)
     hipLaunchKernelGGL((dec_attn<float, 32>), dim3(B * H), dim3(256), shm, st, qkv, (float*)kcache, (float*)vcache,
@@ -679,9 +679,9 @@ int evt_dec_qkv_attn(int32_t dtype, const void* Wqkv, const float* bqkv, const f
   if (D != 32 || H * D != 512 || (size_t)Lmax * 4 > 48 * 1024) return EVT_ENOTSUP;
   const size_t shm = (size_t)Lmax * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL((dec_qkv_attn<bf16_t, 32, 1>), dim3(B * H), dim3(256), shm, st, (const bf16_t*)Wqkv, bqkv, a, r,
-                       ln_g, ln_b, ln_eps, x_out, (bf16_t*)kcache, (bf16_t*)vcache, (const int*)ctr, out, H, Lmax,
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL((dec_qkv_attn<h16_t, 32, 1>), dim3(B * H), dim3(256), shm, st, (const h16_t*)Wqkv, bqkv, a, r,
+                       ln_g, ln_b, ln_eps, x_out, (h16_t*)kcache, (h16_t*)vcache, (const int*)ctr, out, H, Lmax,
                        (const int*)x_lens, x_len);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL((dec_qkv_attn<float, 32, 2>), dim3(B * H), dim3(256), shm, st, (const float*)Wqkv, bqkv, a, r,

@@ -316,7 +316,7 @@ int evt_add_layernorm_fwd(int32_t dtype, const void* x, const void* r, const flo
   const int blocks = (int)((rows + 3) / 4);
 #define LN_FWD(T, E) hipLaunchKernelGGL((add_ln_fwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)r, \
                                         gamma, beta, (T*)y, mean, rstd, (long)rows, C, eps)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_FWD(bf16_t, 1); else LN_FWD(bf16_t, 2); }
+  if (dtype == EVT_DT_HALF) { if (C <= 512) LN_FWD(h16_t, 1); else LN_FWD(h16_t, 2); }
   else if (dtype == EVT_DT_F32) { if (C <= 512) LN_FWD(float, 2); else LN_FWD(float, 4); }
   else return EVT_EINVAL;
 #undef LN_FWD
@@ -334,7 +334,7 @@ int evt_add_layernorm_bwd(int32_t dtype, const void* x, const void* r, const flo
   const int blocks = (int)((rows + rpb - 1) / rpb);
 #define LN_BWD(T, E) hipLaunchKernelGGL((add_ln_bwd<T, E>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)r, \
                                         gamma, (const T*)dy, mean, rstd, (T*)dxr, dgamma, dbeta, (long)rows, C, (int)rpb)
-  if (dtype == EVT_DT_BF16) { if (C <= 512) LN_BWD(bf16_t, 1); else LN_BWD(bf16_t, 2); }
+  if (dtype == EVT_DT_HALF) { if (C <= 512) LN_BWD(h16_t, 1); else LN_BWD(h16_t, 2); }
   else if (dtype == EVT_DT_F32) { if (C <= 512) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else return EVT_EINVAL;
 #undef LN_BWD
@@ -351,9 +351,9 @@ static int launch_ce(int32_t dtype, const void* logits, const int64_t* targets, 
   if (V <= 64 * 17) {                                // the s1 vocabulary (1025) and anything up to 1088 columns
     long nb = (rows + 3) / 4;
     if (nb > 2048) nb = 2048;
-    if (dtype == EVT_DT_BF16)
-      hipLaunchKernelGGL((ce_sum_cached<bf16_t, 17>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)logits,
-                         (const long*)targets, (bf16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
+    if (dtype == EVT_DT_HALF)
+      hipLaunchKernelGGL((ce_sum_cached<h16_t, 17>), dim3((int)nb), dim3(256), 0, st, (const h16_t*)logits,
+                         (const long*)targets, (h16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
                          row_loss, (long)ld);
     else if (dtype == EVT_DT_F32)
       hipLaunchKernelGGL((ce_sum_cached<float, 17>), dim3((int)nb), dim3(256), 0, st, (const float*)logits,
@@ -363,9 +363,9 @@ static int launch_ce(int32_t dtype, const void* logits, const int64_t* targets, 
     return evt_check_launch();
   }
   const int blocks = (int)((rows + 3) / 4);
-  if (dtype == EVT_DT_BF16)
-    hipLaunchKernelGGL(ce_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)logits,
-                       (const long*)targets, (bf16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
+  if (dtype == EVT_DT_HALF)
+    hipLaunchKernelGGL(ce_sum_kernel<h16_t>, dim3(blocks), dim3(256), 0, st, (const h16_t*)logits,
+                       (const long*)targets, (h16_t*)dlogits, loss, hits, (long)rows, V, topk, (long)ignore_index, dloss,
                        row_loss, (long)ld);
   else if (dtype == EVT_DT_F32)
     hipLaunchKernelGGL(ce_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)logits, (const long*)targets,

@@ -95,13 +95,13 @@ __device__ __forceinline__ void wg_finish(const WgP& p, unsigned char* smem, con
 // and stage -- made the blocks that own a bias the slowest of the grid: the s1 dense-layer gradient ran at 605 TFLOP/s
 // with and 795 without it (round 4).  The two waves holding the same A fragments (wc = 0 / 1) take the even / odd ones.
 template <int MI>
-__device__ __forceinline__ void wg_bias_mma(f32x4 (&bacc)[MI], const bf16x8 (&a)[MI], int wc) {
-  bf16x8 ones;
+__device__ __forceinline__ void wg_bias_mma(f32x4 (&bacc)[MI], const h16x8 (&a)[MI], int wc) {
+  h16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = (evt_hn)1.0f;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
-    if ((i & 1) == wc) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, bacc[i], 0, 0, 0);
+    if ((i & 1) == wc) bacc[i] = EVT_MFMA_16x16x32(a[i], ones, bacc[i], 0, 0, 0);
 }
 
 __device__ __forceinline__ void wg_finish_bias(const WgP& p, int channel, float bsum, int split);

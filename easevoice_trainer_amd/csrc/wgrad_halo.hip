@@ -57,8 +57,8 @@ __device__ __forceinline__ uint2 tr_rd(unsigned addr) {
 }
 // 8 consecutive positions of one channel = two reads (rows +0..3 and +4..7 of the lane group's 8-row band)
 struct TrPair { uint2 lo, hi; };
-__device__ __forceinline__ bf16x8 tr_join(const TrPair& p) {
-  union { uint4 u; bf16x8 v; } r;
+__device__ __forceinline__ h16x8 tr_join(const TrPair& p) {
+  union { uint4 u; h16x8 v; } r;
   r.u = make_uint4(p.lo.x, p.lo.y, p.hi.x, p.hi.y);
   return r.v;
 }
@@ -93,15 +93,15 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
   const int ch = blockIdx.x % p.nchunk;
   const int a0 = (blockIdx.x / p.nchunk) * 32 * MA;
 
-  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(p.B);
+  const h16_t* Ag = reinterpret_cast<const h16_t*>(p.A);
+  const h16_t* Bg = reinterpret_cast<const h16_t*>(p.B);
   const int nstages = p.nseq * spq;
   const int st_begin = blockIdx.y * stages_per_split;
   const int nst = min(nstages, st_begin + stages_per_split) - st_begin;
   if (nst <= 0) return;
   const int hrows = HPOS + (NT - 1) * p.dil;        // window rows in use
 
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page_h);
+  const h16_t* zsrc = reinterpret_cast<const h16_t*>(g_zero_page_h);
   int arow[MA], acol[MA];
 #pragma unroll
   for (int i = 0; i < MA; ++i) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
       const int q = q0 + arow[i];
       glds16(q < p.Q ? Ag + ((long)seq * p.LA + q) * p.CA + acol[i] : zsrc, base + wave * (16 * AROW) + i * 1024);
     }
-    const bf16_t* rsrc = Bg + ((long)seq * p.LB + q0 + p.off) * p.CB + bcol;
+    const h16_t* rsrc = Bg + ((long)seq * p.LB + q0 + p.off) * p.CB + bcol;
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int j = ps * 64 + brow;
@@ -192,12 +192,12 @@ __global__ __launch_bounds__(256) void wgrad_halo(WgP p, int spq, int stages_per
     auto mma = [&](TrPair (&a)[MA], TrPair (&b)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const bf16x8 bv = tr_join(b[t]);
+        const h16x8 bv = tr_join(b[t]);
 #pragma unroll
-        for (int i = 0; i < MA; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_join(a[i]), bv, acc[i][t], 0, 0, 0);
+        for (int i = 0; i < MA; ++i) acc[i][t] = EVT_MFMA_16x16x32(tr_join(a[i]), bv, acc[i][t], 0, 0, 0);
       }
       if (do_bias) {
-        bf16x8 af[MA];
+        h16x8 af[MA];
 #pragma unroll
         for (int i = 0; i < MA; ++i) af[i] = tr_join(a[i]);
         wg_bias_mma<MA>(bacc, af, wc);
@@ -249,7 +249,7 @@ int launch_inst(const WgP& p, int spq, int per, hipStream_t st) {
 
 bool wgrad_halo_eligible(const WgP& p, int dtype) {
   static const bool off = getenv("EVT_NO_HALO") != nullptr;           // A/B switch for measurements
-  if (off || dtype != EVT_DT_BF16) return false;
+  if (off || dtype != EVT_DT_HALF) return false;
   if (p.s != 1 || p.KHp != p.KH) return false;
   if (p.KH != 3 && p.KH != 5 && p.KH != 7 && p.KH != 11) return false;
   if ((p.CA % 64 && p.CA != 32) || p.CB % 32) return false;
@@ -276,7 +276,7 @@ bool wgrad_halo_eligible(const WgP& p, int dtype) {
 
 int launch_wgrad_halo(const WgP& p_in, hipStream_t st) {
   WgP p = p_in;
-  if (!wgrad_halo_eligible(p, EVT_DT_BF16)) return EVT_ENOTSUP;
+  if (!wgrad_halo_eligible(p, EVT_DT_HALF)) return EVT_ENOTSUP;
   p.nchunk = p.CB / 32;
   p.ntapgrp = 1;
   const int spq = (p.Q + HPOS - 1) / HPOS;

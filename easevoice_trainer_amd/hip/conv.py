@@ -156,7 +156,8 @@ class WeightBank:
     and the device tables for the two multi-tensor launches (fold before forward, grad after backward)."""
 
     def __init__(self, model: nn.Module, dtype: torch.dtype, device, impl=L.IMPL_AUTO):
-        self.dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
+        L.set_half(dtype)     # a 16-bit compute dtype selects the build of the library that serves it
+        self.dt = L.dt_code(dtype)
         self.dtype, self.device, self.impl = dtype, torch.device(device), impl
         self.weight_grads = True
         # EVT_ASYNC_WGRAD=1: weight gradients on a side HIP stream next to the backward-data chain; grads() joins and
@@ -182,7 +183,7 @@ class WeightBank:
         # packed projections (see PackedConv): only for the bf16 bank -- the fused attention node that uses them is bf16
         for m in model.modules():
             fn = getattr(m, "qkv_pack_modules", None)
-            members = fn() if (fn is not None and dtype == torch.bfloat16) else None
+            members = fn() if (fn is not None and L.is_half(dtype)) else None
             m_packed = None
             if members:
                 pc = PackedConv(members)
@@ -211,7 +212,7 @@ class WeightBank:
         # slabs 1.. (EVT_WGRAD_PARTS=0 switches the deterministic split off: fp32 atomics into the one image as before);
         # how many per image: slab_count().  Never zeroed: a slab is stored before it is read, the counters say how many
         # are valid.
-        self.parts_on = (dtype == torch.bfloat16 and self.device.type == "cuda"
+        self.parts_on = (L.is_half(dtype) and self.device.type == "cuda"
                          and os.environ.get("EVT_WGRAD_PARTS", "1") != "0")
         # the slab sizes below (48 MiB per image, at most 32 slabs: 5.9 GB for the s2 models) were measured on a 288 GB
         # MI355X; on a smaller device the budget shrinks with its memory (at 1/4 of the memory: 12 MiB, 1.5 GB)
@@ -494,7 +495,7 @@ def _t1(e0, kind, m, nseq, lin, extra_elems):
         rf.__exit__(None, None, None)
     lq = lin if m.transposed else m.lout(lin)
     macs = nseq * lq * m.cin * m.cout * m.k // m.groups
-    sz = 2 if m._slot.bank.dtype == torch.bfloat16 else 4
+    sz = 2 if L.is_half(m._slot.bank.dtype) else 4
     act = nseq * (lin * m.cin + m.lout(lin) * m.cout) + extra_elems
     wbytes = m.v.numel() * (4 if kind == "bwd_weight" else sz)
     shape = (f"{'T' if m.transposed else ''}{m.cin}>{m.cout} k{m.k} s{m.stride} d{m.dil} g{m.groups} "
@@ -650,24 +651,24 @@ class ConvFn(torch.autograd.Function):
 def _resunit_params(s1, s2, x, slope):
     """evt_resunit_params when the fused ResBlock step covers this pair of convolutions and input, else None"""
     m1, m2 = s1.module, s2.module
-    if (x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
+    if (not L.is_half(x.dtype) or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
             or m2.cin != m2.cout or m1.cin != m2.cin or m1.k != m2.k or m2.dil != 1 or m1.stride != 1 or m2.stride != 1
             or m1.groups != 1 or m2.groups != 1 or m1.transposed or m2.transposed
             or m1.pad != m1.dil * (m1.k - 1) // 2 or m2.pad != (m2.k - 1) // 2 or s1.bank.impl != L.IMPL_AUTO):
         return None
-    p = L.ResUnitParams(L.DT_BF16, x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
+    p = L.ResUnitParams(L.dt_code(x.dtype), x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
     return p if L.lib().evt_resunit_supported(C.byref(p)) else None
 
 
 def _resunit_wide_params(s1, s2, x, slope):
     """evt_resunit_params when the wide fused step (csrc/resunit_wide.hip: C = 64 / 128) covers this pair, else None"""
     m1, m2 = s1.module, s2.module
-    if (x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
+    if (not L.is_half(x.dtype) or not x.is_cuda or not x.is_contiguous() or x.dim() != 3 or m1.cin != m1.cout
             or m2.cin != m2.cout or m1.cin != m2.cin or m1.k != m2.k or m2.dil != 1 or m1.stride != 1 or m2.stride != 1
             or m1.groups != 1 or m2.groups != 1 or m1.transposed or m2.transposed
             or m1.pad != m1.dil * (m1.k - 1) // 2 or m2.pad != (m2.k - 1) // 2 or s1.bank.impl != L.IMPL_AUTO):
         return None
-    p = L.ResUnitParams(L.DT_BF16, x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
+    p = L.ResUnitParams(L.dt_code(x.dtype), x.size(0), x.size(1), m1.cin, m1.k, m1.dil, float(slope))
     return p if L.lib().evt_resunit_wide_supported(C.byref(p)) else None
 
 
@@ -878,7 +879,7 @@ def _t1_multi(e0, kind, pairs, x, wg):
 def _stage_plan(x, blocks, slope):
     """[(slot pairs of unit j over the blocks)] when every step of the stage is covered by the grouped kernels: the blocks
     have kernel sizes 3 / 7 / 11 (one each), equally many steps, and every step passes _resunit_params"""
-    if not x.is_cuda or x.dtype != torch.bfloat16 or len(blocks) != 3:
+    if not x.is_cuda or not L.is_half(x.dtype) or len(blocks) != 3:
         return None
     nunits = len(blocks[0].convs1)
     if any(len(b.convs1) != nunits or len(b.convs2) != nunits for b in blocks):

@@ -83,7 +83,7 @@ class MPDGenLossFn(torch.autograd.Function):
         n_items, T = y_hat.shape
         dev = y_hat.device
         cd = plan[0][0][0].bank.dtype
-        dt = L.DT_BF16 if cd == torch.bfloat16 else L.DT_F32
+        dt = L.dt_code(cd)
         # [real ; generated] of every sub-discriminator, prepared in one launch
         both = mpd_fold(periods, cd, y_real, y_hat)
         maps, saved = [], []           # per sub-D: list of batched outputs

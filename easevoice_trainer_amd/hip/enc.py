@@ -101,7 +101,7 @@ def res_drop_ln(x, y, gamma, beta, lens, p, site, eps=1e-5):
 
 def _mha_params(dtype, B, H, D, Tq, Tk, window, n_heads_rel, ldq, ldk, ldo, scale, p, site, device):
     """evt_mha_params (include/evt.h): window None = no relative positions"""
-    return L.MhaParams(L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32, B, H, D, Tq, Tk,
+    return L.MhaParams(L.dt_code(dtype), B, H, D, Tq, Tk,
                        -1 if window is None else int(window), int(n_heads_rel), ldq, ldk, ldo, float(scale), float(p),
                        int(site), 0, rng_counter(device).data_ptr())
 
@@ -115,7 +115,7 @@ class MhaCoreFn(torch.autograd.Function):
     def forward(ctx, q, k, v, emb_k, emb_v, lens_q, lens_k, n_heads, window, p, site, scale):
         B, Tq, Cc = q.shape
         Tk = k.size(1)
-        if q.dtype not in (torch.bfloat16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype:
+        if q.dtype not in (torch.bfloat16, torch.float16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype:
             raise L.EvtError(f"mha: q / k / v must share bf16 or fp32, got {q.dtype} {k.dtype} {v.dtype}")
         if Cc % n_heads or k.shape != (B, Tk, Cc) or v.shape != k.shape:
             raise L.EvtError(f"mha: shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} heads {n_heads}")
@@ -174,7 +174,7 @@ class RelAttnFn(torch.autograd.Function):
     def forward(ctx, qkv, emb_k, emb_v, lens, n_heads, window, p, site, scale):
         B, T, C3 = qkv.shape
         Cc = C3 // 3
-        if qkv.dtype not in (torch.bfloat16, torch.float32) or not qkv.is_contiguous() or C3 % 3 or Cc % n_heads:
+        if qkv.dtype not in (torch.bfloat16, torch.float16, torch.float32) or not qkv.is_contiguous() or C3 % 3 or Cc % n_heads:
             raise L.EvtError(f"mha: packed contiguous [B, T, 3*H*D] expected, got {tuple(qkv.shape)} {qkv.dtype}")
         D = Cc // n_heads
         ek = emb_k.contiguous() if window is not None else None
@@ -353,7 +353,7 @@ class WNResidualFn(torch.autograd.Function):
         dev = (dacc if dacc is not None else dx_out).device
         drs = torch.empty(rs_shape, dtype=dtype, device=dev)
         dx = None if last else torch.empty(rs_shape[:-1] + (H,), dtype=dtype, device=dev)
-        L.check(L.lib().evt_wn_residual_bwd(L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32, L.ptr(dx_out), L.ptr(dacc),
+        L.check(L.lib().evt_wn_residual_bwd(L.dt_code(dtype), L.ptr(dx_out), L.ptr(dacc),
                                             L.ptr(lens), rps, L.ptr(dx), L.ptr(drs), C.c_int64(rows), H, int(last),
                                             L.stream_ptr()), "evt_wn_residual_bwd")
         # d(acc): the skip sum passes through unchanged, except for the last layer where the row mask applies to it too
@@ -461,7 +461,7 @@ class ReparamFn(torch.autograd.Function):
         B, T, Cc = ctx.dims
         gs = [g.float().contiguous() if g is not None else None for g in (dz, dm, dlogs)]
         dstats = torch.empty((B, T, 2 * Cc), dtype=ctx.sdt, device=eps.device)
-        dt = L.DT_BF16 if ctx.sdt == torch.bfloat16 else L.DT_F32
+        dt = L.dt_code(ctx.sdt)
         L.check(L.lib().evt_reparam_bwd(dt, L.ptr(gs[0]), L.ptr(gs[1]), L.ptr(gs[2]), L.ptr(eps), L.ptr(logs), L.ptr(lens), T,
                                         C.c_int64(B * T), Cc, L.ptr(dstats), L.stream_ptr()), "evt_reparam_bwd")
         return dstats, None, None
@@ -504,7 +504,7 @@ class CouplingFlipFn(torch.autograd.Function):
             dx0n = dx0n.to(ctx.sdt).contiguous()
         dx = torch.empty_like(dy)
         dstats = torch.empty((B, T, h), dtype=ctx.sdt, device=dy.device)
-        dt = L.DT_BF16 if ctx.sdt == torch.bfloat16 else L.DT_F32
+        dt = L.dt_code(ctx.sdt)
         L.check(L.lib().evt_coupling_flip_bwd(dt, L.ptr(dy), L.ptr(dx0n), L.ptr(lens), T, C.c_int64(B * T), h, L.ptr(dx),
                                               L.ptr(dstats), L.stream_ptr()), "evt_coupling_flip_bwd")
         return dx, dstats, None, None

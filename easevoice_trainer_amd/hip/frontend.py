@@ -19,7 +19,7 @@ def ncl_to_nlc(x, cpad=None, dtype=torch.float32):
     B, Cc, T = x.shape
     cpad = Cc if cpad is None else int(cpad)
     out = torch.empty((B, T, cpad), dtype=dtype, device=x.device)
-    L.check(L.lib().evt_ncl_to_nlc(L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32, L.ptr(x), L.ptr(out), B, Cc, T, cpad,
+    L.check(L.lib().evt_ncl_to_nlc(L.dt_code(dtype), L.ptr(x), L.ptr(out), B, Cc, T, cpad,
                                    L.stream_ptr()), "evt_ncl_to_nlc")
     return out
 

@@ -10,9 +10,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libevt_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libevt_hip.so")           # bfloat16 build
+LIB_PATH_F16 = os.path.join(os.path.dirname(_HERE), "libevt_hip_f16.so")   # the same sources with IEEE half (fp16_run)
 
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+HALF_DTYPES = (torch.bfloat16, torch.float16)
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 IMPL_AUTO, IMPL_NAIVE, IMPL_IGEMM = 0, 1, 2
 
@@ -120,10 +122,41 @@ class MhaParams(C.Structure):
                 ("site", C.c_uint32), ("pad_", C.c_uint32), ("seed_dev", C.c_void_p)]
 
 
-_lib = None
+_libs = {}                   # half dtype -> loaded library
+_half = torch.bfloat16       # the 16-bit type of the library lib() returns
 
 
-def _check_fresh(handle):
+def set_half(dtype) -> None:
+    """Select which build lib() returns: torch.bfloat16 -> libevt_hip.so, torch.float16 -> libevt_hip_f16.so (float32
+    leaves the selection alone: both builds serve it).  The engines call this at the top of every step with their compute
+    dtype; a process that only ever uses one 16-bit type never notices."""
+    global _half
+    if dtype in HALF_DTYPES:
+        _half = dtype
+
+
+def half():
+    return _half
+
+
+def is_half(dtype) -> bool:
+    return dtype in HALF_DTYPES
+
+
+def dt_code(dtype) -> int:
+    """torch dtype -> EVT_DT_* of the ACTIVE library; a 16-bit type the active build does not serve is an error here, before
+    any pointer reaches a kernel that would read its bits as the other format"""
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype in HALF_DTYPES:
+        if dtype != _half:
+            raise EvtError(f"{dtype} data while the {_half} build of the library is selected: call hip.lib.set_half({dtype}) "
+                           "(the engines do, at the top of a step)")
+        return DT_BF16 if dtype == torch.bfloat16 else DT_F16
+    raise EvtError(f"unsupported dtype {dtype}")
+
+
+def _check_fresh(handle, LIB_PATH=LIB_PATH):
     """the library carries the hash of the sources it was built from (evt_version(): "... src=<hash>"); next to a source
     tree (this repository, the GPU box's copy of it) a different hash means a stale .so -- an error, not an old kernel"""
     csrc = os.path.join(os.path.dirname(_HERE), "csrc")
@@ -139,16 +172,21 @@ def _check_fresh(handle):
 
 
 def lib():
-    """Load the shared library once; raise loudly if it is missing (no CPU / eager fallback)."""
-    global _lib
+    """The selected build (set_half), loaded once; raise loudly if it is missing (no CPU / eager fallback)."""
+    _lib = _libs.get(_half)
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH if _half == torch.bfloat16 else LIB_PATH_F16
+        if not os.path.exists(path):
             raise EvtError(
-                f"{LIB_PATH} not found: build it with `python -m easevoice_trainer_amd.build` "
+                f"{path} not found: build it with `python -m easevoice_trainer_amd.build` "
                 "(or __graft_entry__.build()). There is no fallback path.")
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(path)
         _lib.evt_version.restype = C.c_char_p
-        _check_fresh(_lib)
+        _check_fresh(_lib, path)
+        _lib.evt_half_dtype.restype = C.c_int32
+        if _lib.evt_half_dtype() != (DT_BF16 if _half == torch.bfloat16 else DT_F16):
+            raise EvtError(f"{path} serves half code {_lib.evt_half_dtype()}: not the {_half} build")
+        _libs[_half] = _lib
         _lib.evt_conv1d_lout.restype = C.c_int32
         _lib.evt_mel_workspace_floats.restype = C.c_int64
         _lib.evt_workspace_bytes.restype = C.c_int64
@@ -164,15 +202,11 @@ def check(rc: int, what: str) -> None:
 
 
 def dt_of(t: torch.Tensor) -> int:
-    if t.dtype == torch.float32:
-        return DT_F32
-    if t.dtype == torch.bfloat16:
-        return DT_BF16
-    raise EvtError(f"unsupported dtype {t.dtype}")
+    return dt_code(t.dtype)
 
 
 def torch_dtype(dt: int) -> torch.dtype:
-    return torch.float32 if dt == DT_F32 else torch.bfloat16
+    return {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}[dt]
 
 
 def ptr(t):

@@ -60,7 +60,8 @@ class LinearBank:
     -- up to Np rows (runtime.ParamArena(reserve=...))."""
 
     def __init__(self, specs, dtype: torch.dtype, device):
-        self.dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
+        L.set_half(dtype)
+        self.dt = L.dt_code(dtype)
         self.dtype, self.device = dtype, torch.device(device)
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
         self.slots = []

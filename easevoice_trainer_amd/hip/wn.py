@@ -52,7 +52,7 @@ class WNStackFn(torch.autograd.Function):
         in_slots, rs_slots, H, B, T = ctx.cfg
         n_layers = len(in_slots)
         dtype, dev = dout.dtype, dout.device
-        dt = L.DT_BF16 if dtype == torch.bfloat16 else L.DT_F32
+        dt = L.dt_code(dtype)
         rows = B * T
         dacc = dout.contiguous()
         dx_next = None

@@ -788,8 +788,8 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         averages the style vectors) -> waveform [B, 1, T*hop] (models.py:974-1013): prior from the text/ssl encoder,
         z_p = m_p + noise*exp(logs_p)*noise_scale, the flow run in reverse, the HiFi-GAN generator over the whole
         sequence.  `noise` ([B, inter, >=T]) injects the prior draw for deterministic parity runs."""
-        amp = self.cd == torch.bfloat16
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        amp = self.cd in (torch.bfloat16, torch.float16)
+        with torch.autocast("cuda", dtype=self.cd if amp else torch.bfloat16, enabled=amp):
             ges = []
             for r in (refer if isinstance(refer, (list, tuple)) else [refer]):
                 r_cl = r.transpose(1, 2)
@@ -829,8 +829,8 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
         T = y.size(2)
         y_mask = commons.sequence_mask(y_lengths, T).unsqueeze(-1).to(torch.float32)        # [B, T, 1]
         text_mask = commons.sequence_mask(text_lengths, text.size(1)).unsqueeze(-1).to(torch.float32)
-        amp = self.cd == torch.bfloat16
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        amp = self.cd in (torch.bfloat16, torch.float16)
+        with torch.autocast("cuda", dtype=self.cd if amp else torch.bfloat16, enabled=amp):
             lens32 = y_lengths.to(torch.int32)
             # the spectrogram once as channels-last rows in the compute dtype, zero-padded to enc_q.pre's image width
             y_cl = ncl_to_nlc(y.float(), self.enc_q.pre.cin, self.cd)                          # [B, T, 1088]

@@ -143,15 +143,32 @@ class FlatAdamW:
             self._table_lrs = lrs
         return self._table, self._nseg
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, skip=None):
+        """skip: a device fp32 flag (DeviceGradScaler.found_inf): non-zero -> the launch changes nothing, the device step
+        number included (GradScaler.step on an overflow).  The python-side step_count then runs ahead of the device's;
+        sync_step_count() re-reads it (checkpoints do)."""
         self.step_count += 1
         tab, nseg = self._segments()
         a = self.arena
         a.updates += 1
+        if skip is not None:
+            self._guarded = True
+            L.check(L.lib().evt_adamw_flat_dev_guarded(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg),
+                                                       L.ptr(self.exp_avg_sq), C.c_int64(a.numel), L.ptr(tab), nseg,
+                                                       C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                                       L.ptr(self._step_dev), C.c_float(grad_scale), L.ptr(skip),
+                                                       L.stream_ptr()), "evt_adamw_flat_dev_guarded")
+            return
         L.check(L.lib().evt_adamw_flat_dev(L.ptr(a.param), L.ptr(a.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                            C.c_int64(a.numel), L.ptr(tab), nseg, C.c_float(self.betas[0]),
                                            C.c_float(self.betas[1]), C.c_float(self.eps), L.ptr(self._step_dev),
                                            C.c_float(grad_scale), L.stream_ptr()), "evt_adamw_flat_dev")
+
+    def sync_step_count(self):
+        """the number of updates actually applied (the device counter: guarded steps that were skipped do not count)"""
+        if getattr(self, "_guarded", False):
+            self.step_count = int(self._step_dev.item())
+        return self.step_count
 
     def step_range(self, lo, hi, bump, grad_scale=1.0):
         """the update of the arena elements [lo, hi) only (evt_adamw_flat_dev_range): one sub-model's parameters, as soon as
@@ -177,6 +194,7 @@ class FlatAdamW:
     def state_dict(self):
         """torch.optim.AdamW.state_dict() layout: parameters numbered group by group in `slots` order; entries only for
         parameters that are updated (a parameter without gradients has no state in torch either)"""
+        self.sync_step_count()
         named = dict(self.arena.model.named_parameters())
         state, idx, pgroups = {}, 0, []
         for g in self.groups:
@@ -343,3 +361,71 @@ class ModelRuntime:
         L.check(L.lib().evt_sumsq(L.ptr(self.arena.grad), C.c_int64(self.arena.numel), L.ptr(self._sumsq),
                                   L.stream_ptr()), "evt_sumsq")
         return self._sumsq
+
+
+class DeviceGradScaler:
+    """torch.cuda.amp.GradScaler (src/train/sovits.py:378: `GradScaler(enabled=hps.train.fp16_run)`; :504-507 and :521-525:
+    scale(loss).backward(), unscale_(optim), step(optim), update()) with its state in device memory: the scale, the growth
+    tracker and one found-inf flag per optimiser are tensors the kernels read and write, so a step has no host
+    synchronisation (GradScaler.step reads found_inf on the host: `.item()`) and is captured into the HIP graphs like the
+    rest.  Same arithmetic as torch's: _amp_foreach_non_finite_check_and_unscale_ (evt_scaler_unscale), the skipped
+    optimiser step (evt_adamw_flat_dev_guarded), _amp_update_scale_ (evt_scaler_update).  One scaler serves both
+    optimisers of the GAN step, as in the reference: update() looks at both flags."""
+
+    def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 enabled=True):
+        self.device = torch.device(device)
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._scale = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
+        self._tracker = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._found = {}            # id(optimiser) -> fp32 flag [1]
+        self._flag_table = None
+
+    def found_inf(self, owner):
+        """the flag of one optimiser; `owner` is anything that identifies it (the engines pass the model's runtime)"""
+        f = self._found.get(id(owner))
+        if f is None:
+            f = self._found[id(owner)] = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._flag_table = None
+        return f
+
+    def scale(self, loss):
+        """loss * scale as a device-side product (the seed of the backward carries the scale)"""
+        return loss * self._scale[0] if self.enabled else loss
+
+    def unscale_(self, owner):
+        """owner.arena.grad *= 1 / scale; owner's flag is raised if a gradient is not finite"""
+        if not self.enabled:
+            return
+        a = owner.arena
+        L.check(L.lib().evt_scaler_unscale(L.ptr(a.grad), C.c_int64(a.numel), L.ptr(self._scale), L.ptr(self.found_inf(owner)),
+                                           L.stream_ptr()), "evt_scaler_unscale")
+
+    def update(self):
+        if not self.enabled or not self._found:
+            return
+        if self._flag_table is None:
+            flags = list(self._found.values())
+            self._flag_table = (C.c_void_p * len(flags))(*[f.data_ptr() for f in flags])
+        L.check(L.lib().evt_scaler_update(L.ptr(self._scale), L.ptr(self._tracker), self._flag_table, len(self._found),
+                                          C.c_float(self.growth_factor), C.c_float(self.backoff_factor),
+                                          int(self.growth_interval), L.stream_ptr()), "evt_scaler_update")
+
+    def get_scale(self):
+        return float(self._scale.item()) if self.enabled else 1.0
+
+    def state_dict(self):
+        """torch.amp.GradScaler.state_dict() layout"""
+        if not self.enabled:
+            return {}
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self._tracker.item())}
+
+    def load_state_dict(self, sd):
+        if not self.enabled or not sd:
+            return
+        self._scale.fill_(float(sd["scale"]))
+        self._tracker.fill_(int(sd["_growth_tracker"]))
+        self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval = sd["growth_interval"]

@@ -19,6 +19,7 @@ from ..runtime import ParamArena
 
 class S1Engine:
     def __init__(self, config: dict, device="cuda:0", dtype=torch.bfloat16, reducer=None):
+        L.set_half(dtype)
         L.lib()
         self.config, self.device, self.dtype, self.reducer = config, torch.device(device), dtype, reducer
         self.model = Text2SemanticDecoder(config=config, top_k=3).to(self.device)
@@ -54,6 +55,7 @@ class S1Engine:
     def micro_step(self, batch: dict, batch_idx: int):
         """one micro-batch: forward_old (or the DPO `forward` when config train.if_dpo, t2s_lightning_module.py:44) +
         backward (+ optimiser step on the reference's schedule)"""
+        L.set_half(self.dtype)
         dpo = self.config.get("train", {}).get("if_dpo", False) is True
         fwd = self.model.forward if dpo else self.model.forward_old
         stepping = batch_idx > 0 and batch_idx % 4 == 0

@@ -7,7 +7,10 @@ Differences from the reference that do not change the arithmetic of the losses /
     sovits.py:503,511-521) are not computed at all;
   * gradients live in one flat arena per model: zeroing, grad-norm, AdamW and the data-parallel all-reduce
     are single launches over it; no `.item()` host syncs inside the step;
-  * bf16 compute needs no GradScaler (the reference's fp16 autocast + GradScaler is SURVEY §8(f) N4).
+  * dtype torch.bfloat16 needs no loss scaling; dtype torch.float16 is the reference's `fp16_run` mode: the same kernels
+    built for IEEE half (libevt_hip_f16.so) and the reference's GradScaler protocol (sovits.py:378,504-507,521-525:
+    scale -> backward -> unscale_ -> step (skipped on overflow) for D, then for G, then ONE update()) with the scaler's
+    state on the device (runtime.DeviceGradScaler): no host read, captured into the HIP graphs with the rest.
 """
 import os
 from dataclasses import dataclass, field
@@ -24,7 +27,7 @@ from ..module.losses import (discriminator_loss, discriminator_loss_batched, fea
                              l1_mean_scaled)
 from ..module.mel_processing import mel_spectrogram_torch, spec_to_mel_slices
 from ..module.models import MultiPeriodDiscriminator, SynthesizerTrn
-from ..runtime import FlatAdamW, ModelRuntime
+from ..runtime import DeviceGradScaler, FlatAdamW, ModelRuntime
 
 
 @dataclass
@@ -42,9 +45,13 @@ class S2Losses:
 
 
 class S2Engine:
-    def __init__(self, hps: dict, device="cuda:0", dtype=torch.bfloat16, impl=L.IMPL_AUTO, reducer=None):
-        """hps: the parsed configs/s2.json (train/data/model sections)."""
+    def __init__(self, hps: dict, device="cuda:0", dtype=torch.bfloat16, impl=L.IMPL_AUTO, reducer=None, scaler_args=None):
+        """hps: the parsed configs/s2.json (train/data/model sections).  scaler_args: GradScaler keyword arguments for
+        dtype torch.float16 (the reference constructs it with torch's defaults: init_scale 65536, growth 2 every 2000
+        clean steps, backoff 0.5)."""
         self.hps, self.device, self.dtype = hps, torch.device(device), dtype
+        L.set_half(dtype)
+        self.scaler = DeviceGradScaler(self.device, enabled=dtype == torch.float16, **(scaler_args or {}))
         d, m, t = hps["data"], hps["model"], hps["train"]
         self.net_g = SynthesizerTrn(d["filter_length"] // 2 + 1, t["segment_size"] // d["hop_length"],
                                     n_speakers=d["n_speakers"], **m)
@@ -65,6 +72,7 @@ class S2Engine:
         # measured round 4, the launches do overlap (kernel trace) and the step does not get shorter -- 24.7-24.8 ms
         # against 24.6-24.7 -- although it is 2.0 ms shorter without them: the backward next to them slows down by as much
         self.pipe = ((reducer is None or not reducer.active) and self.device.type == "cuda" and not self.cut_only
+                     and not self.scaler.enabled      # the piped bookkeeping updates a range before the whole arena was checked
                      and os.environ.get("EVT_BOOK_PIPE", "0") == "1")
         if self.overlap or self.pipe or self.cut_only:
             self.net_g.split_backward = True
@@ -170,17 +178,20 @@ class S2Engine:
             st.d_done = []
             st.loss_disc = torch.stack([l.detach() for l in st.d_losses]).sum()
             return
-        st.loss_disc.backward()
+        self.scaler.scale(st.loss_disc).backward()
         rt_d.finish_grads()
 
     def _phase_b(self, st, backward=True):
         t = self.hps["train"]
         net_d, rt_g, rt_d = self.net_d, self.rt_g, self.rt_d
+        # fp16 mode: scaler.unscale_(optim_d) -- after the data-parallel sum, so every rank sees the same flag (sovits.py:505)
+        self.scaler.unscale_(rt_d)
         st.gss_d = rt_d.grad_sumsq() * (st.inv_world * st.inv_world)   # norm of the AVERAGED gradient, as DDP logs it
         if st.hook_after_d is not None:
             st.hook_after_d()
         if st.do_opt and not getattr(st, "piped", False):
-            self.optim_d.step(grad_scale=st.inv_world)   # 1/world averaging folded into the AdamW launch
+            # 1/world averaging folded into the AdamW launch; scaler.step(optim_d): skipped on an overflow (sovits.py:507)
+            self.optim_d.step(grad_scale=st.inv_world, **self._skip(rt_d))
             rt_d.prepare()   # D weights changed: refold before the generator's pass through D
         # ---- generator step (sovits.py:509-525) ----
         rt_d.bank.weight_grads = False
@@ -195,14 +206,19 @@ class S2Engine:
         st.loss_gen_all = st.loss_gen + st.loss_fm + st.loss_mel + st.kl_ssl * 1 + st.loss_kl
         if not backward:
             return
-        st.loss_gen_all.backward()
+        self.scaler.scale(st.loss_gen_all).backward()
         rt_d.bank.weight_grads = True
         rt_g.finish_grads()
 
+    def _skip(self, rt):
+        return dict(skip=self.scaler.found_inf(rt)) if self.scaler.enabled else {}
+
     def _phase_c(self, st):
+        self.scaler.unscale_(self.rt_g)                  # sovits.py:522
         st.gss_g = self.rt_g.grad_sumsq() * (st.inv_world * st.inv_world)
         if st.do_opt:
-            self.optim_g.step(grad_scale=st.inv_world)
+            self.optim_g.step(grad_scale=st.inv_world, **self._skip(self.rt_g))     # scaler.step(optim_g), sovits.py:524
+            self.scaler.update()                                                    # sovits.py:525: once, after both
 
     @staticmethod
     def _result(st) -> S2Losses:
@@ -225,16 +241,17 @@ class S2Engine:
         step: the inputs are detached), so that each can be differentiated -- and its gradients reduced -- on its own"""
         self._phase_a(st, backward=False)
 
-    def _phase_a_bwd(self, st, i):
-        st.d_losses[i].backward()
-        st.d_done.append(self.rt_d.finish_conv_grads(self._d_convs[i]))
-        if len(st.d_done) == len(self._d_convs):
+    def _phase_a_bwd(self, st, group):
+        """backward of the sub-discriminators `group` (indices; adjacent in the arena and in the bank's rows)"""
+        torch.autograd.backward([self.scaler.scale(st.d_losses[i]) for i in group])
+        st.d_done.append(self.rt_d.finish_conv_grads([m for i in group for m in self._d_convs[i]]))
+        if sum(hi - lo for lo, hi in st.d_done) == sum(hi - lo for lo, hi in self._d_rows):
             self.rt_d.finish_grads(done=st.d_done)
 
     def _phase_b0(self, st):
         """D optimiser, the generator's losses, and the backward through D and the vocoder (down to the cut)"""
         self._phase_b(st, backward=False)
-        (st.loss_gen + st.loss_fm + st.loss_mel).backward()
+        self.scaler.scale(st.loss_gen + st.loss_fm + st.loss_mel).backward()
         self.rt_d.bank.weight_grads = True
         st.g_done = [self.rt_g.finish_conv_grads(self._dec_convs)]
 
@@ -247,7 +264,7 @@ class S2Engine:
 
     def _bwd_b1(self, st):
         z_full, z_cut = self.net_g._cut[0]
-        roots, grads = [st.loss_kl + st.kl_ssl * 1], [None]
+        roots, grads = [self.scaler.scale(st.loss_kl + st.kl_ssl * 1)], [None]
         if z_cut.grad is not None:
             roots.append(z_full)
             grads.append(z_cut.grad)
@@ -307,7 +324,7 @@ class S2Engine:
         rt_d.book_join()
         # ---- generator step: D update and refold are done; losses, then the backward in its three parts ----
         self._phase_b(st, backward=False)
-        (st.loss_gen + st.loss_fm + st.loss_mel).backward()
+        (st.loss_gen + st.loss_fm + st.loss_mel).backward()       # (the piped program is never built in fp16 mode)
         rt_d.bank.weight_grads = True
         rt_g.book_piece(self.optim_g, [self._dec_rows], [self._dec_rows_fold], [self._dec_range], first=True)
         self._bwd_b1(st)
@@ -326,10 +343,18 @@ class S2Engine:
         (bench.py prints the collective plan per range through GradReducer.describe)"""
         if not self.overlap:
             return [("D arena", self.rt_d.arena.grad.numel()), ("G arena", self.rt_g.arena.grad.numel())]
-        out = [(f"D sub-discriminator {i}", hi - lo) for i, (lo, hi) in reversed(list(enumerate(self._d_ranges)))]
-        out.append(("G vocoder", self._dec_range[1] - self._dec_range[0]))
-        out.append(("G flow + posterior encoder", self._fq_range[1] - self._fq_range[0]))
-        for lo, hi in self._complement([self._dec_range, self._fq_range], self.rt_g.arena.grad.numel()):
+        nd = min(len(self._d_ranges), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
+        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "3"))))
+        dtot = sum(hi - lo for lo, hi in self._d_ranges)
+        out = [(f"D piece {i + 1}/{nd}", dtot // nd) for i in range(nd)]
+        early = []
+        if ng >= 2:
+            out.append(("G vocoder", self._dec_range[1] - self._dec_range[0]))
+            early.append(self._dec_range)
+        if ng == 3:
+            out.append(("G flow + posterior encoder", self._fq_range[1] - self._fq_range[0]))
+            early.append(self._fq_range)
+        for lo, hi in self._complement(early, self.rt_g.arena.grad.numel()):
             out.append(("G rest", hi - lo))
         return out
 
@@ -349,33 +374,63 @@ class S2Engine:
         dp = self.overlap
         prog = [(self._phase_a0, None)]
         order = list(reversed(range(len(self._d_convs))))          # the reference's engine would also end with d0
-        for n, i in enumerate(order):
-            lo, hi = self._d_ranges[i]
-            last = n == len(order) - 1
+        # EVT_DP_D_PIECES (1 .. 6, default 6): the six sub-discriminators differentiated -- and reduced -- in that many
+        # groups of neighbours; EVT_DP_G_PIECES (1 .. 3, default 3): vocoder | flow + posterior encoder | rest, 2 = vocoder |
+        # the other two together, 1 = the whole generator backward in one piece.  Every cut is a graph boundary (the side
+        # stream of deferred weight-gradient batches joins there): fewer pieces cost less on the GPU and overlap less of
+        # the exchange (measured on one GPU: profiles/r05_dp_program.txt)
+        nd = min(len(order), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
+        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "3"))))
+        base, extra = divmod(len(order), nd)
+        groups, at = [], 0
+        for n in range(nd):
+            size = base + (1 if n < extra else 0)
+            groups.append(order[at:at + size])
+            at += size
+        for n, grp in enumerate(groups):
+            lo, hi = min(self._d_ranges[i][0] for i in grp), max(self._d_ranges[i][1] for i in grp)
+            if hi - lo != sum(self._d_ranges[i][1] - self._d_ranges[i][0] for i in grp):
+                raise L.EvtError("data-parallel pieces: neighbouring sub-discriminators are expected to be adjacent in the arena")
+            last = n == len(groups) - 1
 
             def after(lo=lo, hi=hi, last=last):
                 self._reduce_async(gd, lo, hi)
                 if last:
                     red.wait()                                      # optim_d reads the reduced gradients
-            prog.append((lambda st, i=i: self._phase_a_bwd(st, i), after if dp else None))
+            prog.append((lambda st, grp=tuple(grp): self._phase_a_bwd(st, grp), after if dp else None))
         dlo, dhi = self._dec_range
-        prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
-
         flo, fhi = self._fq_range
-        prog.append((self._phase_b1, (lambda: self._reduce_async(gg, flo, fhi)) if dp else None))
 
-        def after_b2():
-            # what is left: everything outside the two early ranges (prior / style encoders, dec.cond)
-            for lo, hi in self._complement([(dlo, dhi), (flo, fhi)], gg.numel()):
-                self._reduce_async(gg, lo, hi)
-            red.wait()
-        prog.append((self._phase_b2, after_b2 if dp else None))
+        def rest_of(done):
+            def after():
+                # what is left: everything outside the early ranges (prior / style encoders, dec.cond)
+                for lo, hi in self._complement(done, gg.numel()):
+                    self._reduce_async(gg, lo, hi)
+                red.wait()
+            return after
+        if ng == 3:
+            prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
+            prog.append((self._phase_b1, (lambda: self._reduce_async(gg, flo, fhi)) if dp else None))
+            prog.append((self._phase_b2, rest_of([(dlo, dhi), (flo, fhi)]) if dp else None))
+        elif ng == 2:
+            def b12(st):
+                self._phase_b1(st)
+                self._phase_b2(st)
+            prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
+            prog.append((b12, rest_of([(dlo, dhi)]) if dp else None))
+        else:
+            def b012(st):
+                self._phase_b0(st)
+                self._phase_b1(st)
+                self._phase_b2(st)
+            prog.append((b012, rest_of([]) if dp else None))
         prog.append((self._phase_c, None))
         return prog
 
     def step(self, ssl, spec, spec_lengths, y, text, text_lengths, eps=None, ids_slice=None, do_opt=True,
              hook_after_d=None) -> S2Losses:
         """One GAN step.  Layouts as in the reference: ssl [B,768,T], spec [B,1025,T], y [B,1,T*hop], text [B,Tt]."""
+        L.set_half(self.dtype)
         if self.graphs_enabled and do_opt and hook_after_d is None:
             return self._step_graphed((ssl, spec, spec_lengths, y, text, text_lengths, eps, ids_slice))
         st = SimpleNamespace(ssl=ssl, spec=spec, spec_lengths=spec_lengths, y=y, text=text, text_lengths=text_lengths,

@@ -11,8 +11,12 @@
  *     as void*; no torch types, no hidden allocation, no global mutable state; every call
  *     only enqueues work on `stream` and returns 0 or a positive errno-style code.
  *   - activations are CHANNELS-LAST: a "sequence tensor" is [nseq][len][channels] with the
- *     channel index contiguous (the reference's [B, C, L] transposed); bf16 tensors are raw
- *     uint16 storage.  dtype: 0 = float32, 1 = bfloat16 (fp32 accumulation everywhere).
+ *     channel index contiguous (the reference's [B, C, L] transposed); 16-bit tensors are raw
+ *     uint16 storage.  dtype: 0 = float32, 1 = bfloat16, 2 = float16 (fp32 accumulation everywhere).
+ *   - the same sources are built twice: libevt_hip.so serves dtype 0 and 1, libevt_hip_f16.so serves
+ *     dtype 0 and 2 (the reference's `fp16_run` autocast type, src/train/sovits.py:459-525); both export
+ *     exactly this header; a half code the loaded build does not serve returns ENOTSUP (95).
+ *     evt_half_dtype() says which one a loaded library is.
  *   - weight gradients / bias gradients are fp32 and are ACCUMULATED (+=) into the caller's
  *     buffers (atomics), so the caller zeroes them once per optimiser step.
  */
@@ -29,6 +33,7 @@ extern "C" {
 
 #define EVT_DT_F32 0
 #define EVT_DT_BF16 1
+#define EVT_DT_F16 2
 #define EVT_ACT_NONE 0
 #define EVT_ACT_LRELU 1
 #define EVT_ACT_TANH 2
@@ -40,11 +45,14 @@ extern "C" {
  * (easevoice_trainer_amd/build.py::source_hash); the Python binding refuses a library whose hash differs from the
  * sources next to it. */
 const char* evt_version(void);
+/* the 16-bit dtype code this build serves: EVT_DT_BF16 (libevt_hip.so) or EVT_DT_F16 (libevt_hip_f16.so) */
+int32_t evt_half_dtype(void);
 /* Profiling aid, OUTSIDE the contract above and off by default: after evt_debug_kernel_tags(1) every dispatcher
  * records the name of the kernel instantiation it launched in a per-thread buffer that evt_last_kernel_tag() returns
  * (bench.py's roofline leg groups its timings by these names, the same names rocprofv3 prints).  With tags off (the
  * product path) nothing is recorded.  evt_debug_* are the library's ONLY process-global mutable state (two flags and a
- * thread-local name buffer): measurement switches, never read by a computation's arithmetic. */
+ * thread-local name buffer): measurement switches, never read by a computation's arithmetic.  DEBUG ONLY, NOT REENTRANT:
+ * switching them while another thread is inside the library is undefined; the product path never calls them. */
 void evt_debug_kernel_tags(int32_t enable);
 const char* evt_last_kernel_tag(void);
 /* measurement switch of the bf16 attention kernels: 1 = both query/key tiles of a wave in one instruction stream
@@ -378,6 +386,26 @@ int evt_mpd_unfold(int32_t grad_dtype, const void* const* douts, const int32_t* 
 
 /* out[0] = sum(x^2) over n floats (grad-norm at commons.py:140-155 without the per-parameter .item()) */
 int evt_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Loss scaling of the fp16 mode (torch.cuda.amp.GradScaler at src/train/sovits.py:378 and :504-507, :521-525:
+ * scale(loss).backward(); unscale_(optim); step(optim); update()), with every piece of state in DEVICE memory so that
+ * the step stays free of host synchronisation and can be captured into a HIP graph.
+ *   scale [1] fp32, growth_tracker [1] int32, found_inf [1] fp32 per optimiser (0 = all gradients finite).
+ * evt_scaler_unscale: grad[i] *= 1 / scale (the reciprocal taken in double and rounded to fp32, as GradScaler._unscale_grads_
+ *   does), *found_inf = 1 if any element is inf / NaN (torch._amp_foreach_non_finite_check_and_unscale_); found_inf is only
+ *   ever raised here, evt_scaler_update clears it.
+ * evt_adamw_flat_dev_guarded: evt_adamw_flat_dev that does NOTHING -- no update, no step-counter increment -- when
+ *   *skip != 0 (GradScaler.step skips optimizer.step() on an overflow); skip == NULL: unconditional.
+ * evt_scaler_update: torch._amp_update_scale_: any of the nflags <= 4 flags set -> scale *= backoff_factor, tracker = 0;
+ *   else tracker += 1 and, when it reaches growth_interval, scale *= growth_factor (kept only if finite), tracker = 0.
+ *   The flags are reset to 0 for the next step. */
+int evt_scaler_unscale(float* grad, int64_t n, const float* scale, float* found_inf, void* stream);
+int evt_adamw_flat_dev_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               const evt_adamw_seg* segs, int32_t nseg, float beta1, float beta2, float eps,
+                               int32_t* step_counter, float grad_scale, const float* skip, void* stream);
+int evt_scaler_update(float* scale, int32_t* growth_tracker, float* const* found_inf, int32_t nflags, float growth_factor,
+                      float backoff_factor, int32_t growth_interval, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * s1 (text -> semantic GPT) kernels.

@@ -25,3 +25,15 @@ def gpu():
 
     lib.lib()  # fail loudly if the extension is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _bf16_build_selected():
+    """every test starts with the bfloat16 build of the library selected (hip.lib.set_half): the fp16-mode tests switch to the
+    IEEE-half build (libevt_hip_f16.so) and must not leak that selection into the next test"""
+    import torch
+    from easevoice_trainer_amd.hip import lib
+
+    lib.set_half(torch.bfloat16)
+    yield
+    lib.set_half(torch.bfloat16)

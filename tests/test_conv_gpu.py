@@ -67,6 +67,10 @@ FUSIONS = [
 ]
 
 
+HALVES = (torch.bfloat16, torch.float16)
+HALF = torch.bfloat16      # the 16-bit type of the hard-wired cases; tests/test_fp16_ops_gpu.py re-runs them with torch.float16
+
+
 def _run_case(gpu, case, fusion, dtype, impl, report=None):
     from easevoice_trainer_amd.hip import conv as HC
 
@@ -81,17 +85,17 @@ def _run_case(gpu, case, fusion, dtype, impl, report=None):
     lout = m.lout(Lin)
     res = torch.randn(nseq, cout, lout) if fusion["res"] else None
     dy = torch.randn(nseq, cout, lout)
-    if dtype == torch.bfloat16:
-        x, dy = x.bfloat16().float(), dy.bfloat16().float()
-        res = res.bfloat16().float() if res is not None else None
+    if dtype in HALVES:
+        x, dy = x.to(dtype).float(), dy.to(dtype).float()
+        res = res.to(dtype).float() if res is not None else None
 
     # ---- oracle (CPU fp32, [B,C,L]) ----
     xo = x.clone().requires_grad_(True)
     ro = res.clone().requires_grad_(True) if res is not None else None
     po = {n_: p.detach().clone().requires_grad_(True) for n_, p in m.named_parameters()}
     w = O.weight_norm_fold(po["weight_v"], po["weight_g"]) if wn else po["weight"]
-    if dtype == torch.bfloat16:
-        w = w + (w.detach().bfloat16().float() - w.detach())  # straight-through bf16 rounding of weights
+    if dtype in HALVES:
+        w = w + (w.detach().to(dtype).float() - w.detach())  # straight-through 16-bit rounding of weights
     yo = O.conv_block(xo, w, po.get("bias"), ro, stride=stride, pad=pad, dil=dil, groups=groups,
                       transposed=transposed, in_slope=fusion["in_slope"], out_act=fusion["out_act"],
                       out_slope=fusion["out_slope"])
@@ -109,7 +113,7 @@ def _run_case(gpu, case, fusion, dtype, impl, report=None):
     bank.grads()
     torch.cuda.synchronize()
 
-    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    tol = {torch.float32: 1e-3, torch.bfloat16: 3e-2, torch.float16: 6e-3}[dtype]
 
     def close(a, b, name):
         a, b = a.detach().float().cpu(), b.detach().float().cpu()
@@ -179,7 +183,7 @@ def test_conv_narrow_parity(gpu, ci):
     for fusion in (FUSIONS[0], FUSIONS[2], FUSIONS[1]):
         HC.set_trace([])
         try:
-            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            _run_case(gpu, case, fusion, HALF, 0)
             tags = {(r[1], r[0].split(",")[0]) for r in HC.TRACE}
         finally:
             HC.set_trace(None)
@@ -196,7 +200,7 @@ def test_conv_ring_parity(gpu, ci):
     for fusion in (FUSIONS[2], FUSIONS[0]):
         HC.set_trace([])
         try:
-            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            _run_case(gpu, case, fusion, HALF, 0)
             tags = {(r[1], r[0]) for r in HC.TRACE}
         finally:
             HC.set_trace(None)
@@ -214,7 +218,7 @@ def test_conv_deep_parity(gpu, ci):
     for fusion in (FUSIONS[2], FUSIONS[0]):
         HC.set_trace([])
         try:
-            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            _run_case(gpu, case, fusion, HALF, 0)
             tags = {(r[1], r[0]) for r in HC.TRACE}
         finally:
             HC.set_trace(None)
@@ -278,7 +282,7 @@ def test_wgrad_halo_parity(gpu, ci):
     for fusion in (FUSIONS[0], FUSIONS[2]):
         HC.set_trace([])
         try:
-            _run_case(gpu, case, fusion, torch.bfloat16, 0)
+            _run_case(gpu, case, fusion, HALF, 0)
             tags = {(r[1], r[0]) for r in HC.TRACE}
         finally:
             HC.set_trace(None)
@@ -297,11 +301,11 @@ def _wgrad_twice(gpu, case, env):
     try:
         torch.manual_seed(5)
         m = HC.EvtConv1d(cin, cout, k, stride, pad, dil, groups, bias=True, transposed=transposed, weight_norm=wn).to(gpu)
-        bank = HC.WeightBank(m, torch.bfloat16, gpu)
+        bank = HC.WeightBank(m, HALF, gpu)
         bank.build_tables()
         bank.fold()
-        x = torch.randn(nseq, Lin, cin, device=gpu).bfloat16()
-        dy = torch.randn(nseq, m.lout(Lin), cout, device=gpu).bfloat16()
+        x = torch.randn(nseq, Lin, cin, device=gpu).to(HALF)
+        dy = torch.randn(nseq, m.lout(Lin), cout, device=gpu).to(HALF)
         outs = []
         for reps in (1, 1, 2):
             for p in m.parameters():

@@ -138,9 +138,16 @@ def test_library_exports_header_symbols():
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "evt.h")).read()
     names = set(re.findall(r"\b(evt_[a-z0-9_]+)\s*\(", hdr))
     assert names, "no declarations parsed"
-    lib = L.lib()
-    missing = [n for n in sorted(names) if not hasattr(lib, n)]
-    assert not missing, f"declared in evt.h but not exported: {missing}"
+    import torch
+
+    # both builds of the sources export exactly the header: libevt_hip.so (bfloat16) and libevt_hip_f16.so (IEEE half)
+    for half, code, tag in ((torch.bfloat16, 1, "half = bf16"), (torch.float16, 2, "half = f16")):
+        L.set_half(half)
+        lib = L.lib()
+        missing = [n for n in sorted(names) if not hasattr(lib, n)]
+        assert not missing, f"declared in evt.h but not exported by the {half} build: {missing}"
+        assert lib.evt_half_dtype() == code and tag in lib.evt_version().decode()
+    L.set_half(torch.bfloat16)
 
 
 def test_workspace_bytes_query():

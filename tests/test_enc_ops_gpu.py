@@ -155,8 +155,8 @@ def test_wn_stack_node(gpu, dtype):
     x = (torch.randn(B, T, H, device=gpu) * live)
     g = torch.randn(B, GIN, device=gpu)
     wgt = torch.randn(B, T, H, device=gpu)
-    if dtype == torch.bfloat16:
-        x, g = x.bfloat16().float(), g.bfloat16().float()
+    if dtype in (torch.bfloat16, torch.float16):
+        x, g = x.to(dtype).float(), g.to(dtype).float()
     x, g = x.detach(), g.detach()
     xg, gg = x.to(dtype).clone().requires_grad_(True), g.clone().requires_grad_(True)
     out = m(xg, live.to(dtype), g=gg, lens=lens)

@@ -9,7 +9,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.bfloat16: 3e-2, torch.float32: 1e-3}
+TOL = {torch.bfloat16: 3e-2, torch.float16: 6e-3, torch.float32: 1e-3}
+HALVES = (torch.bfloat16, torch.float16)
 
 
 def _oracle_core(q, k, v, ek, ev, lens_q, lens_k, H, w, scale=None):
@@ -144,7 +145,7 @@ def test_relattn_dropout_consistency(gpu, dtype):
         out2 = E.rel_attention(qkv2, ek.detach(), ev2, lens, H, w, p, 5)
     lhs = (d_o.float() * out2.float()).sum().item()
     rhs = (qkv.grad[..., 2 * C:].float() * v2.float()).sum().item() + (ev.grad * ev2).sum().item()
-    assert abs(lhs - rhs) < (2e-2 if dtype == torch.bfloat16 else 1e-3) * max(1.0, abs(lhs)), (lhs, rhs)
+    assert abs(lhs - rhs) < (2e-2 if dtype in HALVES else 1e-3) * max(1.0, abs(lhs)), (lhs, rhs)
     # dropout really drops: the p = 0 result differs, and its mean magnitude is preserved (inverted scaling)
     with torch.no_grad():
         out0 = E.rel_attention(qkv.detach(), ek.detach(), ev.detach(), lens, H, w, 0.0, 5)
@@ -190,14 +191,14 @@ def test_self_attention_block_parity(gpu, shape, packed, dtype):
     with torch.no_grad():
         for n_, p_ in m.named_parameters():
             if "conv" in n_:
-                p_.copy_(p_.bfloat16().float())          # the kernels see bf16 weights: give the oracle the same values
+                p_.copy_(p_.to(dtype).float())          # the kernels see 16-bit weights: give the oracle the same values
             if n_.endswith("bias"):
                 p_.normal_(0, 0.1)
-                p_.copy_(p_.bfloat16().float())
+                p_.copy_(p_.to(dtype).float())
     if packed:
         # inside a runtime the three projection weights are adjacent in the arena and run as ONE [3C, C] GEMM
         from easevoice_trainer_amd.runtime import ModelRuntime
-        rt = ModelRuntime(m, torch.bfloat16, gpu)
+        rt = ModelRuntime(m, dtype, gpu)
         rt.prepare()
         assert m._qkv_packed is not None and m._qkv_packed._slot is not None
         finish = rt.finish_grads
@@ -237,7 +238,7 @@ def test_self_attention_block_parity(gpu, shape, packed, dtype):
         if k == "conv_k.bias":
             # a constant added to every key shifts all scores of a query alike: the softmax does not see it, the exact
             # gradient is 0 and both sides hold rounding noise -- compare it with the size of the value-bias gradient
-            assert p_.grad.abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 1e-4) * sd["conv_v.bias"].grad.abs().max().item(), k
+            assert p_.grad.abs().max().item() < (2e-2 if dtype in HALVES else 1e-4) * sd["conv_v.bias"].grad.abs().max().item(), k
             continue
         close(p_.grad, sd[k].grad, k)
 
@@ -269,7 +270,7 @@ def test_mrte_block_parity(gpu, dtype):
     ge = torch.randn(B, 512, device=gpu).to(dtype)
     wgt = torch.randn(B, T, 192, device=gpu)
     yg, tg, gg = (v.clone().requires_grad_(True) for v in (y, t, ge))
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+    with torch.autocast("cuda", dtype=dtype if dtype in HALVES else torch.bfloat16, enabled=dtype in HALVES):
         out = m(yg, ym, tg, tm, gg, lens, tl)
     ((out.float() * ym) * wgt).sum().backward()
     bank.grads()
@@ -287,7 +288,7 @@ def test_mrte_block_parity(gpu, dtype):
     ref = F.conv1d(x * ymc, s["c_post.weight"], s["c_post.bias"]).transpose(1, 2)
     ((ref * ym.cpu()) * wgt.cpu()).sum().backward()
 
-    tol = 4e-2 if dtype == torch.bfloat16 else 1e-3
+    tol = 4e-2 if dtype in HALVES else 1e-3
     _close(out.float() * ym, ref * ym.cpu(), "out", tol, (B, T, Tt))
     _close(yg.grad.float() * ym, yr.grad * ym.cpu(), "dssl", tol, (B, T, Tt))
     _close(tg.grad.float() * tm, tr_.grad * tm.cpu(), "dtext", tol, (B, T, Tt))

@@ -9,6 +9,7 @@ import torch
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
+HALF = torch.bfloat16      # tests/test_fp16_ops_gpu.py re-runs this module's cases with torch.float16
 
 CASES = [(C, k, d, L) for C in (16, 32) for (k, d, L) in
          [(3, 1, 200), (3, 3, 64), (3, 5, 1000), (7, 1, 333), (7, 3, 640), (7, 5, 129), (11, 1, 130), (11, 3, 2048),
@@ -26,11 +27,11 @@ def _setup(gpu, C_, k, d, Lq, nseq=2):
         for c in m:
             c.weight_g.mul_(torch.rand_like(c.weight_g) + 0.5)
             c.bias.normal_(0, 0.2)
-    bank = HC.WeightBank(m, torch.bfloat16, gpu)
+    bank = HC.WeightBank(m, HALF, gpu)
     bank.build_tables()
     bank.fold()
-    x = torch.randn(nseq, Lq, C_, device=gpu).bfloat16()
-    dy = torch.randn(nseq, Lq, C_, device=gpu).bfloat16()
+    x = torch.randn(nseq, Lq, C_, device=gpu).to(HALF)
+    dy = torch.randn(nseq, Lq, C_, device=gpu).to(HALF)
     return HC, m, bank, x, dy
 
 
@@ -117,7 +118,7 @@ def test_fused_backward_scale_on_load(gpu, case):
     HC, m, bank, x, dy = _setup(gpu, C_, k, d, Lq)
     xa = HC._lrelu(x, LRELU_SLOPE)
     mid_a = HC._fwd(m[0]._slot, xa, None, 1.0, L.ACT_LRELU, LRELU_SLOPE)
-    pre = (dy.float() * (1.0 / 3.0)).bfloat16()
+    pre = (dy.float() * (1.0 / 3.0)).to(HALF)
     dx_a, g_a = _fused(HC, m, bank, xa, mid_a, pre, LRELU_SLOPE)
     dx_b, g_b = _fused(HC, m, bank, xa, mid_a, dy, LRELU_SLOPE, 1.0 / 3.0)
     assert torch.equal(dx_a, dx_b)
@@ -144,11 +145,11 @@ def test_fused_backward_vs_oracle(gpu, case):
     ws = []
     for q in po:
         w = O.weight_norm_fold(q["weight_v"], q["weight_g"])
-        ws.append(w + (w.detach().bfloat16().float() - w.detach()))
+        ws.append(w + (w.detach().to(HALF).float() - w.detach()))
     h = F.conv1d(F.leaky_relu(xo, LRELU_SLOPE), ws[0], po[0]["bias"], padding=get_padding(k, d), dilation=d)
     gate = torch.where(mid_a.float().cpu().transpose(1, 2) > 0, 1.0, LRELU_SLOPE)
     h = h * gate
-    h = h + (h.detach().bfloat16().float() - h.detach())
+    h = h + (h.detach().to(HALF).float() - h.detach())
     yo = xo + F.conv1d(h, ws[1], po[1]["bias"], padding=get_padding(k, 1))
     yo.backward(dy.float().cpu().transpose(1, 2))
     assert _rel(dx_f.transpose(1, 2), xo.grad) < 3e-2, "dx: " + _where(dx_f.transpose(1, 2), xo.grad)
@@ -172,11 +173,11 @@ def test_grouped_stage_vs_block_by_block(gpu, case):
         for p_ in blocks.parameters():
             if p_.dim() == 1:
                 p_.normal_(0, 0.2)
-    bank = HC.WeightBank(blocks, torch.bfloat16, gpu)
+    bank = HC.WeightBank(blocks, HALF, gpu)
     bank.build_tables()
     bank.fold()
-    x = torch.randn(2, Lq, C_, device=gpu).bfloat16()
-    dy = torch.randn(2, Lq, C_, device=gpu).bfloat16()
+    x = torch.randn(2, Lq, C_, device=gpu).to(HALF)
+    dy = torch.randn(2, Lq, C_, device=gpu).to(HALF)
 
     def run(fused):
         bank.zero_dw()
@@ -269,13 +270,13 @@ def test_wide_fused_step_vs_oracle(gpu, case):
     ws = []
     for q in po:
         w = O.weight_norm_fold(q["weight_v"], q["weight_g"])
-        ws.append(w + (w.detach().bfloat16().float() - w.detach()))
+        ws.append(w + (w.detach().to(HALF).float() - w.detach()))
     h = F.conv1d(F.leaky_relu(xo, LRELU_SLOPE), ws[0], po[0]["bias"], padding=get_padding(k, d), dilation=d)
     gate = torch.where(mid_f.float().cpu().transpose(1, 2) > 0, 1.0, LRELU_SLOPE)
     agree = ((h.detach() > 0) == (mid_f.float().cpu().transpose(1, 2) > 0))
     assert agree.float().mean().item() >= 0.999, agree.float().mean().item()
     h = h * gate
-    h = h + (h.detach().bfloat16().float() - h.detach())
+    h = h + (h.detach().to(HALF).float() - h.detach())
     yo = xo + F.conv1d(h, ws[1], po[1]["bias"], padding=get_padding(k, 1))
     yo.backward(dy.float().cpu().transpose(1, 2))
     assert _rel(y.transpose(1, 2), yo) < 3e-2, "y: " + _where(y.transpose(1, 2), yo)

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
+HALF = torch.bfloat16      # tests/test_fp16_ops_gpu.py re-runs this module's cases with torch.float16
 
 CASES = [(C, k, d, L) for C in (16, 32) for (k, d, L) in
          [(3, 1, 200), (3, 5, 1000), (7, 1, 333), (7, 3, 64), (11, 1, 130), (11, 5, 777), (11, 3, 2048)]]
@@ -29,11 +30,11 @@ def test_fused_resblock_step(gpu, case):
         for c in m:
             c.weight_g.mul_(torch.rand_like(c.weight_g) + 0.5)
             c.bias.normal_(0, 0.2)
-    bank = HC.WeightBank(m, torch.bfloat16, gpu)
+    bank = HC.WeightBank(m, HALF, gpu)
     bank.build_tables()
     bank.fold()
-    x = torch.randn(nseq, Lq, C_, device=gpu).bfloat16()
-    dy = torch.randn(nseq, Lq, C_, device=gpu).bfloat16()
+    x = torch.randn(nseq, Lq, C_, device=gpu).to(HALF)
+    dy = torch.randn(nseq, Lq, C_, device=gpu).to(HALF)
     s1, s2 = m[0]._slot, m[1]._slot
     assert HC._resunit_params(s1, s2, x, LRELU_SLOPE) is not None, "the fused path must cover this case"
 
@@ -62,7 +63,7 @@ def test_fused_resblock_step(gpu, case):
     ws = []
     for q in po:
         w = O.weight_norm_fold(q["weight_v"], q["weight_g"])
-        ws.append(w + (w.detach().bfloat16().float() - w.detach()))       # straight-through bf16 rounding
+        ws.append(w + (w.detach().to(HALF).float() - w.detach()))       # straight-through bf16 rounding
     h = F.conv1d(F.leaky_relu(xo, LRELU_SLOPE), ws[0], po[0]["bias"], padding=get_padding(k, d), dilation=d)
     # leaky-relu with the KERNEL's branch decisions (the sign of its stored intermediate): the folded weights are rounded
     # to bf16 on either side of an fp32 rounding difference, so a pre-activation within 1e-3 of zero may take the other
@@ -74,7 +75,7 @@ def test_fused_resblock_step(gpu, case):
     assert agree.float().mean().item() >= 0.999, agree.float().mean().item()
     assert float(h.detach()[~agree].abs().max() if (~agree).any() else 0.0) < 2e-2 * float(h.detach().abs().max())
     h = h * gate
-    h = h + (h.detach().bfloat16().float() - h.detach())                  # the intermediate is stored as bf16
+    h = h + (h.detach().to(HALF).float() - h.detach())                  # the intermediate is stored as bf16
     yo = xo + F.conv1d(h, ws[1], po[1]["bias"], padding=get_padding(k, 1))
     yo.backward(dy.float().cpu().transpose(1, 2))
     assert rel(y.transpose(1, 2), yo) < 3e-2, rel(y.transpose(1, 2), yo)

@@ -163,7 +163,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
     tag, a = max(agg.items(), key=lambda kv: kv[1]["us"])
     sec = a["us"] / 1e6
     tf, gbs = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
-    peak_tf = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
+    peak_tf = MFMA_BF16_PEAK_TF if args.dtype in ("bf16", "f16") else MFMA_F32_PEAK_TF
     ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = a["flops"] / max(a["bytes"], 1.0)
     if intensity >= ridge:
@@ -173,7 +173,7 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
     r_voc = None
     if voc["calls"]:
         vsec = voc["us"] / 1e6
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 2 if args.dtype in ("bf16", "f16") else 4
         alg = dec_algorithmic_bytes(args.batch, esz) * n_steps
         r_voc = dict(bound="hbm", achieved=alg / vsec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=alg / vsec / 1e9 / HBM_PEAK_GBS, ms_per_step=voc["us"] / 1e3 / n_steps,

@@ -119,7 +119,8 @@ def run(args, world, rank, local, extras=True):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
     if os.environ.get("EVT_BENCH_TINY") == "1":                              # dry runs only: a 2-layer toy of the model
         cfg["model"].update(hidden_dim=64, embedding_dim=64, head=4, n_layer=2, linear_units=256)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16      # --dtype f16 is the s2 leg's fp16_run mode
+    dtype_name = "f32" if args.dtype == "f32" else "bf16"
     torch.manual_seed(cfg["train"]["seed"])
     reducer = None
     if world > 1 or os.environ.get("EVT_DP_FORCE", "0") == "1":      # forced: one-rank collectives (bench.py --dp-program 2)
@@ -159,7 +160,7 @@ def run(args, world, rank, local, extras=True):
     res = {
         "metric": "tokens/sec (s1)", "value": tok / (dt / args.steps), "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"s1 AR text->semantic GPT micro-step (forward_old + backward, ScaledAdam every 4th "
                                f"micro-batch), batch={B}/GPU, x_len=256 + y_len=768, configs/gpt.yaml, attention dropout 0.1",
                    "global_batch": world * B, "seq_len": x_len + y_len,
@@ -171,11 +172,11 @@ def run(args, world, rank, local, extras=True):
         res["comm"] = comm       # per MICRO-step on rank 0 (one exchange every fourth): collectives, MiB, exposed wait
     if extras:
         try:
-            res["roofline"] = attention_roofline(eng, batch, B, x_len + y_len, args.dtype)
+            res["roofline"] = attention_roofline(eng, batch, B, x_len + y_len, dtype_name)
             if B != 16:       # north_star quotes MFMA utilisation of the attention "at batch 16"
                 b16 = _batch(16, x_len, y_len, dev, 99)
                 eng.micro_step(b16, 1)
-                r16 = attention_roofline(eng, b16, 16, x_len + y_len, args.dtype)
+                r16 = attention_roofline(eng, b16, 16, x_len + y_len, dtype_name)
                 res["roofline"]["at_batch_16"] = {k: r16.get(k) for k in ("achieved", "frac", "frac_credited", "avg_launch_us",
                                                                           "also", "attention_ms_per_micro_step")}
         except Exception as e:
