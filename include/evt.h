@@ -695,6 +695,21 @@ int evt_scaled_adam_stats(const float* param, const float* grad, const evt_sa_ch
 int evt_scaled_adam_apply(float* param, const float* grad, float* delta, float* exp_avg_sq, const evt_sa_chunk* chunks,
                           int32_t nchunks, const float* coef, const evt_scaled_adam_hp* hp, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Feature extractors behind the training set (src/normalization/normalize.py:88-106 `_get_bert_feature`,
+ * :132-180 `_name2go` of the reference: transformers' BertForMaskedLM / HubertModel on the CPU).  Their transformer
+ * layers run on the entry points above (1x1 convolutions = the Linear layers, evt_mha_fwd, evt_res_dropout_ln_fwd);
+ * these two are what they need besides.  Forward only (inference).
+ *   evt_gelu_rows_fwd: out[b][t][:] = gelu(x[b][t][:] + bias) for t < t_out <= t_in, erf form (transformers' "gelu");
+ *     x [nseq][t_in][C], out [nseq][t_out][C], bias fp32 [C] or NULL.  t_out = t_in - 1 is the trim of HuBERT's positional
+ *     convolution (HubertSamePadLayer drops the last frame of an even kernel).
+ *   evt_channel_norm_gelu_fwd: per (sequence, channel) normalisation over the T frames, affine, then GELU if apply_gelu:
+ *     GroupNorm(num_groups = C) + GELU of HuBERT's first feature-extractor layer.  x, out [nseq][T][C]; biased variance. */
+int evt_gelu_rows_fwd(int32_t dtype, const void* x, const float* bias, void* out, int64_t nseq, int32_t t_in, int32_t t_out,
+                      int32_t C, void* stream);
+int evt_channel_norm_gelu_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, float eps, void* out,
+                              int32_t nseq, int32_t T, int32_t C, int32_t apply_gelu, void* stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }
