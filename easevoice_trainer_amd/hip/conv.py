@@ -322,6 +322,7 @@ class WeightBank:
                 torch.cuda.current_stream(self.device).wait_stream(self._side)
             self._held.clear()
         self.dw_arena.zero_()            # slab 0 of every image and the slab counters
+        self._tables_checked = False     # the gradient tensors are looked at once per step, by the first grads() call
         for s in self.slots:
             s.wg_used, s.wg_dirty = 0, False
 
@@ -369,10 +370,18 @@ class WeightBank:
         return self._slot_rows[idx[0]][0], self._slot_rows[idx[-1]][1]
 
     def check_tables(self):
-        if self._items is None or (not torch.cuda.is_current_stream_capturing() and self._grad_stamp != self._grad_ptrs()):
-            # a .grad was replaced since the tables were built (zero_grad(set_to_none=True), a caller assigning a new
-            # tensor): the fused bias gradients / dv / dg would go to the old storage -- rebuild the tables
+        """a .grad replaced since the tables were built (zero_grad(set_to_none=True), a caller assigning a new tensor) would
+        leave the fused bias gradients / dv / dg writing to the old storage -- rebuild the tables.  Looked at ONCE per step
+        (zero_dw() re-arms it): the data-parallel program calls grads() per sub-model, and walking every slot's three
+        pointers each time was pure host time on a launch-bound path.  A capture validates before it records: the check
+        runs on the eager steps that precede it, and a replaced tensor between capture and replay would invalidate the
+        graph's other recorded pointers as well."""
+        if self._items is None:
             self.build_tables()
+        elif not getattr(self, "_tables_checked", False) and not torch.cuda.is_current_stream_capturing():
+            if self._grad_stamp != self._grad_ptrs():
+                self.build_tables()
+            self._tables_checked = True
 
     def grads(self, lo=None, hi=None, join=True):
         """dW images -> weight_v.grad / weight_g.grad (or weight.grad), ACCUMULATED (+=): one launch over the whole

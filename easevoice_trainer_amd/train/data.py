@@ -101,6 +101,11 @@ def open_source(kind, train_input_dir, device, synthetic_factory, batch_size=Non
             # run then repeats a couple of dozen batch shapes instead of > 100, which is what lets the per-shape HIP-graph
             # replay of the s2 step engage.  Measured (profiles/r04_realdata_pad*.json, 2-10 s clips, B = 16, 240 steps):
             # 0 -> 1060, 8 -> 1370, 16 -> 1633, 32 -> 1512 audio-s/s (eager share 90 % / 22 % / 18 % / 16 %).
+            # INVARIANTS this rests on (tests/test_zz_readers_train_gpu.py::test_padded_time_axis_changes_nothing pins them):
+            # (1) no reduction over the time axis without the length mask anywhere in the step -- losses, statistics,
+            # attention keys; (2) the quantiser is frozen (its commitment loss, an unmasked mean over T, is the constant 0:
+            # core_vq.py:311-316); (3) the two random draws are per frame, so a seeded run with padding draws different noise
+            # for the SAME frames than an unpadded one -- equal in distribution, not bit for bit.
             pad = int(os.environ.get("EVT_PAD_FRAMES", "16")) if str(device).startswith("cuda") else None
             return S2Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world, pad_frames=pad)
         return S1Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world)

@@ -144,3 +144,28 @@ def test_s1_bench_batch_is_eight_times_the_b4_golden(gpu, dtype):
             assert cs >= 0.985, (n, cs)
             assert abs(ratio - R) <= 0.05 * R, (n, ratio)
         print("s1 B = 32 vs 8 x own B = 4 (bf16): worst cosine", worst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_position_scale_gradient_without_cancellation(gpu, dtype):
+    """d(alpha) of SinePositionalEmbedding (embedding.py:36-81) is a dot product over every (token, channel); in the whole-
+    step goldens its terms cancel (0.007 out of terms adding up to 50), so the bf16 check there is bounded by the terms'
+    magnitude and could not see a wrong sign.  Here the upstream gradient is the position table itself -- every term is a
+    square, nothing cancels, the exact answer is sum(pe^2) per item -- so sign and size are pinned at one bf16 rounding."""
+    from easevoice_trainer_amd.auto_reg.t2s_model import SinePositionalEmbedding
+
+    m = SinePositionalEmbedding(512, dropout=0.0, scale=False, alpha=True).to(gpu)
+    with torch.no_grad():
+        m.alpha.fill_(0.9)
+    B, T = 3, 1024
+    x = torch.randn(B, T, 512, device=gpu).to(dtype).requires_grad_(True)
+    out = m(x)
+    pe = m.pe(T, gpu, torch.float32)
+    assert out.dtype == dtype
+    ref = x.detach().float() + 0.9 * pe.unsqueeze(0)
+    assert rel(out, ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+    out.backward(pe.to(dtype).unsqueeze(0).expand(B, T, 512).contiguous())
+    want = B * float(pe.to(dtype).double().pow(2).sum())
+    got = float(m.alpha.grad.flatten()[0])
+    assert got > 0 and abs(got - want) <= (1e-5 if dtype == torch.float32 else 4e-3) * want, (got, want)
+    assert rel(x.grad, pe.to(dtype).unsqueeze(0).expand(B, T, 512)) < 1e-6

@@ -122,6 +122,10 @@ def test_whole_step_c2_vs_reference(gpu, dtype):
     # which every loss only sums over)
     # bf16: the logits are read off a waveform that itself sits 4.7e-2 from the reference's (bound 8e-2 above); measured
     # 4e-2 .. 5.2e-2 over equal-precision variants of the generator's element-wise chains -- the same band as the waveform
+    # Error budget of this bound, stage by stage: the discriminators ALONE, on one fixed waveform, hold 3e-2 against fp32
+    # (tests/test_disc_gen_gpu.py); the waveform holds 8e-2 (above).  That the bound hides no arithmetic regression is pinned
+    # elsewhere at full width: the same kernels built for IEEE half reproduce the reference's float16 step to 2.5e-3 on every
+    # loss term (tests/test_s2_fp16_gpu.py), and the fp32 instantiation holds 1e-3 here.
     assert rel(out.extras["d_logits"][0][:, :16], gold["d_logits_head"][0]) < (1e-3 if f32 else 8e-2)
 
 

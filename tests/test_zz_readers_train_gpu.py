@@ -90,3 +90,53 @@ def test_gpt_train_from_feature_dir(gpu, feature_dir, tmp_path, monkeypatch):
     losses = [json.loads(l.split(" ", 1)[1])["loss"] for l in lines]
     assert all(v == v and v > 0 for v in losses)
     assert os.path.isfile(os.path.join(out.model_path, "gd-e1.ckpt"))
+
+
+def test_padded_time_axis_changes_nothing(gpu):
+    """The trainer pads a batch's time axes up to a multiple of 16 frames (train/data.py: EVT_PAD_FRAMES, a departure from the
+    reference's collate layout that lets repeated shapes replay as HIP graphs).  That is only sound while every consumer masks
+    by the lengths: one fp32 step on a batch of two ragged items, once as collated (T = 100) and once with 12 frames of
+    padding appended to every time axis (ssl, spectrogram, waveform, the injected noise), must give the same losses and the
+    same gradients.  A future unmasked reduction over T -- or an unfrozen quantiser, whose commitment loss is one -- fails
+    here."""
+    from easevoice_trainer_amd.module.mel_processing import spectrogram_torch
+    from easevoice_trainer_amd.train.s2_engine import S2Engine
+    from util_fill import fill_module, s2_batch
+
+    hps = json.load(open(os.path.join(os.path.dirname(HERE), "configs", "s2.json")))
+    hps["model"]["p_dropout"] = 0.0
+    b = s2_batch(2, 100, 40)
+    lengths = torch.tensor([100, 77])
+    res = []
+    for pad in (0, 12):
+        eng = S2Engine(hps, gpu, torch.float32)
+        for m in eng.net_g.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        fill_module(eng.net_g, 1)
+        fill_module(eng.net_d, 2)
+        T = 100 + pad
+        wav = torch.zeros(2, 1, T * 640)
+        wav[:, :, :100 * 640] = b["wav"]
+        wav[1, :, 77 * 640:] = 0.0                       # the reference's collate zero-fills behind an item's end
+        ssl = torch.zeros(2, 768, T)
+        ssl[:, :, :100] = b["ssl"]
+        ssl[1, :, 77:] = 0.0
+        eps = torch.randn(2, 192, T, generator=torch.Generator().manual_seed(pad + 1))     # padding frames: any noise
+        eps[:, :, :100] = b["eps"]
+        spec = spectrogram_torch(wav.squeeze(1).to(gpu), 2048, 32000, 640, 2048)
+        assert spec.size(2) == T
+        ids = torch.tensor([10, 30])                     # both segments inside the live part of their item
+        out = eng.step(ssl.to(gpu), spec, lengths.to(gpu), wav.to(gpu), b["text"].to(gpu), b["text_lengths"].to(gpu),
+                       eps=eps.to(gpu), ids_slice=ids.to(gpu), do_opt=False)
+        torch.cuda.synchronize()
+        res.append((dict(disc=float(out.disc), gen=float(out.gen), fm=float(out.fm), mel=float(out.mel), kl=float(out.kl)),
+                    eng.rt_g.arena.grad.detach().cpu().clone(), eng.rt_d.arena.grad.detach().cpu().clone()))
+        del eng
+        torch.cuda.empty_cache()
+    (l0, g0, d0), (l1, g1, d1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
+    for a, c, what in ((g0, g1, "G"), (d0, d1, "D")):
+        err = float((a - c).abs().max() / (a.abs().max() + 1e-12))
+        assert err < 1e-4, (what, err)
