@@ -235,7 +235,13 @@ def cpu_baseline_s2(args, hard_timeout_s=170.0):
 
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--stage", "s2", "--batch", str(args.batch),
            "--clip-seconds", str(args.clip_seconds), "--budget", "60"]
-    return _cpu_subprocess(cmd, hard_timeout_s, "audio-s/s", "oracle s2 step")
+    out = _cpu_subprocess(cmd, hard_timeout_s, "audio-s/s", "oracle s2 step")
+    if isinstance(out, dict):
+        # kind "port": the GPU box has no reference checkout.  How far the port's step time is from the reference's own was
+        # measured where both exist (tools/cpu_baseline.py --with-reference on the build box, 8 threads, same batch)
+        out["port_vs_reference"] = ("the oracle port's step takes 0.94-1.02 x the reference's own modules' on the build box "
+                                    "(profiles/r05_cpu_port_vs_reference.txt)")
+    return out
 
 
 def cpu_baseline_s1(hard_timeout_s=170.0):

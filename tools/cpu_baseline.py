@@ -58,8 +58,70 @@ def main_s1(a, threads):
                    f"(batch sized to {_mem_available_gb():.0f} GB of free host memory)")), flush=True)
 
 
+def time_reference_s2(B, clip_seconds, threads, steps=3):
+    """Build box only (needs /root/reference): the REFERENCE's own modules through the reference's loop body
+    (src/train/sovits.py:459-525 in fp32: G forward, D step, G step, both torch.optim.AdamW updates) on the batch the port is
+    timed on -- so that the `cpu_baseline` of the bench line (kind "port": the GPU box has no reference checkout) can be read
+    against the reference's own step time.  Returns seconds per step (median)."""
+    import torch
+
+    from oracle import refshim
+
+    refshim.install()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_r2 import g_groups
+    from src.easevoice.module import commons, models
+    from src.easevoice.module.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+    from src.easevoice.module.mel_processing import mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch
+
+    torch.set_num_threads(threads)
+    cfg = json.load(open(os.path.join(refshim.REFERENCE_ROOT, "configs", "s2.json")))
+    t = cfg["train"]
+    torch.manual_seed(1234)
+    net_g = models.SynthesizerTrn(1025, 32, n_speakers=300, **cfg["model"])
+    net_d = models.MultiPeriodDiscriminator(False)
+    cb = net_g.quantizer.vq.layers[0]._codebook
+    cb.embed.normal_()
+    cb.inited.fill_(1.0)
+    lr, low = t["learning_rate"], t["learning_rate"] * t["text_low_lr_rate"]
+    optim_g = torch.optim.AdamW(g_groups(net_g, lr, low), lr, betas=t["betas"], eps=t["eps"])
+    optim_d = torch.optim.AdamW(net_d.parameters(), lr, betas=t["betas"], eps=t["eps"])
+    T, tt = clip_seconds * 50, 60
+    gen = torch.Generator().manual_seed(1234)
+    wav = torch.rand(B, 1, T * 640, generator=gen) - 0.5
+    ssl = torch.randn(B, 768, T, generator=gen)
+    text = torch.randint(0, 732, (B, tt), generator=gen)
+    lens, tl = torch.full((B,), T), torch.full((B,), tt)
+    spec = spectrogram_torch(wav.squeeze(1), 2048, 32000, 640, 2048, center=False)
+    times = []
+    for step in range(steps + 1):
+        t0 = time.perf_counter()
+        y_hat, kl_ssl, ids_slice, x_mask, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), _ = net_g(ssl, spec, lens, text, tl)
+        mel = spec_to_mel_torch(spec, 2048, 128, 32000, 0.0, None)
+        y_mel = commons.slice_segments(mel, ids_slice, 32)
+        y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), 2048, 128, 32000, 640, 2048, 0.0, None)
+        y = commons.slice_segments(wav, ids_slice * 640, 20480)
+        y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+        loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
+        optim_d.zero_grad()
+        loss_disc.backward()
+        optim_d.step()
+        y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = net_d(y, y_hat)
+        loss_gen_all = (generator_loss(y_d_hat_g)[0] + feature_loss(fmap_r, fmap_g)
+                        + torch.nn.functional.l1_loss(y_mel, y_hat_mel) * t["c_mel"] + kl_ssl * 1
+                        + kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * t["c_kl"])
+        optim_g.zero_grad()
+        loss_gen_all.backward()
+        optim_g.step()
+        if step:
+            times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--with-reference", action="store_true",
+                    help="build box only: also time the reference's own modules on the same batch and print the port / reference ratio")
     ap.add_argument("--stage", default="s2", choices=["s2", "s1"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--clip-seconds", type=int, default=4)
@@ -121,6 +183,13 @@ def main():
             value=B * a.clip_seconds / med, unit="audio-s/s", cores=threads, kind="port", seconds_per_step=med,
             sample=f"oracle s2 step (fwd + D/G backward + AdamW on every tensor), batch {B} x {a.clip_seconds} s clips, "
                    f"fp32, {threads} threads, 1 warm-up + {len(times)} timed steps, median {med:.2f} s/step")), flush=True)
+    if a.with_reference and os.path.isdir("/root/reference"):
+        ref = time_reference_s2(B, a.clip_seconds, threads)
+        print(json.dumps(dict(kind="reference", seconds_per_step=ref, value=B * a.clip_seconds / ref, unit="audio-s/s",
+                              cores=threads, port_over_reference=med / ref,
+                              sample=f"the reference's own modules (src/train/sovits.py:459-525 body, fp32, torch AdamW), batch "
+                                     f"{B} x {a.clip_seconds} s clips, {threads} threads, 1 warm-up + 3 timed steps, median "
+                                     f"{ref:.2f} s/step; the oracle port takes {med / ref:.2f} x that")), flush=True)
 
 
 if __name__ == "__main__":
