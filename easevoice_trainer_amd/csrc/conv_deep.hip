@@ -1316,7 +1316,11 @@ int launch_conv_deep(const ConvP& p_in, int out_ch, int k_ch, int nphase, hipStr
     p.P = (int)(((long)p.nseq * p.Q + 63) / 64);
     p.U = 0;
     // 4 stages: 6 / 8 stages were measured no faster (the 3-36-stage chains cost 0.25-0.5 us per stage; ~10 us of every
-    // launch is fixed cost) and leave room for only one block per CU
+    // launch is fixed cost) and leave room for only one block per CU.  Round 5 (profiles/r05_ring_tiles.txt): 64 x 128,
+    // 128 x 64 and 128 x 128 tiles and 3 / 6 stages of this kernel on the 3200-position layers -- none faster stand-alone
+    // (WN in-layer 12 us forward either way), all slower in the step (23.4 -> 24.0-24.8 ms): fewer, fatter blocks lose more
+    // to their own latency chains than the halved block count gives back.  Stand-alone the WN in-layer forward takes 12 us
+    // where the step's trace shows 19 us: in the step every layer's 369 KB weight image is read for the first time.
     constexpr int NS = 4;
     static bool attr1 = false;
     const size_t lds1 = (size_t)NS * (64 + 64) * 128;

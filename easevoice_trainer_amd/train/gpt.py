@@ -36,10 +36,27 @@ class GPTTrainParams:
     project_dir: str = ""
 
 
+def compute_dtype(config):
+    """train.precision as Lightning reads it (src/train/gpt.py:112-113,157; configs/gpt.yaml: "16-mixed"): "16-mixed" ->
+    torch.float16 with loss scaling (train/s1_engine.py), "bf16-mixed" -> bfloat16, "32" -> float32.  EVT_HALF=bf16 runs a
+    16-mixed config in bfloat16 instead (no loss scaling needed; the default before round 5)."""
+    prec = str(config["train"].get("precision", "32"))
+    if prec.startswith("bf16"):
+        return torch.bfloat16
+    if prec.startswith("16"):
+        half = os.environ.get("EVT_HALF", "f16").lower()
+        if half in ("bf16", "bfloat16"):
+            return torch.bfloat16
+        if half in ("f16", "fp16", "float16", "half"):
+            return torch.float16
+        raise ValueError(f"EVT_HALF={half!r}: expected f16 or bf16")
+    return torch.float32
+
+
 class GPTTrain:
-    def __init__(self, params: GPTTrainParams, dtype=torch.bfloat16, config_path=None):
+    def __init__(self, params: GPTTrainParams, dtype=None, config_path=None):
         self.config = yaml.safe_load(open(config_path or os.path.join(repo_root(), "configs", "gpt.yaml")))
-        self.params, self.dtype = params, dtype
+        self.params, self.dtype = params, (dtype if dtype is not None else compute_dtype(self.config))
         self.train_output = get_gpt_train_dir(params.project_dir, params.output_model_name)
         self.train_logs_output = os.path.join(self.train_output, train_logs_path)
         self.train_ckpts_output = os.path.join(self.train_logs_output, "ckpt")

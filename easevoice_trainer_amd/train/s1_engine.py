@@ -14,11 +14,17 @@ import torch
 from ..auto_reg.optim import ScaledAdam, WarmupCosineLRSchedule
 from ..auto_reg.t2s_model import Text2SemanticDecoder
 from ..hip import lib as L
-from ..runtime import ParamArena
+from ..runtime import DeviceGradScaler, ParamArena
 
 
 class S1Engine:
-    def __init__(self, config: dict, device="cuda:0", dtype=torch.bfloat16, reducer=None):
+    def __init__(self, config: dict, device="cuda:0", dtype=torch.bfloat16, reducer=None, scaler_args=None):
+        """dtype torch.float16: the reference's `precision: 16-mixed` (configs/gpt.yaml:6; Lightning's AMP plugin around the
+        manual optimisation of t2s_lightning_module.py:41-89: manual_backward scales the loss, the optimiser step every fourth
+        micro-batch unscales, skips on an overflow and updates the scale).  The scaled gradients of the four micro-batches
+        accumulate in the arena under ONE scale (update() only runs at the step), the arena is unscaled and checked once, after
+        the data-parallel sum; the skip decision is read on the host there -- one read per four micro-batches, exactly where
+        torch's GradScaler.step has its own `.item()`."""
         L.set_half(dtype)
         L.lib()
         self.config, self.device, self.dtype, self.reducer = config, torch.device(device), dtype, reducer
@@ -36,6 +42,8 @@ class S1Engine:
         self.scheduler = WarmupCosineLRSchedule(self.optimizer, init_lr=o["lr_init"], peak_lr=o["lr"],
                                                 end_lr=o["lr_end"], warmup_steps=o["warmup_steps"],
                                                 total_steps=o["decay_steps"])
+        self.scaler = DeviceGradScaler(self.device, enabled=dtype == torch.float16, **(scaler_args or {}))
+        self.skipped_steps = 0
         self.arena.zero_grad()
         self._views = [(p, p.grad) for p in self.model.parameters()]
         for p, v in self._views:       # the GEMM weight-gradient launches accumulate straight into these (hip/linear.py)
@@ -77,7 +85,7 @@ class S1Engine:
         self._reduced_from = None
         self.model.h.grad_hook = self._piece_done if overlap else None
         try:
-            loss.backward()
+            self.scaler.scale(loss).backward()
         finally:
             self.model.h.grad_hook = None
         hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
@@ -89,10 +97,18 @@ class S1Engine:
             if self.reducer is not None and self.reducer.active:
                 self.reducer.all_reduce(self.arena.grad[:hi], async_op=self.arena.grad.is_cuda, average=True)
                 self.reducer.wait()
-            self.optimizer.step()
-            self.bank.mark_dirty()        # weights written through raw pointers: refold the GEMM images on next use
+            overflow = False
+            if self.scaler.enabled:
+                self.scaler.unscale_(self)                                    # self.arena: every rank holds the same sums
+                overflow = bool(self.scaler.found_inf(self).item() != 0.0)    # GradScaler.step's host read
+            if not overflow:
+                self.optimizer.step()
+                self.bank.mark_dirty()    # weights written through raw pointers: refold the GEMM images on next use
+            else:
+                self.skipped_steps += 1
+            self.scaler.update()
             self.optimizer.zero_grad()
-            self.scheduler.step()
+            self.scheduler.step()         # Lightning steps the scheduler whether or not the scaler skipped the optimiser
             stepped = True
         return loss.detach(), acc.detach(), stepped
 

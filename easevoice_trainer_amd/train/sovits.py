@@ -37,8 +37,24 @@ class SovitsTrainParams:
     project_dir: str = ""
 
 
+def compute_dtype(hps):
+    """The step's compute type from the config, as the reference reads it (src/train/sovits.py:378,459: `fp16_run` switches the
+    float16 autocast and the GradScaler on): fp16_run true -> torch.float16 on the IEEE-half build of the library with the
+    device-side GradScaler (train/s2_engine.py), false -> float32.  EVT_HALF=bf16 runs a half-precision config in bfloat16
+    instead -- same kernels and speed, fp32's exponent range, so no loss scaling and no skipped steps; a deliberate departure
+    from the reference that has to be asked for (until round 5 it was the silent default)."""
+    if not hps["train"].get("fp16_run", False):
+        return torch.float32
+    half = os.environ.get("EVT_HALF", "f16").lower()
+    if half in ("f16", "fp16", "float16", "half"):
+        return torch.float16
+    if half in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError(f"EVT_HALF={half!r}: expected f16 or bf16")
+
+
 class SovitsTrain:
-    def __init__(self, params: SovitsTrainParams, dtype=torch.bfloat16, config_path=None):
+    def __init__(self, params: SovitsTrainParams, dtype=None, config_path=None):
         hps = json.load(open(config_path or os.path.join(repo_root(), "configs", "s2.json")))
         t = hps["train"]
         t["batch_size"], t["epochs"], t["text_low_lr_rate"] = params.batch_size, params.total_epochs, params.text_low_lr_rate
@@ -56,7 +72,7 @@ class SovitsTrain:
         t["pretrained_s2D"] = default_pretrained("s2D") if params.pretrained_s2D in (stock[0], stock[2]) else params.pretrained_s2D
         os.makedirs(t["output_dir"], exist_ok=True)
         os.makedirs(t["train_logs_dir"], exist_ok=True)
-        self.hps, self.params, self.dtype = hps, params, dtype
+        self.hps, self.params, self.dtype = hps, params, (dtype if dtype is not None else compute_dtype(hps))
         self.global_step = 0
 
     # ---- export for inference (sovits.py:179-196): fp16 weights without enc_q, config, info ----

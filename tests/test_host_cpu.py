@@ -582,3 +582,38 @@ def test_slab_count_policy():
     assert slab_count(32 * 32 * 11 * 4, 32) == 256
     assert slab_count(0, 1) == 256 and slab_count(1 << 30, 512) == 1
     assert slab_count(128 * 128 * 11 * 4, 128, cap=8) == 8 and slab_count(4 << 20, 512, budget=8 << 20) == 2
+
+
+def test_compute_dtype_follows_fp16_run(monkeypatch):
+    """train.fp16_run (configs/s2.json: true) selects the reference's float16 + GradScaler mode; bfloat16 only on request"""
+    import json
+
+    from easevoice_trainer_amd.train.sovits import compute_dtype
+
+    hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
+    monkeypatch.delenv("EVT_HALF", raising=False)
+    assert hps["train"]["fp16_run"] is True and compute_dtype(hps) == torch.float16
+    monkeypatch.setenv("EVT_HALF", "bf16")
+    assert compute_dtype(hps) == torch.bfloat16
+    monkeypatch.setenv("EVT_HALF", "fp8")
+    with pytest.raises(ValueError):
+        compute_dtype(hps)
+    hps["train"]["fp16_run"] = False
+    assert compute_dtype(hps) == torch.float32
+
+
+def test_s1_compute_dtype_follows_precision(monkeypatch):
+    """train.precision (configs/gpt.yaml: 16-mixed) selects float16 + loss scaling; bfloat16 on request or by config"""
+    import yaml
+
+    from easevoice_trainer_amd.train.gpt import compute_dtype
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "gpt.yaml")))
+    monkeypatch.delenv("EVT_HALF", raising=False)
+    assert cfg["train"]["precision"] == "16-mixed" and compute_dtype(cfg) == torch.float16
+    monkeypatch.setenv("EVT_HALF", "bf16")
+    assert compute_dtype(cfg) == torch.bfloat16
+    cfg["train"]["precision"] = "bf16-mixed"
+    assert compute_dtype(cfg) == torch.bfloat16
+    cfg["train"]["precision"] = "32"
+    assert compute_dtype(cfg) == torch.float32
