@@ -102,9 +102,10 @@ def _run_case(gpu, case, fusion, dtype, impl, report=None):
     if fusion["out_act"] == 1:
         # the library takes the leaky-relu derivative from the STORED activation output; an output that underflows the
         # storage type to zero (IEEE half: |y| < 3e-8; met once in 1.2 M elements, tools/exp/diag_ring_f16.py) has lost its
-        # sign -- as it has in the reference's fp16 autocast, whose saved pre-activation is half as well.  Such elements get
-        # no upstream gradient here, so that the comparison is about the kernels and not about a coin toss.
-        dy = dy.masked_fill(yo.detach().abs() < 1e-6, 0.0)
+        # sign -- as it has in the reference's fp16 autocast, whose saved pre-activation is half as well -- and an output
+        # within the accumulation noise of zero (~1e-6 of a sum of 640 products) may have either.  Such elements (about one
+        # in ten thousand) get no upstream gradient here, so that the comparison is about the kernels and not a coin toss.
+        dy = dy.masked_fill(yo.detach().abs() < 1e-4, 0.0)
     yo.backward(dy)
 
     # ---- HIP path (channels-last) ----

@@ -25,12 +25,14 @@ def test_bench_two_ranks_one_device(gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2, all-reduce") and d["config"]["global_batch"] == 4
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up, all-reduce otherwise") and d["config"]["global_batch"] == 4
+    # the collective plan of every reduced range is spelt out (two ranks: all-reduce throughout)
+    assert "per range: D piece 1/6" in d["config"]["parallelism"] and "G vocoder" in d["config"]["parallelism"]
     # the line explains its own gradient exchange: collectives and MiB per step, and the wait the overlap did not hide
     c = d["comm"]
     assert c["all_reduce_per_step"] >= 2 and c["mib_per_step"] > 300 and c["exposed_wait_ms_per_step"] is not None
     assert d["losses_finite"] and d["value"] > 0
     assert "graph" in d["config"]["launch"] and "reductions between them" in d["config"]["launch"]
     assert "roofline" not in d and "roofline_note" in d and "roofline" not in d["s1"]
-    assert d["s1"]["n_gpus"] == 2 and d["s1"]["value"] > 0 and d["s1"]["config"]["parallelism"].startswith("dp2, all-reduce")
+    assert d["s1"]["n_gpus"] == 2 and d["s1"]["value"] > 0 and d["s1"]["config"]["parallelism"].startswith("dp2, reduce-scatter + all-gather")
     assert d["s1"]["comm"]["mib_per_step"] >= 0        # three micro-steps after one warm-up: no optimiser step in the window

@@ -135,8 +135,10 @@ def test_padded_time_axis_changes_nothing(gpu):
         del eng
         torch.cuda.empty_cache()
     (l0, g0, d0), (l1, g1, d1) = res
+    # same arithmetic, other tile boundaries (T = 100 vs 112): fp32 summation order differs, measured 2.4e-5 on a loss behind
+    # ninety layers; a reduction that saw the 12 padded frames of 112 would be off by per cent
     for k in l0:
-        assert abs(l0[k] - l1[k]) <= 1e-5 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
+        assert abs(l0[k] - l1[k]) <= 2e-4 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
     for a, c, what in ((g0, g1, "G"), (d0, d1, "D")):
         err = float((a - c).abs().max() / (a.abs().max() + 1e-12))
-        assert err < 1e-4, (what, err)
+        assert err < 2e-3, (what, err)
