@@ -131,14 +131,17 @@ def test_padded_time_axis_changes_nothing(gpu):
                        eps=eps.to(gpu), ids_slice=ids.to(gpu), do_opt=False)
         torch.cuda.synchronize()
         res.append((dict(disc=float(out.disc), gen=float(out.gen), fm=float(out.fm), mel=float(out.mel), kl=float(out.kl)),
-                    eng.rt_g.arena.grad.detach().cpu().clone(), eng.rt_d.arena.grad.detach().cpu().clone()))
+                    eng.rt_g.arena.grad.detach().cpu().clone(), eng.rt_d.arena.grad.detach().cpu().clone(),
+                    out.extras["y_hat"].detach().float().cpu().clone()))
         del eng
         torch.cuda.empty_cache()
-    (l0, g0, d0), (l1, g1, d1) = res
-    # same arithmetic, other tile boundaries (T = 100 vs 112): fp32 summation order differs, measured 2.4e-5 on a loss behind
-    # ninety layers; a reduction that saw the 12 padded frames of 112 would be off by per cent
+    (l0, g0, d0, y0), (l1, g1, d1, y1) = res
+    # same arithmetic, other tile boundaries (T = 100 vs 112): fp32 summation order differs -- measured 2.4e-5 on the
+    # adversarial loss behind ninety layers, 3.9e-4 on the mel term (a log of a near-silent random-init waveform); a reduction
+    # that saw the 12 padded frames of 112 would be off by per cent
+    assert float((y0 - y1).abs().max()) <= 1e-3 * float(y0.abs().max())
     for k in l0:
-        assert abs(l0[k] - l1[k]) <= 2e-4 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
+        assert abs(l0[k] - l1[k]) <= 1e-3 * max(abs(l0[k]), 1e-3), (k, l0[k], l1[k])
     for a, c, what in ((g0, g1, "G"), (d0, d1, "D")):
         err = float((a - c).abs().max() / (a.abs().max() + 1e-12))
         assert err < 2e-3, (what, err)
