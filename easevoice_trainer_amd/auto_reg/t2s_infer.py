@@ -183,6 +183,7 @@ class T2SInfer:
         if m.training:
             raise L.EvtError("decoding needs model.eval() (the reference decodes with dropout off)")
         dev, cd = xs[0].device, m.cd
+        L.set_half(cd)                        # a 16-bit streaming dtype selects the build of the library that serves it
         B = len(xs)
         W = self.weights(cd)
         # ---- prompt pass (t2s_model.py:575-660 / 775-825, T2SBlock.process_prompt) ----

@@ -43,6 +43,13 @@ __device__ __forceinline__ int fold_row_of_block(int b, int nrows) {
   return row < nrows ? row : -1;
 }
 
+// Round 5, tried and dropped (profiles/r05_fold_tiled_negative.txt): one block per 32 consecutive rows of a layer, every wave
+// transposing its own 64-column tiles through a wave-private LDS square so that the ALT image leaves as whole 64-byte runs
+// (no block barrier after the norms).  Same images (tested), 3.3 x SLOWER: 1126 us against 337 us per launch, the s2 step
+// 23.25 -> 24.9 ms.  The row-per-block form wins on parallelism -- 12 K blocks of 256 threads with ~20 elements each, against
+// 375 blocks whose waves walk 20 tiles of 96 memory instructions in sequence -- and both forms issue the same number of
+// 2-byte store instructions per element; a version that pays off has to make the stores 16 bytes per lane for BOTH images
+// (REG runs are 8 consecutive input channels at a stride of k floats in the source row), which needs tiles of 8 k columns.
 __global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* items, const int32_t* rows, int nrows) {
   __shared__ float red[4];
   const int trow = fold_row_of_block(blockIdx.x, nrows);

@@ -6,6 +6,7 @@ dropped, the weights are loaded non-strictly and the module is put in eval mode.
 the HIP kernels (runtime.ModelRuntime) is built and folded once, since inference never updates the parameters."""
 import torch
 
+from ..hip import lib as L
 from ..module import models
 from ..runtime import ModelRuntime
 
@@ -36,6 +37,7 @@ class SoVITSVoice:
 
     @torch.no_grad()
     def decode(self, codes, text, refer, noise_scale=0.5, speed=1, noise=None):
+        L.set_half(self.dtype)
         mv = lambda t: t.to(self.device)
         refer = [mv(r) for r in refer] if isinstance(refer, (list, tuple)) else mv(refer)
         return self.model.decode(mv(codes), mv(text), refer, noise_scale=noise_scale, speed=speed,
@@ -43,4 +45,5 @@ class SoVITSVoice:
 
     @torch.no_grad()
     def extract_latent(self, ssl):
+        L.set_half(self.dtype)
         return self.model.extract_latent(ssl.to(self.device))

@@ -371,6 +371,8 @@ class MelStyleEncoder(nn.Module):
                                        style_hidden // style_head, dropout)
         self.fc = LinearNorm(style_hidden, style_vector_dim)
         self._sites = (new_site(), new_site())
+        # set by a caller that pads the time axis beyond the reference's collate length (train/data.py, EVT_PAD_FRAMES): see forward
+        self.mask_beyond_collate = False
 
     def _spectral(self, x):
         """self.spectral with Mish + Dropout as one launch per pair on the GPU (the Sequential keeps the reference's
@@ -390,6 +392,16 @@ class MelStyleEncoder(nn.Module):
         if lens is None:
             lens = x_mask.sum(dim=(1, 2))
         x = self._spectral(x)
+        if self.mask_beyond_collate:
+            # The reference's style encoder is the one consumer that does NOT mask by the lengths before a convolution over
+            # time (modules.py:748-756): `temporal` (two k = 5 convolutions) runs over spectral(zero frames) != 0 behind an
+            # item's end and over the convolution's own zero padding behind the TENSOR's end, which the reference's collate
+            # puts at 2 * (longest // 2 + 1) frames (data_utils.py:189-193).  A batch whose time axis was padded further
+            # (EVT_PAD_FRAMES) must look the same to those convolutions: frames the reference's tensor would not have had
+            # contribute zeros.  Device-side arithmetic on the lengths: no host read, replayable.
+            t_ref = 2 * (torch.div(lens.max(), 2, rounding_mode="floor") + 1)
+            live = (torch.arange(x.size(1), device=x.device) < t_ref).to(x.dtype).view(1, -1, 1)
+            x = x * live
         x = self.temporal(x)
         x = x.masked_fill(pad.unsqueeze(-1), 0)
         x = self.slf_attn(x, lens.to(torch.int32))

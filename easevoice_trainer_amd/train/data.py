@@ -102,8 +102,12 @@ def open_source(kind, train_input_dir, device, synthetic_factory, batch_size=Non
             # replay of the s2 step engage.  Measured (profiles/r04_realdata_pad*.json, 2-10 s clips, B = 16, 240 steps):
             # 0 -> 1060, 8 -> 1370, 16 -> 1633, 32 -> 1512 audio-s/s (eager share 90 % / 22 % / 18 % / 16 %).
             # INVARIANTS this rests on (tests/test_zz_readers_train_gpu.py::test_padded_time_axis_changes_nothing pins them):
-            # (1) no reduction over the time axis without the length mask anywhere in the step -- losses, statistics,
-            # attention keys; (2) the quantiser is frozen (its commitment loss, an unmasked mean over T, is the constant 0:
+            # (1) no reduction or convolution over the time axis sees an unmasked padded frame -- losses, statistics,
+            # attention keys.  ONE consumer of the reference does: the style encoder's temporal convolutions run over
+            # spectral(zero frames) up to the collate's tensor length (modules.py:748-756); the trainer therefore switches
+            # MelStyleEncoder.mask_beyond_collate on when it pads, which makes frames beyond the reference's own tensor
+            # length contribute zeros there (found by that test: without it the waveform moved by more than 1e-3);
+            # (2) the quantiser is frozen (its commitment loss, an unmasked mean over T, is the constant 0:
             # core_vq.py:311-316); (3) the two random draws are per frame, so a seeded run with padding draws different noise
             # for the SAME frames than an unpadded one -- equal in distribution, not bit for bit.
             pad = int(os.environ.get("EVT_PAD_FRAMES", "16")) if str(device).startswith("cuda") else None

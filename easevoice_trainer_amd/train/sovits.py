@@ -112,6 +112,9 @@ class SovitsTrain:
         source = open_source("s2", hps["data"]["exp_dir"], device,
                              lambda n: SyntheticS2Batches(t["batch_size"], 4, n, device, seed=t["seed"], rank=rank, world=world),
                              batch_size=t["batch_size"], cfg=hps["data"], rank=rank, world=world)
+        if int(getattr(source, "pad_frames", 0) or 0) > 0:
+            # the reader pads time axes beyond the reference's collate length: the one consumer that would notice is told
+            eng.net_g.ref_enc.mask_beyond_collate = True
         # resume, else pretrained (sovits.py:327-366)
         try:
             _, _, _, epoch_str = ckpt.load_checkpoint(ckpt.latest_checkpoint_path(t["train_logs_dir"], "D_*.pth"),

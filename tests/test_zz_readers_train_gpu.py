@@ -95,10 +95,13 @@ def test_gpt_train_from_feature_dir(gpu, feature_dir, tmp_path, monkeypatch):
 def test_padded_time_axis_changes_nothing(gpu):
     """The trainer pads a batch's time axes up to a multiple of 16 frames (train/data.py: EVT_PAD_FRAMES, a departure from the
     reference's collate layout that lets repeated shapes replay as HIP graphs).  That is only sound while every consumer masks
-    by the lengths: one fp32 step on a batch of two ragged items, once as collated (T = 100) and once with 12 frames of
-    padding appended to every time axis (ssl, spectrogram, waveform, the injected noise), must give the same losses and the
-    same gradients.  A future unmasked reduction over T -- or an unfrozen quantiser, whose commitment loss is one -- fails
-    here."""
+    by the lengths: one fp32 step on a batch of two ragged items, once as the reference collates it (T = 102 for a longest
+    item of 100 frames) and once with 12 more frames of padding on every time axis (ssl, spectrogram, waveform, the injected
+    noise), must give the same waveform, losses and gradients.  The first version of this test FAILED: the reference's style
+    encoder convolves over unmasked frames up to the tensor's end (modules.py:748-756), so its style vector -- and the
+    waveform, by more than 1e-3 -- depended on the padding; MelStyleEncoder.mask_beyond_collate (set by the trainer whenever
+    its reader pads) restores the reference's view.  A future unmasked reduction over T -- or an unfrozen quantiser, whose
+    commitment loss is one -- fails here."""
     from easevoice_trainer_amd.module.mel_processing import spectrogram_torch
     from easevoice_trainer_amd.train.s2_engine import S2Engine
     from util_fill import fill_module, s2_batch
@@ -115,7 +118,8 @@ def test_padded_time_axis_changes_nothing(gpu):
                 m.p = 0.0
         fill_module(eng.net_g, 1)
         fill_module(eng.net_d, 2)
-        T = 100 + pad
+        eng.net_g.ref_enc.mask_beyond_collate = True     # what the trainer sets when its reader pads (a no-op at pad = 0)
+        T = 102 + pad                                    # 102 = the reference collate's length for a longest item of 100
         wav = torch.zeros(2, 1, T * 640)
         wav[:, :, :100 * 640] = b["wav"]
         wav[1, :, 77 * 640:] = 0.0                       # the reference's collate zero-fills behind an item's end
@@ -136,7 +140,7 @@ def test_padded_time_axis_changes_nothing(gpu):
         del eng
         torch.cuda.empty_cache()
     (l0, g0, d0, y0), (l1, g1, d1, y1) = res
-    # same arithmetic, other tile boundaries (T = 100 vs 112): fp32 summation order differs -- measured 2.4e-5 on the
+    # same arithmetic, other tile boundaries (T = 102 vs 114): fp32 summation order differs -- measured 2.4e-5 on the
     # adversarial loss behind ninety layers, 3.9e-4 on the mel term (a log of a near-silent random-init waveform); a reduction
     # that saw the 12 padded frames of 112 would be off by per cent
     assert float((y0 - y1).abs().max()) <= 1e-3 * float(y0.abs().max())
