@@ -617,3 +617,23 @@ def test_s1_compute_dtype_follows_precision(monkeypatch):
     assert compute_dtype(cfg) == torch.bfloat16
     cfg["train"]["precision"] = "32"
     assert compute_dtype(cfg) == torch.float32
+
+
+def test_reducer_plan_and_description():
+    """GradReducer.plan / describe(ranges): which collective a flat range becomes, per bucket, without any process group"""
+    from easevoice_trainer_amd.dist import GradReducer
+
+    mib = 1 << 18                                     # fp32 elements per MiB
+    r8 = GradReducer(8, bucket_bytes=64 << 20, rsag="auto")
+    assert r8.active and r8.plan(31 * mib) == [(31 << 20, "reduce-scatter + all-gather")]
+    assert r8.plan(4 * mib) == [(4 << 20, "all-reduce")]                       # below rsag_min_bytes
+    assert [k for _b, k in r8.plan(150 * mib)] == ["reduce-scatter + all-gather"] * 3 and sum(b for b, _k in r8.plan(150 * mib)) == 150 << 20
+    r2 = GradReducer(2, rsag="auto")
+    assert r2.plan(100 * mib) == [(64 << 20, "all-reduce"), (36 << 20, "all-reduce")]      # two ranks: one link either way
+    d = r8.describe([("D piece 1/6", 31 * mib), ("G rest", 4 * mib)])
+    assert d.startswith("dp8, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up, all-reduce otherwise, buckets of 64 MiB")
+    assert "D piece 1/6 31.0 MiB = 1 x reduce-scatter + all-gather" in d and "G rest 4.0 MiB = 1 x all-reduce" in d
+    one = GradReducer(1)
+    assert not one.active and GradReducer(1, force=True).active
+    with pytest.raises(ValueError):
+        GradReducer(2, rsag="sometimes")
