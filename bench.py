@@ -86,7 +86,7 @@ def run_s2(args, world, rank, local):
     use_graphs = bool(getattr(args, "graphs", 0))
     if use_graphs:
         # fixed-shape batches: after two eager steps the step is captured once and replayed as HIP graphs (three on one GPU;
-        # eleven smaller ones with the collectives between them when data-parallel)
+        # nine smaller ones with the collectives between them when data-parallel)
         eng.enable_graphs(warmup_steps=2)
     B, T, t_text = args.batch, args.clip_seconds * 50, 60
     wav, ssl, text, lengths, tl = synth_s2_batch(B, T, t_text, dev, 1234 + rank)
@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=1, help="1: replay the s2 step as HIP graphs (default), 0: eager launches")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs (use under rocprofv3)")
     ap.add_argument("--dp-program", type=int, default=0, choices=[0, 1, 2],
-                    help="one GPU only. 1: run the data-parallel (cut, eleven-graph) program without collectives -- the cost of "
+                    help="one GPU only. 1: run the data-parallel (cut, nine-graph) program without collectives -- the cost of "
                          "the decomposition itself next to the default three-phase program; 2: the same with the collectives "
                          "issued on a one-rank RCCL group (side stream, between the graph replays)")
     args = ap.parse_args()

@@ -64,7 +64,7 @@ class S2Engine:
         # data parallelism: gradients are reduced sub-model by sub-model on a side stream while the backward of the next
         # sub-model runs (EVT_DP_OVERLAP=0: the two whole-arena reductions between the phases, nothing overlapped)
         self.overlap = (reducer is not None and reducer.active and os.environ.get("EVT_DP_OVERLAP", "1") != "0")
-        # EVT_DP_CUT=1: the cut program (eleven pieces) on one GPU WITHOUT collectives -- what the decomposition itself costs
+        # EVT_DP_CUT=1: the cut program (nine pieces by default) on one GPU WITHOUT collectives -- what the decomposition itself costs
         # next to the three-phase program (bench.py --dp-program 1)
         self.cut_only = (not self.overlap and os.environ.get("EVT_DP_CUT", "0") == "1")
         # one GPU, EVT_BOOK_PIPE=1: the same cuts, used to run each sub-model's bookkeeping (weight-norm gradient, AdamW,
@@ -248,19 +248,23 @@ class S2Engine:
         if sum(hi - lo for lo, hi in st.d_done) == sum(hi - lo for lo, hi in self._d_rows):
             self.rt_d.finish_grads(done=st.d_done)
 
-    def _phase_b0(self, st):
-        """D optimiser, the generator's losses, and the backward through D and the vocoder (down to the cut)"""
+    def _phase_b0(self, st, finish=True):
+        """D optimiser, the generator's losses, and the backward through D and the vocoder (down to the cut).
+        finish=False: the vocoder's range is not reduced on its own, so its weight-gradient rows are left to the final
+        finish_grads -- finishing them here would make the main stream wait for the side stream's deferred weight-gradient
+        launches, which otherwise run under the flow / encoder backward (that join, not arithmetic, is what a cut costs)"""
         self._phase_b(st, backward=False)
         self.scaler.scale(st.loss_gen + st.loss_fm + st.loss_mel).backward()
         self.rt_d.bank.weight_grads = True
-        st.g_done = [self.rt_g.finish_conv_grads(self._dec_convs)]
+        st.g_done = [self.rt_g.finish_conv_grads(self._dec_convs)] if finish else []
 
-    def _phase_b1(self, st):
+    def _phase_b1(self, st, finish=True):
         """the generator's backward below the vocoder, first part: KL term + the gradient saved at the vocoder's input
         -> flow, posterior encoder (both end at the second cut: their own copy of the style vector, detached prior
         statistics)"""
         self._bwd_b1(st)
-        st.g_done.append(self.rt_g.finish_conv_grads(self._fq_convs))
+        if finish:
+            st.g_done.append(self.rt_g.finish_conv_grads(self._fq_convs))
 
     def _bwd_b1(self, st):
         z_full, z_cut = self.net_g._cut[0]
@@ -344,7 +348,7 @@ class S2Engine:
         if not self.overlap:
             return [("D arena", self.rt_d.arena.grad.numel()), ("G arena", self.rt_g.arena.grad.numel())]
         nd = min(len(self._d_ranges), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
-        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "3"))))
+        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "1"))))
         dtot = sum(hi - lo for lo, hi in self._d_ranges)
         out = [(f"D piece {i + 1}/{nd}", dtot // nd) for i in range(nd)]
         early = []
@@ -375,12 +379,14 @@ class S2Engine:
         prog = [(self._phase_a0, None)]
         order = list(reversed(range(len(self._d_convs))))          # the reference's engine would also end with d0
         # EVT_DP_D_PIECES (1 .. 6, default 6): the six sub-discriminators differentiated -- and reduced -- in that many
-        # groups of neighbours; EVT_DP_G_PIECES (1 .. 3, default 3): vocoder | flow + posterior encoder | rest, 2 = vocoder |
-        # the other two together, 1 = the whole generator backward in one piece.  Every cut is a graph boundary (the side
-        # stream of deferred weight-gradient batches joins there): fewer pieces cost less on the GPU and overlap less of
-        # the exchange (measured on one GPU: profiles/r05_dp_program.txt)
+        # groups of neighbours; EVT_DP_G_PIECES (1 .. 3, default 1): 1 = the whole generator backward in one piece, 2 = vocoder |
+        # the rest, 3 = vocoder | flow + posterior encoder | rest.  Every early piece is a graph boundary at which the main
+        # stream waits for the side stream's deferred weight-gradient launches of that piece (which otherwise run under the
+        # next sub-model's backward).  Measured on one GPU (profiles/r05_dp_program.txt): the six discriminator pieces are
+        # free, an early generator piece costs 0.5-1 ms -- more than the ~0.25-0.5 ms of exchange it would hide on 8 GPUs'
+        # xGMI -- so the discriminators' 187 MB are reduced under their own backward and the generator's 205 MB after its.
         nd = min(len(order), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
-        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "3"))))
+        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "1"))))
         base, extra = divmod(len(order), nd)
         groups, at = [], 0
         for n in range(nd):
@@ -414,14 +420,14 @@ class S2Engine:
             prog.append((self._phase_b2, rest_of([(dlo, dhi), (flo, fhi)]) if dp else None))
         elif ng == 2:
             def b12(st):
-                self._phase_b1(st)
+                self._phase_b1(st, finish=False)
                 self._phase_b2(st)
             prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
             prog.append((b12, rest_of([(dlo, dhi)]) if dp else None))
         else:
             def b012(st):
-                self._phase_b0(st)
-                self._phase_b1(st)
+                self._phase_b0(st, finish=False)
+                self._phase_b1(st, finish=False)
                 self._phase_b2(st)
             prog.append((b012, rest_of([]) if dp else None))
         prog.append((self._phase_c, None))

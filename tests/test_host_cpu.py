@@ -407,9 +407,10 @@ def test_weight_bank_row_ranges_cpu():
 
 
 def test_s2_data_parallel_program_plumbing_cpu():
-    """The data-parallel s2 step's bookkeeping without launching anything (train/s2_engine.py::_program): eleven pieces
-    (D forward, six per-sub-discriminator backward pieces, three generator backward pieces -- through D and the vocoder,
-    flow + posterior encoder, prior + style encoder --, the G optimiser); the
+    """The data-parallel s2 step's bookkeeping without launching anything (train/s2_engine.py::_program): nine pieces by
+    default (D forward, six per-sub-discriminator backward pieces, the generator's backward as ONE piece since round 5 --
+    an early generator piece costs more on the GPU than the exchange it hides --, the G optimiser), eleven with
+    EVT_DP_G_PIECES=3 (through D and the vocoder | flow + posterior encoder | prior + style encoder); the
     sub-discriminators' arena ranges tile the discriminator arena and their weight-gradient row ranges tile the bank's row
     table; the vocoder's range and rows are contiguous, exclude its conditioning layer's parameters and leave two rest
     ranges; the generator is switched to the cut backward.  (The arithmetic of the overlapped step is checked on the GPU:
@@ -425,7 +426,19 @@ def test_s2_data_parallel_program_plumbing_cpu():
     eng = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
     assert eng.overlap and eng.net_g.split_backward
     prog = eng._program()
-    assert len(prog) == 11 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
+    assert len(prog) == 9 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
+    assert [n for n, _ in eng.exchange_ranges()] == [f"D piece {i}/6" for i in range(1, 7)] + ["G rest"]
+    for ng, n in (("3", 11), ("2", 10), ("1", 9)):
+        os.environ["EVT_DP_G_PIECES"] = ng
+        try:
+            assert len(eng._program()) == n
+        finally:
+            del os.environ["EVT_DP_G_PIECES"]
+    os.environ["EVT_DP_D_PIECES"] = "2"
+    try:
+        assert len(eng._program()) == 5
+    finally:
+        del os.environ["EVT_DP_D_PIECES"]
     # discriminator: ranges tile the arena in order, row ranges tile the row table
     d = eng.rt_d.arena
     at = 0

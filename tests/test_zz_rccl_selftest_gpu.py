@@ -1,7 +1,7 @@
 """GPU: the data-parallel paths on a one-rank RCCL communicator (tests/rccl_selftest_worker.py).  The multi-GPU runs are the
 driver's; what a single GPU can establish is that RCCL initialises in this environment, that every collective the reducer
 issues (all-reduce, reduce-scatter into the shard buffer + all-gather, broadcast) runs on the side stream in order with the
-compute stream and with HIP-graph replays, and that the cut (eleven-graph) s2 program and the hook-driven s1 pieces with
+compute stream and with HIP-graph replays, and that the cut (nine-graph) s2 program and the hook-driven s1 pieces with
 REAL collectives between them train exactly like the plain program.  Reference: src/train/sovits.py:219-224,321-322
 (init_process_group("nccl") + DDP), src/train/gpt.py:147-162."""
 import json
@@ -48,7 +48,7 @@ def test_s2_cut_program_with_rccl_collectives_equals_plain(gpu, tmp_path):
     pre = _run(tmp_path, "s2_rccl", 29562)
     _run(tmp_path, "s2_plain", 29563)
     a, b = torch.load(pre + "_s2_rccl.pt"), torch.load(pre + "_s2_plain.pt")
-    assert a["graphs"] == 11 and b["graphs"] == 3
+    assert a["graphs"] == 8 + int(os.environ.get("EVT_DP_G_PIECES", "1")) and b["graphs"] == 3
     assert a["replayed"] >= 2 and b["replayed"] >= 2
     assert a["stats"]["rs_ag"] > 0, a["stats"]           # the reduce-scatter + all-gather path did run on RCCL
     for k in ("g", "d"):
