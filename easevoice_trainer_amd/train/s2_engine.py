@@ -74,8 +74,12 @@ class S2Engine:
         self.pipe = ((reducer is None or not reducer.active) and self.device.type == "cuda" and not self.cut_only
                      and not self.scaler.enabled      # the piped bookkeeping updates a range before the whole arena was checked
                      and os.environ.get("EVT_BOOK_PIPE", "0") == "1")
+        # pieces of the data-parallel program (see _program): six discriminator pieces, the generator's backward as one
+        self.dp_d_pieces = max(1, int(os.environ.get("EVT_DP_D_PIECES", "6")))
+        self.dp_g_pieces = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "1"))))
         if self.overlap or self.pipe or self.cut_only:
-            self.net_g.split_backward = True
+            # the generator's autograd graph is only built with its cuts when a piece of its backward is reduced early
+            self.net_g.split_backward = self.pipe or self.dp_g_pieces > 1
             nd = len(self.net_d.discriminators)
             self._d_ranges = [self.rt_d.arena.range_of_prefix(f"discriminators.{i}.") for i in range(nd)]
             self._d_convs = [[m for m in d.modules() if hasattr(m, "_slot")] for d in self.net_d.discriminators]
@@ -347,8 +351,7 @@ class S2Engine:
         (bench.py prints the collective plan per range through GradReducer.describe)"""
         if not self.overlap:
             return [("D arena", self.rt_d.arena.grad.numel()), ("G arena", self.rt_g.arena.grad.numel())]
-        nd = min(len(self._d_ranges), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
-        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "1"))))
+        nd, ng = min(len(self._d_ranges), self.dp_d_pieces), self.dp_g_pieces
         dtot = sum(hi - lo for lo, hi in self._d_ranges)
         out = [(f"D piece {i + 1}/{nd}", dtot // nd) for i in range(nd)]
         early = []
@@ -385,8 +388,7 @@ class S2Engine:
         # next sub-model's backward).  Measured on one GPU (profiles/r05_dp_program.txt): the six discriminator pieces are
         # free, an early generator piece costs 0.5-1 ms -- more than the ~0.25-0.5 ms of exchange it would hide on 8 GPUs'
         # xGMI -- so the discriminators' 187 MB are reduced under their own backward and the generator's 205 MB after its.
-        nd = min(len(order), max(1, int(os.environ.get("EVT_DP_D_PIECES", "6"))))
-        ng = min(3, max(1, int(os.environ.get("EVT_DP_G_PIECES", "1"))))
+        nd, ng = min(len(order), self.dp_d_pieces), self.dp_g_pieces
         base, extra = divmod(len(order), nd)
         groups, at = [], 0
         for n in range(nd):
@@ -425,11 +427,8 @@ class S2Engine:
             prog.append((self._phase_b0, (lambda: self._reduce_async(gg, dlo, dhi)) if dp else None))
             prog.append((b12, rest_of([(dlo, dhi)]) if dp else None))
         else:
-            def b012(st):
-                self._phase_b0(st, finish=False)
-                self._phase_b1(st, finish=False)
-                self._phase_b2(st)
-            prog.append((b012, rest_of([]) if dp else None))
+            # one piece: the plain generator phase (no cuts in the autograd graph: split_backward is off), whole arena after it
+            prog.append((self._phase_b, rest_of([]) if dp else None))
         prog.append((self._phase_c, None))
         return prog
 

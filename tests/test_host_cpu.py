@@ -424,21 +424,22 @@ def test_s2_data_parallel_program_plumbing_cpu():
 
     hps = json.load(open(os.path.join(ROOT, "configs", "s2.json")))
     eng = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
-    assert eng.overlap and eng.net_g.split_backward
+    assert eng.overlap and not eng.net_g.split_backward          # one generator piece: its autograd graph has no cuts
     prog = eng._program()
     assert len(prog) == 9 and prog[0][1] is None and prog[-1][1] is None and all(a is not None for _, a in prog[1:-1])
     assert [n for n, _ in eng.exchange_ranges()] == [f"D piece {i}/6" for i in range(1, 7)] + ["G rest"]
-    for ng, n in (("3", 11), ("2", 10), ("1", 9)):
-        os.environ["EVT_DP_G_PIECES"] = ng
-        try:
-            assert len(eng._program()) == n
-        finally:
-            del os.environ["EVT_DP_G_PIECES"]
-    os.environ["EVT_DP_D_PIECES"] = "2"
+    for ng, n in ((3, 11), (2, 10), (1, 9)):
+        eng.dp_g_pieces = ng
+        assert len(eng._program()) == n
+    eng.dp_d_pieces = 2
+    assert len(eng._program()) == 5
+    eng.dp_d_pieces = 6
+    os.environ["EVT_DP_G_PIECES"] = "3"
     try:
-        assert len(eng._program()) == 5
+        e3 = S2Engine(hps, "cpu", torch.float32, reducer=FakeReducer())
     finally:
-        del os.environ["EVT_DP_D_PIECES"]
+        del os.environ["EVT_DP_G_PIECES"]
+    assert e3.net_g.split_backward and len(e3._program()) == 11
     # discriminator: ranges tile the arena in order, row ranges tile the row table
     d = eng.rt_d.arena
     at = 0
