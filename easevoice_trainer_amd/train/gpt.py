@@ -122,6 +122,9 @@ class GPTTrain:
                 eng.optimizer.load_state_dict({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in opt_sd.items()})
             if ck.get("lr_schedulers"):
                 eng.scheduler.load_state_dict(ck["lr_schedulers"][0])
+            amp = ck.get("MixedPrecisionPlugin") or ck.get("MixedPrecision")       # Lightning 2.0 / later 2.x key
+            if amp and eng.scaler.enabled:
+                eng.scaler.load_state_dict(amp)
             start_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
         if reducer is not None:
             reducer.broadcast_params(eng.arena.param)
@@ -162,10 +165,13 @@ class GPTTrain:
                 opt_sd = eng.optimizer.reference_state_dict(order)
                 sch_sd = eng.scheduler.state_dict()
                 new_name = f"epoch={epoch}-step={self.global_step}.ckpt"
-                ckpt.save_with_torch({"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
-                                      "optimizer_states": [opt_sd], "lr_schedulers": [sch_sd],
-                                      "hyper_parameters": {"config": cfg}},
-                                     os.path.join(self.train_ckpts_output, new_name))
+                blob = {"epoch": epoch, "global_step": self.global_step, "state_dict": sd,
+                        "optimizer_states": [opt_sd], "lr_schedulers": [sch_sd], "hyper_parameters": {"config": cfg}}
+                if eng.scaler.enabled:
+                    # precision 16-mixed: Lightning 2.0 stores its AMP plugin's state -- the GradScaler's state_dict --
+                    # under the plugin's class name (trainer/connectors/checkpoint_connector.py: dump_checkpoint)
+                    blob["MixedPrecisionPlugin"] = eng.scaler.state_dict()
+                ckpt.save_with_torch(blob, os.path.join(self.train_ckpts_output, new_name))
                 for name in before:
                     if name != new_name:
                         try:

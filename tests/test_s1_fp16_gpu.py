@@ -87,3 +87,19 @@ def test_s1_fp16_overflow_skips_the_step(gpu):
     assert st and eng.skipped_steps == 1 and eng.optimizer.step_count == 1
     assert not torch.equal(eng.arena.param, p0) and torch.isfinite(eng.arena.param).all()
     assert eng.scaler.get_scale() == 2.0 ** 13
+
+
+def test_scaler_state_dict_is_torchs(gpu):
+    """DeviceGradScaler.state_dict() has torch.amp.GradScaler's layout (what Lightning stores under its AMP plugin's name in
+    an s1 resume file, what a caller of the s2 engine can hand to torch's scaler), and round-trips"""
+    from easevoice_trainer_amd.runtime import DeviceGradScaler
+
+    ref = torch.amp.GradScaler("cpu", init_scale=512.0, growth_interval=7)
+    ref.scale(torch.zeros(1))
+    sc = DeviceGradScaler(gpu, init_scale=512.0, growth_interval=7)
+    assert sc.state_dict() == ref.state_dict()
+    sc.load_state_dict(dict(ref.state_dict(), scale=2048.0, _growth_tracker=3))
+    assert sc.get_scale() == 2048.0 and int(sc._tracker.item()) == 3
+    ref.load_state_dict(sc.state_dict())
+    assert ref.get_scale() == 2048.0
+    assert DeviceGradScaler(gpu, enabled=False).state_dict() == {}
