@@ -247,6 +247,8 @@ class WeightBank:
                 s.db_part = self.db_part_arena[do: do + s.parts * s.layout.d0]
         self._items = self._rows = None
         self._nrows = 0
+        # images that also exist in MFMA fragment order (frag()): re-made behind every fold by one launch
+        self._frags, self._frag_items, self._frag_rows, self._frag_tables = {}, [], [], {}
 
     def build_tables(self):
         """(Re)build the device descriptor tables.  Must be called after parameters (and their .grad
@@ -311,6 +313,49 @@ class WeightBank:
             return
         rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
         L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_fold_multi")
+        self._repack_frags(lo, hi)
+
+    def frag(self, slot, which):
+        """`slot`'s REG (which = "reg") or ALT ("alt") image in MFMA FRAGMENT ORDER (evt_frag_pack: [16-row tile][K step of
+        32][64 lanes][8], lane (n, g) = row 16 tile + n, K elements 32 ks + 8 g ..): what the kernels that stream a weight
+        image straight from global memory into MFMA operands with ONE MFMA per fragment read (csrc/wn_layer.hip) -- a
+        wave's fragment load is then 1 KiB contiguous instead of 16 rows x 64 bytes, which the vector memory path serves at
+        ~12 B/clk per CU (34 -> 20 us per WN layer).  Tried for csrc/resunit_wide.hip too (9-14 MFMAs per fragment): no change
+        (23.06-23.20 against 22.96-22.98 ms per step), its loads are not what it waits for -- it reads REG / ALT directly.  A copy owned by the bank: made on first request, re-made behind every fold of the slot's rows (ONE launch for
+        all registered images, captured with the fold when the step is a HIP graph)."""
+        key = (id(slot), which)
+        f = self._frags.get(key)
+        if f is None:
+            lay = slot.layout
+            if which == "reg":
+                rows, ktot, src, elems = lay.d0, lay.reg_nchunk * lay.reg_kp * lay.reg_ck, slot.reg, lay.reg_elems
+            else:
+                rows, ktot, src, elems = lay.d1, lay.alt_nchunk * lay.alt_kp * lay.alt_ck, slot.alt, lay.alt_elems
+            if elems != rows * ktot or rows % 16 or ktot % 32 or not L.is_half(self.dtype):
+                raise L.EvtError(f"no fragment-order form for this image ({which}, {rows} x {ktot}, {self.dtype})")
+            if self._items is None:
+                self.build_tables()
+            f = torch.empty(elems, dtype=self.dtype, device=self.device)
+            it = L.FragItem()
+            it.src, it.dst, it.rows, it.ktot = src.data_ptr(), f.data_ptr(), rows, ktot
+            self._frags[key] = f
+            self._frag_items.append(it)
+            self._frag_rows.append(self._slot_rows[self.slots.index(slot)])
+            self._frag_tables.clear()
+            one = L.struct_to_device([it], self.device)
+            self._frag_tables[("one", len(self._frag_items))] = (one, 1)      # kept alive
+            L.check(L.lib().evt_frag_pack(L.ptr(one), 1, L.stream_ptr()), "evt_frag_pack")
+        return f
+
+    def _repack_frags(self, lo, hi):
+        if not self._frag_items:
+            return
+        tab = self._frag_tables.get((lo, hi))
+        if tab is None:
+            items = [it for it, (r0, r1) in zip(self._frag_items, self._frag_rows) if r0 < hi and r1 > lo]
+            tab = self._frag_tables[(lo, hi)] = (L.struct_to_device(items, self.device) if items else None, len(items))
+        if tab[1]:
+            L.check(L.lib().evt_frag_pack(L.ptr(tab[0]), tab[1], L.stream_ptr()), "evt_frag_pack")
 
     def zero_dw(self):
         if self._deferred or self._held:

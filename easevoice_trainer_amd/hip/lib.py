@@ -67,6 +67,11 @@ class WPrepItem(C.Structure):
     ]
 
 
+class FragItem(C.Structure):
+    """evt_frag_item (include/evt.h): one REG image -> fragment order copy of evt_frag_pack"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("ktot", C.c_int32)]
+
+
 class WgradParts(C.Structure):
     _fields_ = [("dw_extra", C.c_void_p), ("part_stride", C.c_int64), ("db_part", C.c_void_p), ("used_dev", C.c_void_p),
                 ("parts", C.c_int32), ("prev_used", C.c_int32), ("used", C.c_int32), ("dirty0", C.c_int32),

@@ -3,7 +3,9 @@ autograd node per stack.
 
 Per layer the arithmetic is the reference's: in_layer conv (k = 5) -> tanh * sigmoid gate with the conditioning slice ->
 res_skip conv (1x1) -> x <- (x + rs[:H]) * mask, out <- out + rs[H:] (last layer: out <- (out + rs) * mask).  The launches
-are the library's (evt_conv1d_*, evt_gated_act_*, evt_wn_residual_*), five forward and eight backward per layer; what the
+are the library's: forward ONE per layer in the 16-bit types at the model's shape (evt_wn_layer_fwd, csrc/wn_layer.hip: H =
+192, k = 5; the gate output stays in LDS between the two convolutions), otherwise four (evt_conv1d_fwd, evt_gated_act_fwd,
+evt_conv1d_fwd, evt_wn_residual_fwd: fp32, other shapes, EVT_NO_WN_LAYER=1); backward eight per layer; what the
 single node removes is everything between them that torch issued: the element-wise sum of the two gradient branches of
 every layer input (now the add-epilogue of the in_layer backward-data launch), a zero fill and a cast per layer for the
 conditioning gradient (one fp32 buffer and one cast per stack), the unbind / stack bookkeeping, and ~80 autograd nodes.
@@ -28,8 +30,28 @@ class WNStackFn(torch.autograd.Function):
         rows = B * T
         saved = []
         out = None
+        fused = _layer_fused(dt, H, in_slots, rs_slots)
+        frag_in, frag_rs = _frag_images(in_slots, rs_slots) if fused else (None, None)
         for i in range(n_layers):
             last = i == n_layers - 1
+            if fused:
+                mi, mr = in_slots[i].module, rs_slots[i].module
+                x_in = torch.empty((B, T, 2 * H), dtype=x.dtype, device=x.device)
+                acts = torch.empty((B, T, H), dtype=x.dtype, device=x.device)
+                acc_out = torch.empty((B, T, H), dtype=x.dtype, device=x.device)
+                x_out = None if last else torch.empty_like(acc_out)
+                e0 = HC._t0()
+                L.check(L.lib().evt_wn_layer_fwd(dt, L.ptr(x), L.ptr(frag_in[i]),
+                                                 L.ptr(mi.bias.data if mi.bias is not None else None), L.ptr(frag_rs[i]),
+                                                 L.ptr(mr.bias.data if mr.bias is not None else None),
+                                                 L.ptr(g_lbh[i] if g_lbh is not None else None), L.ptr(out), L.ptr(lens),
+                                                 L.ptr(x_in), L.ptr(acts), L.ptr(x_out), L.ptr(acc_out), B, T, H, mi.k,
+                                                 int(last), L.stream_ptr()), "evt_wn_layer_fwd")
+                if e0 is not None:
+                    _t1_layer(e0, mi, mr, x)
+                saved += [x, x_in, acts]
+                x, out = x_out, acc_out
+                continue
             x_in = HC._fwd(in_slots[i], x, None, 1.0, L.ACT_NONE, 1.0)
             acts = torch.empty((B, T, H), dtype=x.dtype, device=x.device)
             L.check(L.lib().evt_gated_act_fwd(dt, L.ptr(x_in), L.ptr(g_lbh[i] if g_lbh is not None else None), L.ptr(acts),
@@ -82,6 +104,48 @@ class WNStackFn(torch.autograd.Function):
             dx_next = HC._bwd_data(s, dx_in, None, x, dx_res, B, T, 1.0, L.ACT_NONE, 1.0) if need_dx else None
         dg = dg32.to(g_lbh.dtype) if (dg32 is not None and ctx.needs_input_grad[1]) else None
         return dx_next, dg, None, None, None, None, None
+
+
+FUSED_FORWARD = True     # tests / measurements: False = the four-launch layer forward at every shape
+
+
+def _layer_fused(dt, H, in_slots, rs_slots):
+    """the one-launch layer forward serves this stack: 16-bit type, every in_layer [H -> 2H, k = 5, dilation 1, 'same' padding],
+    every res_skip 1 x 1 [H -> 2H, last H -> H] -- the two WN stacks of the model (posterior encoder, flow)"""
+    if not FUSED_FORWARD:
+        return False
+    n = len(in_slots)
+    for i, (si, sr) in enumerate(zip(in_slots, rs_slots)):
+        mi, mr = si.module, sr.module
+        if not L.lib().evt_wn_layer_supported(dt, H, mi.k, mi.dil):
+            return False
+        if (mi.cin, mi.cout, mi.stride, mi.groups, mi.pad, mi.transposed) != (H, 2 * H, 1, 1, (mi.k - 1) // 2, False):
+            return False
+        if (mr.cin, mr.cout, mr.k, mr.stride, mr.groups, mr.pad, mr.transposed) != (H, H if i == n - 1 else 2 * H, 1, 1, 1, 0,
+                                                                                    False):
+            return False
+    return True
+
+
+def _frag_images(in_slots, rs_slots):
+    """the stack's REG images in MFMA fragment order (WeightBank.frag: copies the bank re-makes behind every fold)"""
+    bank = in_slots[0].bank
+    return [bank.frag(s, "reg") for s in in_slots], [bank.frag(s, "reg") for s in rs_slots]
+
+
+def _t1_layer(e0, mi, mr, x):
+    """trace record of one fused layer forward (bench.py's per-launch table): flops of both convolutions; bytes = x and the
+    skip sum in, x_in / acts / x / skip sum out, both weight images"""
+    e0, rf = e0
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    if rf is not None:
+        rf.__exit__(None, None, None)
+    n, ln, h = x.shape
+    macs = n * ln * (mi.cin * mi.cout * mi.k + mr.cin * mr.cout)
+    HC.TRACE.append((L.lib().evt_last_kernel_tag().decode(), "fwd", 2 * macs,
+                     (7 * x.numel() + mi.v.numel() + mr.v.numel()) * 2, e0, e1,
+                     f"WN layer {h}>{mi.cout}>{mr.cout} k{mi.k} n{n} L{ln}", mi))
 
 
 def wn_stack(x, g_lbh, lens, in_layers, rs_layers, hidden):

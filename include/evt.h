@@ -258,6 +258,31 @@ int evt_resunit_wide_fwd(const evt_resunit_params* p, const void* x, const void*
 int evt_resunit_wide_bwd_data(const evt_resunit_params* p, const void* dy, float dy_scale, const void* xa, const void* mid_a,
                               const void* w1_alt, const void* w2_alt, void* dmid, void* dx, void* stream);
 
+/* One layer of the WN stack of the posterior encoder / the flow (modules.py:187-211 of the reference) FORWARD in one launch
+ * (16-bit type, H = 192, k = 5, dilation 1): x_in = in_layer(x) [nseq][L][2H], acts = tanh(x_in[:H] + g[:H]) *
+ * sigmoid(x_in[H:] + g[H:]) [nseq][L][H], rs = res_skip(acts); x_out = (x + rs[:H]) * mask, acc_out = acc_in + rs[H:]
+ * (last != 0: res_skip has H outputs, acc_out = (acc_in + rs) * mask, x_out unused).  Replaces evt_conv1d_fwd +
+ * evt_gated_act_fwd + evt_conv1d_fwd + evt_wn_residual_fwd with the same rounding points (x_in, acts, rs rounded to the
+ * 16-bit type); the gate output stays in LDS between the two convolutions.  w_in_frag / w_rs_frag: the two convolutions'
+ * REG images (evt_conv1d_layout) re-ordered by evt_frag_pack, b_in [2H] / b_rs [2H or H] fp32 or NULL, g [nseq][2H] or
+ * NULL, acc_in NULL for the first layer, lens [nseq] or NULL (mask = position < lens[sequence]).  x_in and acts are outputs
+ * the backward launches (evt_gated_act_bwd, the weight gradients) read, as before.  EVT_ENOTSUP outside that shape family.
+ *
+ * evt_frag_pack: items is a DEVICE table; each item copies a REG or ALT image of `rows` (multiple of 16) rows x `ktot`
+ * (multiple of 32) elements of the 16-bit type into FRAGMENT ORDER [rows / 16][ktot / 32][64][8] -- lane (n, g) of (tile, K step)
+ * holds row 16 tile + n, elements 32 ks + 8 g .. + 7, i.e. every MFMA A operand is one contiguous 1 KiB load of a wave.
+ * One launch per weight fold for all such images of a model (they change when the weights do).  Reader: evt_wn_layer_fwd. */
+typedef struct evt_frag_item {
+  const void* src;   /* REG or ALT image, [rows][ktot] */
+  void* dst;         /* rows * ktot elements */
+  int32_t rows, ktot;
+} evt_frag_item;
+int evt_frag_pack(const evt_frag_item* items, int32_t nitems, void* stream);
+int32_t evt_wn_layer_supported(int32_t dtype, int32_t H, int32_t k, int32_t dil);
+int evt_wn_layer_fwd(int32_t dtype, const void* x, const void* w_in_frag, const float* b_in, const void* w_rs_frag,
+                     const float* b_rs, const void* g, const void* acc_in, const int32_t* lens, void* x_in, void* acts,
+                     void* x_out, void* acc_out, int32_t nseq, int32_t L, int32_t H, int32_t k, int32_t last, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Element-wise / reduction helpers of the s2 path.
  * ------------------------------------------------------------------------------------- */
