@@ -20,7 +20,8 @@
 // convolution) or the residual and the skip term (second) of the same (channel, position): both epilogues are lane-local.
 // With 4 waves x NT MFMAs per 1 KiB fragment the block is bound by its weight stream (884 KB per block and layer), which is
 // why the ring is deeper than resunit_wide's and the grid (208 blocks of 16 positions) does not need to fill the chip.
-// Measured (profiles/r05_wn_layer.txt): 18.0 us per layer against 25.5 us for the four launches, s2 step -0.34 ms.
+// Measured (profiles/r05_wn_layer.txt): 18.0 us per layer against 25.5 us for the four launches, s2 step -0.34 ms; with the
+// data half of the backward fused the same way (wn_layer_bwd below) 22.38-22.44 against 23.50-23.69 ms per step.
 //
 // Rounding points are those of the unfused launches (x_in, acts, rs are rounded to the 16-bit type where the separate
 // kernels stored them), so the two paths differ only by the order of the fp32 sums inside a convolution.
@@ -275,6 +276,248 @@ __global__ __launch_bounds__(256, 1) void wn_layer_fwd(WNP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The DATA half of the layer's backward in one launch (instead of evt_wn_residual_bwd, the 1 x 1 backward-data launch,
+// evt_gated_act_bwd and the k = 5 backward-data launch with its add epilogue):
+//
+//     drs    = [dx_next * mask | dacc]                     (last layer: drs = dacc * mask, H channels)
+//     dacts  = res_skip^T drs                              (1 x 1: H rows x 2H, ALT image)
+//     dx_in  = gate'(x_in + g) dacts                       (tanh / sigmoid derivatives; dg[seq] += sum over positions)
+//     dx     = in_layer^T dx_in + dx_next * mask           (k = 5, ALT image = flipped taps: a plain correlation)
+//
+// Same structure as the forward: "first convolution on tile + halo into LDS, second convolution on the tile"; the rows are
+// 2H wide here (768 bytes: slot ^ (row & 15) is conflict-free for 16 consecutive rows).  A wave owns M-tiles {3 wm ..
+// 3 wm + 2} of the H output rows of both convolutions: the lane that holds dacts of (channel h, position) writes both gate
+// gradients, channels h and H + h of dx_in.  drs and dx_in are also written to global memory: the two weight-gradient
+// launches (side stream) read them, as before.
+struct WNB {
+  const h16_t* dx_next;  // [nseq][L][H] gradient of the layer's x output; null: none (last layer)
+  const h16_t* dacc;     // [nseq][L][H] gradient of the skip sum
+  const h16_t* x_in;     // [nseq][L][2H] saved by the forward
+  const h16_t* g;        // [nseq][2H] or null
+  const h16_t* w_rs;     // ALT image of res_skip, fragment order: H / 16 tiles x (2H or H) / 32 K steps
+  const h16_t* w_in;     // ALT image of in_layer, fragment order: H / 16 tiles x (2H / 32 chunks x K taps)
+  const int* lens;
+  h16_t* drs;            // out [nseq][L][2H] (last: [nseq][L][H])
+  h16_t* dx_in;          // out [nseq][L][2H]
+  h16_t* dx;             // out [nseq][L][H]
+  float* dg;             // [nseq][2H] fp32, += (atomics), or null
+  int nseq, L, tps;
+};
+
+__device__ __forceinline__ int wslot2(int row, int slot) { return slot ^ (row & 15); }
+
+// sum over the 16 lanes that share g (the positions n of one tile): xor-butterfly inside a row of 16 lanes
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 8, 16);
+  return v;
+}
+
+template <int H, int K, int NT, int R, bool LAST>
+__global__ __launch_bounds__(256, 1) void wn_layer_bwd(WNB p) {
+  constexpr int PB = H * 4;                  // row pitch: 2H channels
+  constexpr int SPRB = H / 4;                // 16-byte slots per row
+  constexpr int MT = H / 16 / 4;             // M-tiles per wave
+  constexpr int P = 16 * NT;                 // own positions per block
+  constexpr int HALO = (K - 1) / 2;
+  constexpr int NT1 = NT + 1;                // position tiles of the first convolution: P + 2 HALO <= 16 NT1 rows
+  constexpr int ROWS = P + 2 * HALO;         // rows that matter in both LDS regions
+  constexpr int CIN1 = LAST ? H : 2 * H;     // channels of drs
+  constexpr int NK1 = CIN1 / 32, NK2 = (2 * H / 32) * K;
+  static_assert(2 * HALO <= 16, "one extra position tile covers the halo");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* ds = smem;                          // 16 NT1 rows: drs at positions q0 - HALO ..
+  unsigned char* es = smem + 16 * NT1 * PB;          // 16 NT1 rows: dx_in at positions q0 - HALO ..
+  const int tid = threadIdx.x, lane = tid & 63, wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int seq = blockIdx.x / p.tps;
+  const int q0 = (blockIdx.x - seq * p.tps) * P;
+  const long sbase = (long)seq * p.L;
+  const int len = p.lens ? p.lens[seq] : p.L;
+
+  u32x4 fa[R][MT];
+  auto issue_a = [&](const h16_t* w, const int nk, const int ks, const int s) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      fa[s][i] = *reinterpret_cast<const u32x4*>(w + ((long)((wm * MT + i) * nk + ks) * 64 + lane) * 8);
+  };
+
+  // ---- every non-weight global read up front (oldest first): the drs rows, then what the gate epilogue reads ----
+  constexpr int SPR1 = CIN1 / 8;             // 16-byte pieces per staged row
+  constexpr int NP = ROWS * SPR1;
+  constexpr int PER = (NP + 255) / 256;
+  uint4 dv[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = u * 256 + tid;
+    const int r = idx / SPR1, sl = idx - r * SPR1;
+    const int pos = q0 - HALO + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (idx < NP && pos >= 0 && pos < p.L) {
+      if (LAST) {
+        if (pos < len) v = *reinterpret_cast<const uint4*>(p.dacc + (sbase + pos) * H + sl * 8);
+      } else if (sl < H / 8) {
+        if (p.dx_next && pos < len) v = *reinterpret_cast<const uint4*>(p.dx_next + (sbase + pos) * H + sl * 8);
+      } else {
+        v = *reinterpret_cast<const uint4*>(p.dacc + (sbase + pos) * H + (sl - H / 8) * 8);
+      }
+    }
+    dv[u] = v;
+  }
+#pragma unroll
+  for (int s = 0; s < R - 1 && s < NK1; ++s) issue_a(p.w_rs, NK1, s, s);
+  u32x2 xa[MT][NT1], xb[MT][NT1], ga[MT], gb[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int h = (wm * MT + i) * 16 + g * 4;
+    ga[i] = gb[i] = u32x2{0u, 0u};
+    if (p.g) {
+      ga[i] = *reinterpret_cast<const u32x2*>(p.g + (long)seq * 2 * H + h);
+      gb[i] = *reinterpret_cast<const u32x2*>(p.g + (long)seq * 2 * H + H + h);
+    }
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+      const int m = j * 16 + n;
+      const int pos = q0 - HALO + m;
+      const bool in = m < ROWS && pos >= 0 && pos < p.L;
+      xa[i][j] = in ? *reinterpret_cast<const u32x2*>(p.x_in + (sbase + pos) * 2 * H + h) : u32x2{0u, 0u};
+      xb[i][j] = in ? *reinterpret_cast<const u32x2*>(p.x_in + (sbase + pos) * 2 * H + H + h) : u32x2{0u, 0u};
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = u * 256 + tid;
+    if (idx >= NP) continue;
+    const int r = idx / SPR1, sl = idx - r * SPR1;
+    *reinterpret_cast<uint4*>(ds + r * PB + wslot2(r, sl) * 16) = dv[u];
+    const int pos = q0 - HALO + r;
+    if (r >= HALO && r < HALO + P && pos < p.L)            // own rows: drs for the res_skip weight gradient
+      *reinterpret_cast<uint4*>(p.drs + (sbase + pos) * CIN1 + sl * 8) = dv[u];
+  }
+  __syncthreads();
+
+  auto conv = [&](auto& acc, const h16_t* w, auto nk_c, auto taps_c, auto nt_c, const unsigned char* rows) {
+    constexpr int NK = decltype(nk_c)::value, TAPS = decltype(taps_c)::value, NTC = decltype(nt_c)::value;
+    u32x4 fb[NTC];
+    auto b_addr = [&](const int ks) {
+      const int ch = ks / TAPS, tap = ks - ch * TAPS;
+      const int row = n + tap;
+      return rows + row * PB + wslot2(row, ch * 4 + g) * 16;
+    };
+    {
+      const unsigned char* b0 = b_addr(0);
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) fb[j] = *reinterpret_cast<const u32x4*>(b0 + j * 16 * PB);   // (row + 16) & 15 == row & 15
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int s = ks % R;
+      if (ks + R - 1 < NK) issue_a(w, NK, ks + R - 1, (ks + R - 1) % R);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) tie(fa[s][i]);
+      const unsigned char* nb = b_addr(ks + 1 < NK ? ks + 1 : ks);
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        tie(fb[j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[i][j] = EVT_MFMA_16x16x32(as_h8(fa[s][i]), as_h8(fb[j]), acc[i][j], 0, 0, 0);
+        fb[j] = *reinterpret_cast<const u32x4*>(nb + j * 16 * PB);
+      }
+    }
+  };
+
+  // ---- first convolution (1 x 1 transposed) on tile + halo, gate derivative ----
+  {
+    f32x4 acc[MT][NT1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT1; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv(acc, p.w_rs, std::integral_constant<int, NK1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, NT1>{}, ds);
+#pragma unroll
+    for (int s = 0; s < R - 1 && s < NK2; ++s) issue_a(p.w_in, NK2, s, s);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int h = (wm * MT + i) * 16 + g * 4;
+      float gaf[4], gbf[4], sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+      unpack4(ga[i], gaf);
+      unpack4(gb[i], gbf);
+#pragma unroll
+      for (int j = 0; j < NT1; ++j) {
+        const int m = j * 16 + n;
+        const int pos = q0 - HALO + m;
+        const bool in = m < ROWS && pos >= 0 && pos < p.L;
+        const bool own = in && m >= HALO && m < HALO + P;
+        float xaf[4], xbf[4];
+        unpack4(xa[i][j], xaf);
+        unpack4(xb[i][j], xbf);
+        h16_t oa[4], ob[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = h2f(f2h(acc[i][j][r]));            // dacts as the 1 x 1 launch stored it
+          const float t = tanh_f(xaf[r] + gaf[r]), sg = sigmoid_f(xbf[r] + gbf[r]);
+          const float da = in ? d * sg * (1.f - t * t) : 0.f, db = in ? d * t * sg * (1.f - sg) : 0.f;
+          oa[r] = f2h(da);
+          ob[r] = f2h(db);
+          if (own) { sa[r] += da; sb[r] += db; }
+        }
+        unsigned char* ep = es + m * PB;
+        *reinterpret_cast<uint2*>(ep + wslot2(m, h >> 3) * 16 + (h & 7) * 2) = *reinterpret_cast<uint2*>(oa);
+        *reinterpret_cast<uint2*>(ep + wslot2(m, (H + h) >> 3) * 16 + (h & 7) * 2) = *reinterpret_cast<uint2*>(ob);
+        if (own) {
+          h16_t* o = p.dx_in + (sbase + pos) * 2 * H + h;
+          *reinterpret_cast<uint2*>(o) = *reinterpret_cast<uint2*>(oa);
+          *reinterpret_cast<uint2*>(o + H) = *reinterpret_cast<uint2*>(ob);
+        }
+      }
+      if (p.dg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ta = sum16(sa[r]), tb = sum16(sb[r]);
+          if (n == 0) {
+            atomicAdd(p.dg + (long)seq * 2 * H + h + r, ta);
+            atomicAdd(p.dg + (long)seq * 2 * H + H + h + r, tb);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- second convolution (k = K transposed: the ALT image holds the flipped taps) + the residual branch's gradient ----
+  {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv(acc, p.w_in, std::integral_constant<int, NK2>{}, std::integral_constant<int, K>{}, std::integral_constant<int, NT>{}, es);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int h = (wm * MT + i) * 16 + g * 4;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int m = j * 16 + n;
+        const int pos = q0 + m;
+        if (pos >= p.L) continue;
+        float dr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!LAST) {
+          const int r0 = HALO + m;                             // drs[:H] of this position = dx_next * mask
+          unpack4(*reinterpret_cast<const u32x2*>(ds + r0 * PB + wslot2(r0, h >> 3) * 16 + (h & 7) * 2), dr);
+        }
+        h16_t o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = f2h(acc[i][j][r] + dr[r]);
+        *reinterpret_cast<uint2*>(p.dx + (sbase + pos) * H + h) = *reinterpret_cast<uint2*>(o4);
+      }
+    }
+  }
+}
+
 // REG image [rows][ktot] -> fragment order [rows / 16][ktot / 32][64 lanes][8]: lane (n = lane & 15, g = lane >> 4) of
 // (tile, K step) holds row 16 tile + n, K elements 32 ks + 8 g .. + 7 -- the MFMA A operand of that step as one 16-byte load
 __global__ __launch_bounds__(256) void frag_pack_kernel(const evt_frag_item* items) {
@@ -321,6 +564,31 @@ int launch_nt(WNP p, hipStream_t st) {
   return launch<2, 8, LAST>(p, st);
 }
 
+template <int NT, int R, bool LAST>
+int launch_b(WNB p, hipStream_t st) {
+  constexpr int H = 192, K = 5, P = 16 * NT;
+  p.tps = (p.L + P - 1) / P;
+  const size_t lds = (size_t)2 * 16 * (NT + 1) * H * 4;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_layer_bwd<H, K, NT, R, LAST>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return EVT_ELAUNCH;
+    attr = true;
+  }
+  evt_set_last_tag("wn_layer_bwd<%s, %d, k%d, nt %d, ring %d%s>", EVT_HALF_NAME, H, K, NT, R, LAST ? ", last" : "");
+  hipLaunchKernelGGL((wn_layer_bwd<H, K, NT, R, LAST>), dim3(p.nseq * p.tps), dim3(256), lds, st, p);
+  return evt_check_launch();
+}
+
+template <bool LAST>
+int launch_b_nt(WNB p, hipStream_t st) {
+  // 16 or 32 own positions per block: 22.38 / 22.44 vs 22.44 / 22.37 ms per s2 step -- alike; 16 keeps the LDS under 64 KB
+  static const int nt = getenv("EVT_WN_BWD_NT") ? atoi(getenv("EVT_WN_BWD_NT")) : 1;
+  if (nt == 2) return launch_b<2, 8, LAST>(p, st);
+  return launch_b<1, 8, LAST>(p, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -349,6 +617,21 @@ int evt_wn_layer_fwd(int32_t dtype, const void* x, const void* w_in_frag, const 
   p.nseq = nseq; p.L = L;
   hipStream_t st = (hipStream_t)stream;
   return last ? launch_nt<true>(p, st) : launch_nt<false>(p, st);
+}
+
+int evt_wn_layer_bwd_data(int32_t dtype, const void* dx_next, const void* dacc, const void* x_in, const void* g,
+                          const void* w_rs_alt_frag, const void* w_in_alt_frag, const int32_t* lens, void* drs, void* dx_in,
+                          void* dx, float* dg, int32_t nseq, int32_t L, int32_t H, int32_t k, int32_t last, void* stream) {
+  if (!evt_wn_layer_supported(dtype, H, k, 1)) return EVT_ENOTSUP;
+  if (!dacc || !x_in || !w_rs_alt_frag || !w_in_alt_frag || !drs || !dx_in || !dx || nseq <= 0 || L <= 0) return EVT_EINVAL;
+  if (last && dx_next) return EVT_EINVAL;          // the last layer has no x output
+  WNB p{};
+  p.dx_next = (const h16_t*)dx_next; p.dacc = (const h16_t*)dacc; p.x_in = (const h16_t*)x_in; p.g = (const h16_t*)g;
+  p.w_rs = (const h16_t*)w_rs_alt_frag; p.w_in = (const h16_t*)w_in_alt_frag; p.lens = lens;
+  p.drs = (h16_t*)drs; p.dx_in = (h16_t*)dx_in; p.dx = (h16_t*)dx; p.dg = dg;
+  p.nseq = nseq; p.L = L;
+  hipStream_t st = (hipStream_t)stream;
+  return last ? launch_b_nt<true>(p, st) : launch_b_nt<false>(p, st);
 }
 
 }  // extern "C"

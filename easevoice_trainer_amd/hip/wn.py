@@ -5,7 +5,8 @@ Per layer the arithmetic is the reference's: in_layer conv (k = 5) -> tanh * sig
 res_skip conv (1x1) -> x <- (x + rs[:H]) * mask, out <- out + rs[H:] (last layer: out <- (out + rs) * mask).  The launches
 are the library's: forward ONE per layer in the 16-bit types at the model's shape (evt_wn_layer_fwd, csrc/wn_layer.hip: H =
 192, k = 5; the gate output stays in LDS between the two convolutions), otherwise four (evt_conv1d_fwd, evt_gated_act_fwd,
-evt_conv1d_fwd, evt_wn_residual_fwd: fp32, other shapes, EVT_NO_WN_LAYER=1); backward eight per layer; what the
+evt_conv1d_fwd, evt_wn_residual_fwd: fp32, other shapes, EVT_NO_WN_LAYER=1); backward likewise ONE launch for the data half
+(evt_wn_layer_bwd_data) plus the two weight gradients, otherwise four + two; what the
 single node removes is everything between them that torch issued: the element-wise sum of the two gradient branches of
 every layer input (now the add-epilogue of the in_layer backward-data launch), a zero fill and a cast per layer for the
 conditioning gradient (one fp32 buffer and one cast per stack), the unbind / stack bookkeeping, and ~80 autograd nodes.
@@ -30,7 +31,7 @@ class WNStackFn(torch.autograd.Function):
         rows = B * T
         saved = []
         out = None
-        fused = _layer_fused(dt, H, in_slots, rs_slots)
+        fused = FUSED_FORWARD and _layer_fused(dt, H, in_slots, rs_slots)
         frag_in, frag_rs = _frag_images(in_slots, rs_slots) if fused else (None, None)
         for i in range(n_layers):
             last = i == n_layers - 1
@@ -79,10 +80,31 @@ class WNStackFn(torch.autograd.Function):
         dacc = dout.contiguous()
         dx_next = None
         dg32 = torch.zeros((n_layers, B, 2 * H), dtype=torch.float32, device=dev) if g_lbh is not None else None
+        fused = FUSED_BACKWARD and _layer_fused(dt, H, in_slots, rs_slots)
         for i in reversed(range(n_layers)):
             last = i == n_layers - 1
             x, x_in, acts = saved[3 * i: 3 * i + 3]
             rs_w = H if last else 2 * H
+            if fused:
+                # one launch for the data half (csrc/wn_layer.hip); the weight gradients read the drs / dx_in it writes
+                si, sr = in_slots[i], rs_slots[i]
+                drs = torch.empty((B, T, rs_w), dtype=dtype, device=dev)
+                dx_in = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
+                dx = torch.empty((B, T, H), dtype=dtype, device=dev)
+                L.check(L.lib().evt_wn_layer_bwd_data(dt, L.ptr(dx_next), L.ptr(dacc), L.ptr(x_in),
+                                                      L.ptr(g_lbh[i] if g_lbh is not None else None),
+                                                      L.ptr(sr.bank.frag(sr, "alt")), L.ptr(si.bank.frag(si, "alt")),
+                                                      L.ptr(lens), L.ptr(drs), L.ptr(dx_in), L.ptr(dx),
+                                                      L.ptr(dg32[i] if dg32 is not None else None), B, T, H, si.module.k,
+                                                      int(last), L.stream_ptr()), "evt_wn_layer_bwd_data")
+                if last:
+                    dacc = drs
+                if sr.bank.weight_grads:
+                    HC._bwd_weight(sr, acts, drs, None, B, T, 1.0, L.ACT_NONE, 1.0)
+                if si.bank.weight_grads:
+                    HC._bwd_weight(si, x, dx_in, None, B, T, 1.0, L.ACT_NONE, 1.0)
+                dx_next = dx
+                continue
             drs = torch.empty((B, T, rs_w), dtype=dtype, device=dev)
             dx_res = None if last else torch.empty((B, T, H), dtype=dtype, device=dev)
             L.check(L.lib().evt_wn_residual_bwd(dt, L.ptr(dx_next), L.ptr(dacc), L.ptr(lens), T, L.ptr(dx_res), L.ptr(drs),
@@ -107,13 +129,12 @@ class WNStackFn(torch.autograd.Function):
 
 
 FUSED_FORWARD = True     # tests / measurements: False = the four-launch layer forward at every shape
+FUSED_BACKWARD = True    # likewise: False = the four-launch data half of the layer backward
 
 
 def _layer_fused(dt, H, in_slots, rs_slots):
     """the one-launch layer forward serves this stack: 16-bit type, every in_layer [H -> 2H, k = 5, dilation 1, 'same' padding],
     every res_skip 1 x 1 [H -> 2H, last H -> H] -- the two WN stacks of the model (posterior encoder, flow)"""
-    if not FUSED_FORWARD:
-        return False
     n = len(in_slots)
     for i, (si, sr) in enumerate(zip(in_slots, rs_slots)):
         mi, mr = si.module, sr.module

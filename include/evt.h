@@ -271,13 +271,24 @@ int evt_resunit_wide_bwd_data(const evt_resunit_params* p, const void* dy, float
  * evt_frag_pack: items is a DEVICE table; each item copies a REG or ALT image of `rows` (multiple of 16) rows x `ktot`
  * (multiple of 32) elements of the 16-bit type into FRAGMENT ORDER [rows / 16][ktot / 32][64][8] -- lane (n, g) of (tile, K step)
  * holds row 16 tile + n, elements 32 ks + 8 g .. + 7, i.e. every MFMA A operand is one contiguous 1 KiB load of a wave.
- * One launch per weight fold for all such images of a model (they change when the weights do).  Reader: evt_wn_layer_fwd. */
+ * One launch per weight fold for all such images of a model (they change when the weights do).  Readers: evt_wn_layer_fwd,
+ * evt_wn_layer_bwd_data. */
 typedef struct evt_frag_item {
   const void* src;   /* REG or ALT image, [rows][ktot] */
   void* dst;         /* rows * ktot elements */
   int32_t rows, ktot;
 } evt_frag_item;
 int evt_frag_pack(const evt_frag_item* items, int32_t nitems, void* stream);
+/* evt_wn_layer_bwd_data: the data half of the same layer's backward in one launch (instead of evt_wn_residual_bwd, the 1 x 1
+ * evt_conv1d_bwd_data, evt_gated_act_bwd and the k = 5 evt_conv1d_bwd_data with its add epilogue):
+ *   drs = [dx_next * mask | dacc] [nseq][L][2H]   (last: drs = dacc * mask [nseq][L][H]; dx_next must be NULL)
+ *   dacts = res_skip^T drs;  dx_in = gate'(x_in + g) dacts [nseq][L][2H];  dg [nseq][2H] fp32 += sum over positions (or NULL)
+ *   dx = in_layer^T dx_in + dx_next * mask [nseq][L][H]
+ * w_rs_alt_frag / w_in_alt_frag: the ALT images in fragment order.  drs and dx_in are outputs the two weight-gradient
+ * launches (evt_conv1d_bwd_weight on (acts, drs) and (x, dx_in)) read, as before. */
+int evt_wn_layer_bwd_data(int32_t dtype, const void* dx_next, const void* dacc, const void* x_in, const void* g,
+                          const void* w_rs_alt_frag, const void* w_in_alt_frag, const int32_t* lens, void* drs, void* dx_in,
+                          void* dx, float* dg, int32_t nseq, int32_t L, int32_t H, int32_t k, int32_t last, void* stream);
 int32_t evt_wn_layer_supported(int32_t dtype, int32_t H, int32_t k, int32_t dil);
 int evt_wn_layer_fwd(int32_t dtype, const void* x, const void* w_in_frag, const float* b_in, const void* w_rs_frag,
                      const float* b_rs, const void* g, const void* acc_in, const int32_t* lens, void* x_in, void* acts,

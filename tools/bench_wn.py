@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--backward", action="store_true", help="forward + backward of the stack (weight gradients included)")
     args = ap.parse_args()
     from easevoice_trainer_amd.hip import conv as HC
     from easevoice_trainer_amd.hip import lib as L
@@ -45,23 +46,39 @@ def main():
     junk = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev) if args.flush else None
     times = {True: [], False: []}
     graphs = {}
-    with torch.no_grad():
-        g_lbh = m.cond_layer(g).to(dtype).view(B, NL, 2 * H).transpose(0, 1).contiguous()
+    wgt = torch.randn(B, T, H, device=dev).to(dtype)
+    bank.defer_n = 0                     # weight gradients in line: one stream, what the captured graph replays
+
+    def run(xin, glb):
+        out = W.wn_stack(xin, glb, lens, m.in_layers, m.res_skip_layers, H)
+        if args.backward:
+            out.backward(wgt)
+        return out
+    with torch.set_grad_enabled(args.backward):
+        g_lbh = m.cond_layer(g).to(dtype).view(B, NL, 2 * H).transpose(0, 1).contiguous().detach()
+        if args.backward:
+            x.requires_grad_(True)
+            g_lbh.requires_grad_(True)
         for fused in (True, False):          # one captured graph per variant: replay has no host time between the launches
-            W.FUSED_FORWARD = fused
-            for _ in range(2):
-                W.wn_stack(x, g_lbh, lens, m.in_layers, m.res_skip_layers, H)
+            W.FUSED_FORWARD = W.FUSED_BACKWARD = fused
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    run(x, g_lbh)
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                out = W.wn_stack(x, g_lbh, lens, m.in_layers, m.res_skip_layers, H)
-            graphs[fused] = (gr, out)
-        W.FUSED_FORWARD = True
+                out = run(x, g_lbh)
+            graphs[fused] = (gr, out.detach())
+        W.FUSED_FORWARD = W.FUSED_BACKWARD = True
         for gr, _ in graphs.values():
             gr.replay()
         torch.cuda.synchronize()
         d = (graphs[True][1].float() - graphs[False][1].float()).abs().max().item()
         print(f"max |one launch - four launches| of the stack output: {d:.4g} (output max {graphs[False][1].float().abs().max().item():.4g})")
+    with torch.no_grad():
         for it in range(args.iters + 3):
             for fused in (True, False):
                 if junk is not None:
@@ -76,8 +93,8 @@ def main():
     for fused in (True, False):
         v = sorted(times[fused])
         print(f"{'one launch ' if fused else 'four launches'} per layer: median {v[len(v) // 2]:7.2f} us  min {v[0]:7.2f} us   "
-              f"[{args.dtype}, {B} x {T}, {NL} layers, flush={args.flush}, EVT_WN_NT={os.environ.get('EVT_WN_NT', '2')}, "
-              f"EVT_WN_RING={os.environ.get('EVT_WN_RING', '8')}; graph replay]")
+              f"[{args.dtype}, {B} x {T}, {NL} layers, flush={args.flush}, EVT_WN_NT={os.environ.get('EVT_WN_NT', '1')}, "
+              f"EVT_WN_RING={os.environ.get('EVT_WN_RING', '8')}; graph replay{', forward + backward' if args.backward else ''}]")
 
 
 if __name__ == "__main__":
