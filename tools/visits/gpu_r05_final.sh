@@ -24,7 +24,13 @@ if [ -n "$F" ] && [ -n "$W" ]; then timeout 60 python tools/pmc_traffic.py $F $W
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/p5 -- python tools/bench_attn.py --iters 2 > $O/p5.log 2>&1
 A=$(find $O/p5 -name '*counter_collection.csv' | head -1)
 if [ -n "$A" ]; then timeout 60 python tools/pmc_summary.py $A attn_ --json $O/attn_pmc.json > $O/attn_pmc.txt 2>&1; fi
-rm -rf $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
+mkdir -p $O/p6
+timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/p6 -- python -m pytest tests/test_wn_layer_gpu.py -q -k "16-200 and bf16" > $O/p6.log 2>&1
+Wn=$(find $O/p6 -name '*counter_collection.csv' | head -1)
+if [ -n "$Wn" ]; then timeout 60 python tools/pmc_summary.py $Wn wn_layer > $O/wn_layer_pmc.txt 2>&1; fi
+rm -rf $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6
+timeout 120 python tools/bench_wn.py --flush > $O/bench_wn.txt 2>&1
+timeout 120 python tools/bench_wn.py --flush --backward >> $O/bench_wn.txt 2>&1
 timeout 200 python tools/trace_shapes.py --top 400 > $O/conv_time_by_shape.txt 2>&1
 timeout 100 python tools/bench_attn.py > $O/bench_attn_b32.json 2>/dev/null
 bash tools/visits/graphstats.sh $O/replay_kernels.txt > /dev/null 2>&1
