@@ -91,12 +91,15 @@ class WNStackFn(torch.autograd.Function):
                 drs = torch.empty((B, T, rs_w), dtype=dtype, device=dev)
                 dx_in = torch.empty((B, T, 2 * H), dtype=dtype, device=dev)
                 dx = torch.empty((B, T, H), dtype=dtype, device=dev)
+                e0 = HC._t0()
                 L.check(L.lib().evt_wn_layer_bwd_data(dt, L.ptr(dx_next), L.ptr(dacc), L.ptr(x_in),
                                                       L.ptr(g_lbh[i] if g_lbh is not None else None),
                                                       L.ptr(sr.bank.frag(sr, "alt")), L.ptr(si.bank.frag(si, "alt")),
                                                       L.ptr(lens), L.ptr(drs), L.ptr(dx_in), L.ptr(dx),
                                                       L.ptr(dg32[i] if dg32 is not None else None), B, T, H, si.module.k,
                                                       int(last), L.stream_ptr()), "evt_wn_layer_bwd_data")
+                if e0 is not None:
+                    _t1_layer(e0, si.module, sr.module, x, "bwd_data")
                 if last:
                     dacc = drs
                 if sr.bank.weight_grads:
@@ -154,9 +157,10 @@ def _frag_images(in_slots, rs_slots):
     return [bank.frag(s, "reg") for s in in_slots], [bank.frag(s, "reg") for s in rs_slots]
 
 
-def _t1_layer(e0, mi, mr, x):
-    """trace record of one fused layer forward (bench.py's per-launch table): flops of both convolutions; bytes = x and the
-    skip sum in, x_in / acts / x / skip sum out, both weight images"""
+def _t1_layer(e0, mi, mr, x, kind="fwd"):
+    """trace record of one fused layer launch (bench.py's per-launch table): flops of both convolutions; bytes: forward = x and
+    the skip sum in, x_in / acts / x / skip sum out; backward-data = the two gradients and x_in in, drs / dx_in / dx out; both
+    weight images either way"""
     e0, rf = e0
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
@@ -164,7 +168,7 @@ def _t1_layer(e0, mi, mr, x):
         rf.__exit__(None, None, None)
     n, ln, h = x.shape
     macs = n * ln * (mi.cin * mi.cout * mi.k + mr.cin * mr.cout)
-    HC.TRACE.append((L.lib().evt_last_kernel_tag().decode(), "fwd", 2 * macs,
+    HC.TRACE.append((L.lib().evt_last_kernel_tag().decode(), kind, 2 * macs,
                      (7 * x.numel() + mi.v.numel() + mr.v.numel()) * 2, e0, e1,
                      f"WN layer {h}>{mi.cout}>{mr.cout} k{mi.k} n{n} L{ln}", mi))
 

@@ -63,7 +63,7 @@ def kernel_profile(run):
     return kernels, seq
 
 
-_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_|resunit_|rows16_|add3_scale_kernel|lrelu_kernel|dact_mul_kernel|"
+_MAIN = re.compile(r"^(conv_|wgrad_|grouped_|cout1_|cin1_|resunit_|wn_layer_|rows16_|add3_scale_kernel|lrelu_kernel|dact_mul_kernel|"
                    r"fold_partials_multi)")
 
 
