@@ -136,8 +136,19 @@ FUSED_BACKWARD = True    # likewise: False = the four-launch data half of the la
 
 
 def _layer_fused(dt, H, in_slots, rs_slots):
-    """the one-launch layer forward serves this stack: 16-bit type, every in_layer [H -> 2H, k = 5, dilation 1, 'same' padding],
-    every res_skip 1 x 1 [H -> 2H, last H -> H] -- the two WN stacks of the model (posterior encoder, flow)"""
+    """the one-launch layer kernels serve this stack: 16-bit type, every in_layer [H -> 2H, k = 5, dilation 1, 'same' padding],
+    every res_skip 1 x 1 [H -> 2H, last H -> H] -- the two WN stacks of the model (posterior encoder, flow).  Decided once per
+    stack and bank (the geometry of a module does not change)."""
+    bank = in_slots[0].bank
+    cache = bank.__dict__.setdefault("_wn_fused", {})
+    key = (id(in_slots[0]), len(in_slots), dt, H)
+    ok = cache.get(key)
+    if ok is None:
+        ok = cache[key] = _layer_fused_check(dt, H, in_slots, rs_slots)
+    return ok
+
+
+def _layer_fused_check(dt, H, in_slots, rs_slots):
     n = len(in_slots)
     for i, (si, sr) in enumerate(zip(in_slots, rs_slots)):
         mi, mr = si.module, sr.module
