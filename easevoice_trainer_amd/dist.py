@@ -37,7 +37,12 @@ class GradReducer:
         under rsag_min_bytes (and for worlds of two, where there is one link either way).  The results are the same sums
         (per element one reduction over the ranks either way); equality-tested against all_reduce on gloo
         (tests/test_host_cpu.py) and issued on RCCL by the one-rank self-test (tests/test_zz_rccl_selftest_gpu.py).
-        Default auto: reduce-scatter + all-gather from 3 ranks up (EVT_DP_RSAG=0 is the all-reduce fallback).
+        Default auto: reduce-scatter + all-gather from 3 ranks up -- but only after `verify_rsag()` has run BOTH forms
+        on the real group over a small integer-valued buffer and every rank saw identical sums (the pair has
+        never met a multi-rank RCCL communicator; a mismatch or an exception on any rank puts all ranks back on
+        all-reduce, with a warning).  The check runs once, at the first bucket that would take the pair -- before any
+        graph capture, since the first steps of a shape are eager.  EVT_DP_RSAG=0 is the all-reduce fallback,
+        EVT_DP_RSAG=1 forces the pair without the check.
         force (default: EVT_DP_FORCE=1): issue the collectives even in a world of one -- a one-rank RCCL group runs the
         same launches on the same side stream between the same graph replays, so the stream / replay ordering of the
         data-parallel program can be exercised (and its cost timed) on a single GPU: bench.py --dp-program 2.
@@ -58,6 +63,7 @@ class GradReducer:
         self.stats = {"all_reduce": 0, "rs_ag": 0, "bytes": 0}
         self.timing = False
         self._waits = []
+        self.rsag_verified = None     # auto mode: None = not checked yet, True / False = result of verify_rsag()
 
     @property
     def rsag(self):
@@ -71,7 +77,51 @@ class GradReducer:
     def _use_rsag(self, n):
         if self.rsag_mode == "1":
             return n >= self.world
-        return self.rsag_mode == "auto" and self.world > 2 and n >= max(self.world, self.rsag_min_elems)
+        return (self.rsag_mode == "auto" and self.rsag_verified is not False and self.world > 2
+                and n >= max(self.world, self.rsag_min_elems))
+
+    def _rs_ag(self, body, chunk):
+        # the reduced shard lands in a buffer of its own (an output aliasing the input is something only gloo has run), the
+        # all-gather then writes every rank's shard back over the bucket
+        key = (chunk, body.dtype, body.device)
+        mine = self._shards.get(key)
+        if mine is None:
+            mine = self._shards[key] = torch.empty(chunk, dtype=body.dtype, device=body.device)
+        dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_gather_into_tensor(body, mine, group=self.group)
+
+    def verify_rsag(self, device):
+        """auto mode, once per reducer: reduce-scatter + all-gather against all_reduce on THIS group.  Small integers
+        (every partial sum exact in fp32), a different vector per rank, a length that is not a multiple of the world.
+        The verdict is itself reduced (MIN over ranks), so all ranks take the same branch afterwards."""
+        if self.rsag_verified is not None:
+            return self.rsag_verified
+        ok = 1.0
+        try:
+            rank = dist.get_rank(self.group)
+            n = 4096 * self.world
+            idx = torch.arange(n, device=device, dtype=torch.float32)
+            a = ((idx * 7 + rank * 13) % 251) - 125.0
+            b = a.clone()
+            dist.all_reduce(a, op=dist.ReduceOp.SUM, group=self.group)
+            self._rs_ag(b, n // self.world)
+            if not torch.equal(a, b):
+                ok = 0.0
+        except Exception as e:  # noqa: BLE001 -- any failure of the pair means: do not use it
+            import warnings
+
+            warnings.warn(f"GradReducer: reduce-scatter + all-gather self-check raised {e!r}")
+            ok = 0.0
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self.rsag_verified = bool(flag.item() == 1.0)
+        self._shards.pop((4096, torch.float32, device), None)
+        if not self.rsag_verified:
+            import warnings
+
+            warnings.warn("GradReducer: reduce-scatter + all-gather did not reproduce all_reduce on this group; "
+                          "using all_reduce for every bucket (EVT_DP_RSAG=0 behaviour)")
+        return self.rsag_verified
 
     def plan(self, n):
         """what all_reduce() issues for a flat range of n fp32 elements: [(bytes, "all-reduce" | "reduce-scatter + all-gather")]"""
@@ -81,6 +131,8 @@ class GradReducer:
     def _sum_bucket(self, t):
         """sum the 1-D contiguous bucket `t` over the group, in place"""
         self.stats["bytes"] += t.numel() * t.element_size()
+        if self.rsag_mode == "auto" and self.rsag_verified is None and self._use_rsag(t.numel()):
+            self.verify_rsag(t.device)
         if not self._use_rsag(t.numel()):
             self.stats["all_reduce"] += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -89,14 +141,7 @@ class GradReducer:
         w = self.world
         chunk = t.numel() // w
         body = t[: chunk * w]
-        # the reduced shard lands in a buffer of its own (an output aliasing the input is something only gloo has run), the
-        # all-gather then writes every rank's shard back over the bucket
-        key = (chunk, t.dtype, t.device)
-        mine = self._shards.get(key)
-        if mine is None:
-            mine = self._shards[key] = torch.empty(chunk, dtype=t.dtype, device=t.device)
-        dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_gather_into_tensor(body, mine, group=self.group)
+        self._rs_ag(body, chunk)
         if chunk * w < t.numel():                           # fewer than `world` leftover elements
             dist.all_reduce(t[chunk * w:], op=dist.ReduceOp.SUM, group=self.group)
 
@@ -104,8 +149,8 @@ class GradReducer:
         """how gradients are exchanged, for the bench line's config.parallelism.  ranges: [(name, elements)] of the flat
         ranges the step reduces one by one -> the plan per range (MiB, kind) is spelt out."""
         kind = {"0": "all-reduce", "1": "reduce-scatter + all-gather",
-                "auto": (f"reduce-scatter + all-gather for buckets >= {self.rsag_min_elems * 4 >> 20} MiB from 3 ranks up, "
-                         "all-reduce otherwise")}
+                "auto": (f"reduce-scatter + all-gather for buckets >= {self.rsag_min_elems * 4 >> 20} MiB from 3 ranks up "
+                         "(after a start-up equality check against all-reduce on the group), all-reduce otherwise")}
         s = f"dp{self.world}, {kind[self.rsag_mode]}, buckets of {self.bucket_elems * 4 >> 20} MiB"
         if self.force and self.world == 1:
             s += ", one-rank collectives forced"

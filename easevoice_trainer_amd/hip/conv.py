@@ -249,6 +249,7 @@ class WeightBank:
         self._nrows = 0
         # images that also exist in MFMA fragment order (frag()): re-made behind every fold by one launch
         self._frags, self._frag_items, self._frag_rows, self._frag_tables = {}, [], [], {}
+        self._frag_retired = []       # superseded device tables, kept alive for graphs captured with them
 
     def build_tables(self):
         """(Re)build the device descriptor tables.  Must be called after parameters (and their .grad
@@ -341,6 +342,9 @@ class WeightBank:
             self._frags[key] = f
             self._frag_items.append(it)
             self._frag_rows.append(self._slot_rows[self.slots.index(slot)])
+            # a new image changes what a fold of its rows has to re-pack: the row-range tables are rebuilt on demand, but
+            # the old device tables stay ALIVE -- a HIP graph captured earlier holds their addresses
+            self._frag_retired.extend(t for t, _n in self._frag_tables.values() if t is not None)
             self._frag_tables.clear()
             one = L.struct_to_device([it], self.device)
             self._frag_tables[("one", len(self._frag_items))] = (one, 1)      # kept alive
@@ -352,6 +356,11 @@ class WeightBank:
             return
         tab = self._frag_tables.get((lo, hi))
         if tab is None:
+            if torch.cuda.is_current_stream_capturing():
+                # the table is a synchronous host-to-device copy: not inside a capture (the eager steps that precede a
+                # capture fold the same row ranges, so this only fires for a range first seen while capturing)
+                raise L.EvtError(f"fragment-order table for rows [{lo}, {hi}) requested during a graph capture; fold the "
+                                 "same range once eagerly first")
             items = [it for it, (r0, r1) in zip(self._frag_items, self._frag_rows) if r0 < hi and r1 > lo]
             tab = self._frag_tables[(lo, hi)] = (L.struct_to_device(items, self.device) if items else None, len(items))
         if tab[1]:

@@ -395,7 +395,9 @@ class DeviceGradScaler:
         return loss * self._scale[0] if self.enabled else loss
 
     def unscale_(self, owner):
-        """owner.arena.grad *= 1 / scale; owner's flag is raised if a gradient is not finite"""
+        """owner.arena.grad *= 1 / scale; owner's flag is raised if a gradient is not finite.  The flag is cleared by
+        update() only (torch.amp.GradScaler keeps found_inf per optimizer until update() as well): a step that unscales
+        must end with update(), as both trainers' loops do -- a do_opt=False caller that skips it inherits the flag."""
         if not self.enabled:
             return
         a = owner.arena

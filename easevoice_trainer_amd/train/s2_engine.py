@@ -346,14 +346,31 @@ class S2Engine:
         rt_g.book_join()
         st.gss_g = rt_g.grad_sumsq()
 
+    def _d_groups(self):
+        """[(sub-discriminator indices, arena lo, arena hi)]: the EVT_DP_D_PIECES groups of neighbouring sub-discriminators
+        the data-parallel D step differentiates and reduces one by one, in issue order (last sub-discriminator first)"""
+        order = list(reversed(range(len(self._d_convs))))
+        nd = min(len(order), self.dp_d_pieces)
+        base, extra = divmod(len(order), nd)
+        groups, at = [], 0
+        for n in range(nd):
+            size = base + (1 if n < extra else 0)
+            grp = order[at:at + size]
+            at += size
+            lo, hi = min(self._d_ranges[i][0] for i in grp), max(self._d_ranges[i][1] for i in grp)
+            if hi - lo != sum(self._d_ranges[i][1] - self._d_ranges[i][0] for i in grp):
+                raise L.EvtError("data-parallel pieces: neighbouring sub-discriminators are expected to be adjacent in the arena")
+            groups.append((grp, lo, hi))
+        return groups
+
     def exchange_ranges(self):
         """[(name, fp32 elements)] of the flat gradient ranges the data-parallel step reduces one by one, in issue order
         (bench.py prints the collective plan per range through GradReducer.describe)"""
         if not self.overlap:
             return [("D arena", self.rt_d.arena.grad.numel()), ("G arena", self.rt_g.arena.grad.numel())]
-        nd, ng = min(len(self._d_ranges), self.dp_d_pieces), self.dp_g_pieces
-        dtot = sum(hi - lo for lo, hi in self._d_ranges)
-        out = [(f"D piece {i + 1}/{nd}", dtot // nd) for i in range(nd)]
+        ng = self.dp_g_pieces
+        groups = self._d_groups()                     # the very groups _program reduces (sizes differ a lot: d0 is small)
+        out = [(f"D piece {i + 1}/{len(groups)}", hi - lo) for i, (_grp, lo, hi) in enumerate(groups)]
         early = []
         if ng >= 2:
             out.append(("G vocoder", self._dec_range[1] - self._dec_range[0]))
@@ -388,17 +405,9 @@ class S2Engine:
         # next sub-model's backward).  Measured on one GPU (profiles/r05_dp_program.txt): the six discriminator pieces are
         # free, an early generator piece costs 0.5-1 ms -- more than the ~0.25-0.5 ms of exchange it would hide on 8 GPUs'
         # xGMI -- so the discriminators' 187 MB are reduced under their own backward and the generator's 205 MB after its.
-        nd, ng = min(len(order), self.dp_d_pieces), self.dp_g_pieces
-        base, extra = divmod(len(order), nd)
-        groups, at = [], 0
-        for n in range(nd):
-            size = base + (1 if n < extra else 0)
-            groups.append(order[at:at + size])
-            at += size
-        for n, grp in enumerate(groups):
-            lo, hi = min(self._d_ranges[i][0] for i in grp), max(self._d_ranges[i][1] for i in grp)
-            if hi - lo != sum(self._d_ranges[i][1] - self._d_ranges[i][0] for i in grp):
-                raise L.EvtError("data-parallel pieces: neighbouring sub-discriminators are expected to be adjacent in the arena")
+        ng = self.dp_g_pieces
+        groups = self._d_groups()
+        for n, (grp, lo, hi) in enumerate(groups):
             last = n == len(groups) - 1
 
             def after(lo=lo, hi=hi, last=last):

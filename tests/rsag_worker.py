@@ -36,6 +36,28 @@ def main():
         want_rsag = full + (1 if tail >= 512 else 0)
         assert r.stats["rs_ag"] == want_rsag and r.stats["all_reduce"] == (1 if 0 < tail < 512 else 0), (n, r.stats)
         assert r.stats["bytes"] == 4 * n and "reduce-scatter" in r.describe()
+        assert r.rsag_verified is (True if want_rsag else None), (n, r.rsag_verified)    # checked at the first eligible bucket
+    # the start-up check of auto mode: a pair that does not reproduce all_reduce on ONE rank puts EVERY rank
+    # back on all-reduce, and the sums stay right
+    x = torch.randn(4099, generator=g)
+    a, c = x.clone(), x.clone()
+    GradReducer(world, bucket_bytes=4 * 1024, rsag=False).all_reduce(a)
+    r = GradReducer(world, bucket_bytes=4 * 1024, rsag="auto", rsag_min_bytes=2 * 1024)
+    good = r._rs_ag
+
+    def broken(body, chunk):
+        good(body, chunk)
+        if rank == 1:
+            body[0] += 1.0
+
+    r._rs_ag = broken
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r.all_reduce(c)
+    assert r.rsag_verified is False and r.stats["rs_ag"] == 0 and r.stats["all_reduce"] == 5, (r.rsag_verified, r.stats)
+    assert torch.allclose(c, a, rtol=1e-6, atol=1e-6)
+    assert r.plan(1 << 20) == [(4 * 1024, "all-reduce")] * 1024
     dist.destroy_process_group()
 
 

@@ -645,8 +645,11 @@ def test_reducer_plan_and_description():
     r2 = GradReducer(2, rsag="auto")
     assert r2.plan(100 * mib) == [(64 << 20, "all-reduce"), (36 << 20, "all-reduce")]      # two ranks: one link either way
     d = r8.describe([("D piece 1/6", 31 * mib), ("G rest", 4 * mib)])
-    assert d.startswith("dp8, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up, all-reduce otherwise, buckets of 64 MiB")
+    assert d.startswith("dp8, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up (after a start-up equality "
+                        "check against all-reduce on the group), all-reduce otherwise, buckets of 64 MiB")
     assert "D piece 1/6 31.0 MiB = 1 x reduce-scatter + all-gather" in d and "G rest 4.0 MiB = 1 x all-reduce" in d
+    r8.rsag_verified = False                     # what a failed start-up check leaves behind: all-reduce everywhere
+    assert r8.plan(31 * mib) == [(31 << 20, "all-reduce")]
     one = GradReducer(1)
     assert not one.active and GradReducer(1, force=True).active
     with pytest.raises(ValueError):
