@@ -278,7 +278,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
     const int trow = r * 4 + rrow;
     const int row = pb * 256 + wc * 64 + trow;
     if (row >= p.M) continue;
-    const long off = (long)row * p.NO + yi * 256 + wr * 128 + c16 * 8;
+    // VAR bit 4 (measurement): every token tile writes the rows of tile 0 -- the output stays L2-resident
+    const long off = (long)((VAR & 16) ? (row & 255) : row) * p.NO + yi * 256 + wr * 128 + c16 * 8;
     uint4 v = *reinterpret_cast<const uint4*>(ep + trow * EP_PITCH + c16 * 16);
     if (p.gate || p.add) {
       uint4 gv = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
@@ -364,6 +365,8 @@ int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int
     case 6: G256_LAUNCH(6) break;
     case 8: G256_LAUNCH(8) break;
     case 9: G256_LAUNCH(9) break;
+    case 16: G256_LAUNCH(16) break;
+    case 17: G256_LAUNCH(17) break;
     default: return EVT_EINVAL;
   }
 #undef G256_LAUNCH

@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 
 SHAPES = [(32768, 1536, 512), (32768, 512, 512), (32768, 2048, 512), (32768, 512, 2048), (16384, 1536, 512)]
 VARIANTS = {0: "full", 8: "no stores", 2: "no DMA after prologue", 1: "no MFMA", 4: "no fragment reads", 5: "no MFMA, no reads",
-            6: "no DMA, no reads", 9: "no MFMA, no stores"}
+            6: "no DMA, no reads", 9: "no MFMA, no stores", 16: "stores folded onto 256 rows (L2-resident output)",
+            17: "no MFMA, stores folded"}
 
 
 def main():
