@@ -841,6 +841,10 @@ __global__ __launch_bounds__(256, NS > 2 ? 1 : 2) void wgrad_gemm(WgP p, int sta
         for (int r = 0; r < 4; ++r) atomicAdd(p.dbias + a0 + wr * 64 + i * 16 + g8 * 4 + r, bacc[i][r]);
   }
 
+  if (p.parts < 0) {      // measurement variant (EVT_WGRAD_GEMM_NOEPI=1): the main loop without its atomics
+    if (acc[0][0][0] == 12345.678f) p.dw[0] = 1.f;
+    return;
+  }
   // lane holds dy-channels g8*4..+3 (rows) x x-channel j16 (column) of each tile; image [CA][nchunk][1][32]
 #pragma unroll
   for (int t = 0; t < GKT; ++t)
@@ -1444,6 +1448,8 @@ int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
   if (!wgrad_gemm_eligible(p, EVT_DT_HALF)) return EVT_ENOTSUP;
   p.nchunk = p.CB / 32;
   p.ntapgrp = 1;
+  static const bool noepi = getenv("EVT_WGRAD_GEMM_NOEPI") != nullptr;
+  if (noepi) p.parts = -1;
   const long tiles = (long)(p.CA / 128) * (p.CB / 128);
   const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
   // one resident wave of blocks (2 per CU): more splits only add fp32 atomics (46 MB of them per launch was a third of

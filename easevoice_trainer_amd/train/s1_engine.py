@@ -94,23 +94,29 @@ class S1Engine:
             p.grad = v
         stepped = False
         if stepping:
-            if self.reducer is not None and self.reducer.active:
-                self.reducer.all_reduce(self.arena.grad[:hi], async_op=self.arena.grad.is_cuda, average=True)
-                self.reducer.wait()
-            overflow = False
-            if self.scaler.enabled:
-                self.scaler.unscale_(self)                                    # self.arena: every rank holds the same sums
-                overflow = bool(self.scaler.found_inf(self).item() != 0.0)    # GradScaler.step's host read
-            if not overflow:
-                self.optimizer.step()
-                self.bank.mark_dirty()    # weights written through raw pointers: refold the GEMM images on next use
-            else:
-                self.skipped_steps += 1
-            self.scaler.update()
-            self.optimizer.zero_grad()
-            self.scheduler.step()         # Lightning steps the scheduler whether or not the scaler skipped the optimiser
+            self._finish_window(hi)
             stepped = True
         return loss.detach(), acc.detach(), stepped
+
+    def _finish_window(self, hi=None):
+        """the optimiser step of an accumulation window on the gradients in the arena (t2s_lightning_module.py:53-56 under
+        the AMP plugin: scaler.step = unscale, skip on inf / nan, step; scaler.update; zero_grad; scheduler.step)"""
+        hi = self.arena.grad.numel() if hi is None else hi
+        if self.reducer is not None and self.reducer.active:
+            self.reducer.all_reduce(self.arena.grad[:hi], async_op=self.arena.grad.is_cuda, average=True)
+            self.reducer.wait()
+        overflow = False
+        if self.scaler.enabled:
+            self.scaler.unscale_(self)                                    # self.arena: every rank holds the same sums
+            overflow = bool(self.scaler.found_inf(self).item() != 0.0)    # GradScaler.step's host read
+        if not overflow:
+            self.optimizer.step()
+            self.bank.mark_dirty()    # weights written through raw pointers: refold the GEMM images on next use
+        else:
+            self.skipped_steps += 1
+        self.scaler.update()
+        self.optimizer.zero_grad()
+        self.scheduler.step()         # Lightning steps the scheduler whether or not the scaler skipped the optimiser
 
     def _gather(self, lo, hi):
         """add the gradient tensors autograd produced for the parameters in arena range [lo, hi) into their arena views"""

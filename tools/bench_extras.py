@@ -192,6 +192,14 @@ def roofline_s2(args, eng, step_fn, n_steps=2):
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if tag in pmc:
             traffic = pmc[tag]["traffic_bytes_per_launch"]
+        dec_only = pmc.get("hifigan_dec_only_kernels")
+        if r_voc is not None and dec_only:
+            # counter bytes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) of the kernels only `dec` launches:
+            # the fused ResBlock steps, their weight gradients and fold launches -- NOT the shared conv kernels of its
+            # up-sampling / C = 256 stage (conv_ring / conv_deep rows above are per launch over all their callers)
+            r_voc["traffic"] = dict(dec_only_kernels_gb_per_step=dec_only["traffic_gb_per_step"],
+                                    dec_only_kernel_launches_per_step=dec_only["launches_per_step"],
+                                    source="profiles/pmc_traffic.json: hifigan_dec_only_kernels (per kernel instantiation there)")
     except Exception:
         traffic = None
     top = sorted(kernels.items(), key=lambda kv: -kv[1][1])[:10]
