@@ -24,6 +24,8 @@
 // branch's gradient) -- what the s1 block otherwise runs as separate element-wise launches.
 #include "evt_common.h"
 #include "../../include/evt.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -306,6 +308,349 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt(G256 p) {
   }   // tile loop
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm256_pipe (round 6): the same 256 x 256 x 64 tile and LDS-DMA ring, with the tile boundary taken out of the critical path.
+//
+// What the ablations of gemm256_nt say at [32768, 1536, 512] (profiles/r06_gemm256_ablation.txt): 74 us in all, 53 us
+// without the output stores, and the stores cost the same 21 us when every token tile writes the SAME 256 rows (an
+// L2-resident output): the epilogue is bound by its own issue -- the LDS round trip of the tile and ~10-14 B/clk/CU of
+// global-store issue -- not by HBM, and nothing else runs on the CU while it lasts (one block per CU; the K = 512 layers
+// have only 8 K tiles per output tile).  So here:
+//   * the DMA stream never drains at a tile boundary: pieces are issued five ahead across tiles (the issuing side walks
+//     its own (tile, K tile, piece) cursor), the next tile's first pieces land while the current tile finishes;
+//   * the epilogue is cut into the four 64-channel x 32-token QUADRANTS of a wave's accumulators and each quadrant leaves
+//     in the phase after its last MFMA, next to the following quadrant's MFMAs: phases 1, 2, 3 of the last K tile carry
+//     quadrants (0,0), (0,1), (1,1), phase 0 of the NEXT tile's first K tile carries (1,0).  A quadrant goes through a
+//     wave-private 2 KiB staging area (two halves of 16 tokens x 128 bytes, 16-byte-chunk swizzle) behind the ring -- no
+//     block barrier, the ring is never touched -- and leaves as 16 bytes per lane, whole 128-byte row segments;
+//   * the accumulators of a finished quadrant are zeroed there, so the K loop has no first-tile variant.
+// gfx9 counts loads AND stores in vmcnt and retires them in order, so the counted waits of the ring have to know about the
+// stores that are interleaved with the DMA: the wave keeps a small queue model in SGPRs (instructions issued in each of
+// the last four phases, split into "before / after that phase's piece") and waits for exactly what the next fragment
+// reads need: everything up to the piece issued four phases ago.
+// Epilogues with a gate / residual operand (backward-data of linear2 / of the block inputs) stay on gemm256_nt.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int STG_WAVE = 2048;                                  // staging bytes per wave: 16 token rows x 128 bytes
+constexpr int LDS_PIPE = 2 * KTB + 8 * STG_WAVE + 256 * 4;      // ring | staging | bias   (148480 bytes)
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (rounded down to an even count: waiting for one more is always safe)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n >> 1) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<2>(); break;
+    case 2: wait_vmcnt<4>(); break;
+    case 3: wait_vmcnt<6>(); break;
+    case 4: wait_vmcnt<8>(); break;
+    case 5: wait_vmcnt<10>(); break;
+    case 6: wait_vmcnt<12>(); break;
+    case 7: wait_vmcnt<14>(); break;
+    case 8: wait_vmcnt<16>(); break;
+    case 9: wait_vmcnt<18>(); break;
+    case 10: wait_vmcnt<20>(); break;
+    case 11: wait_vmcnt<22>(); break;
+    case 12: wait_vmcnt<24>(); break;
+    default: wait_vmcnt<26>(); break;
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void gemm256_pipe(G256 p, int g_store_nt) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nt = p.K >> 6;
+  const int stride = gridDim.x;
+  const int nvirt = 8 * ((p.P + 7) / 8) * p.Y;
+
+  // tile list of this block: lin = blockIdx.x + i * gridDim.x, virtual tiles beyond the token range skipped
+  auto valid_from = [&](int lin) {
+    while (lin < nvirt && (lin & 7) + 8 * ((lin >> 3) / p.Y) >= p.P) lin += stride;
+    return lin;
+  };
+  auto tile_yi = [&](int lin) { return (lin >> 3) % p.Y; };
+  auto tile_pb = [&](int lin) { return (lin & 7) + 8 * ((lin >> 3) / p.Y); };
+
+  // ---- per-lane DMA source offsets WITHIN a tile (BYTES, 32 bit); the tile's base is a wave-uniform pointer, so the DMA
+  //      takes the scalar-base + 32-bit-offset form and an issue costs one VALU add per instruction ----
+  const int rsub = lane >> 3, pslot = lane & 7;
+  // instruction i and half h move a lane's row by 8 / by 64 (a) or 32 (b) rows -- the k-slot swizzle only looks at the low
+  // three row bits -- so ONE byte offset per operand is kept and the rest is a wave-uniform displacement of the base
+  const int brl0 = ((wave * 16) >> 5) * 64 + ((wave * 16) & 31) + rsub;   // tile-local token row of the b pieces' instruction 0 (h = 0)
+  unsigned aoff0, boff0;
+  {
+    const int lr = wave * 16 + rsub;
+    const int c = pslot ^ (lr & 7);
+    aoff0 = 2u * ((unsigned)((lr >> 6) * 128 + (lr & 63)) * (unsigned)p.K + c * 8);
+    boff0 = 2u * ((unsigned)brl0 * (unsigned)p.K + c * 8);
+  }
+  const unsigned rowb = 2u * (unsigned)p.K;                 // bytes per operand row
+  unsigned char* my = smem + wave * 2048;
+  float* bias_l = reinterpret_cast<float*>(smem + 2 * KTB + 8 * STG_WAVE);
+  unsigned char* stg = smem + 2 * KTB + wave * STG_WAVE;
+
+  // ---- issuing side: cursor over (tile, K tile, piece); piece order a0, b0, b1, a1 ----
+  int lin_i = valid_from(blockIdx.x);
+  int kt_i = 0, kg_i = 0;
+  const unsigned char* abase_i = reinterpret_cast<const unsigned char*>(p.a);
+  const unsigned char* bbase_i = reinterpret_cast<const unsigned char*>(p.b);
+  int pb_i = 0;
+  bool full_i = true;                                       // every token row of the issue tile exists (the usual case)
+  auto set_issue_tile = [&]() {
+    if (lin_i < nvirt) {
+      pb_i = tile_pb(lin_i);
+      full_i = pb_i * 256 + 256 <= p.M;
+      abase_i = reinterpret_cast<const unsigned char*>(p.a + (long)tile_yi(lin_i) * 256 * p.K);
+      bbase_i = reinterpret_cast<const unsigned char*>(p.b + (long)pb_i * 256 * p.K);
+    }
+  };
+  set_issue_tile();
+  // issues piece (region R of the cursor's K tile): two DMA instructions per wave; returns how many went out (0: no tile
+  // left).  The region of a phase is static -- phase ph issues region (ph + 1) & 3: b0, b1, a1, a0 of the NEXT K tile --
+  // so the cursor advances behind region 3 (a1).
+  auto issue_piece = [&](auto r_tag) -> int {
+    constexpr int R = decltype(r_tag)::value;
+    if (lin_i >= nvirt) return 0;
+    unsigned char* dst = my + (kg_i & 1) * KTB + R * PIECE;
+    const unsigned kob = (unsigned)kt_i * 128u;
+    if constexpr (R == R_A0 || R == R_A1) {
+      constexpr int h = R == R_A1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(abase_i + (size_t)(aoff0 + ((h * 64 + i * 8) * rowb + kob)), dst + i * 1024);
+    } else {
+      constexpr int h = R == R_B1;
+      if (full_i) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(bbase_i + (size_t)(boff0 + ((h * 32 + i * 8) * rowb + kob)), dst + i * 1024);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {           // ragged last token tile (rare): rows beyond M read the zero page
+          const bool ok = pb_i * 256 + brl0 + 8 * i + h * 32 < p.M;
+          const void* zsrc = reinterpret_cast<const h16_t*>(g256_zero_page) + (lane & 7) * 8;
+          glds16(ok ? reinterpret_cast<const void*>(bbase_i + (size_t)(boff0 + ((h * 32 + i * 8) * rowb + kob))) : zsrc,
+                 dst + i * 1024);
+        }
+      }
+    }
+    if constexpr (R == R_A1) {
+      ++kg_i;
+      if (++kt_i == nt) {
+        kt_i = 0;
+        lin_i = valid_from(lin_i + stride);
+        set_issue_tile();
+      }
+    }
+    return 2;
+  };
+  auto issue_bias = [&](int yi) -> int {          // the tile's 256 bias values (every wave loads a quarter; 4-7 repeat 0-3)
+    if (!p.bias) return 0;
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + yi * 256 + (wave & 3) * 64 + lane), (lptr_t)(bias_l + (wave & 3) * 64), 4,
+                                     0, 0);
+    return 1;
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = n & 7;
+  const int so0 = ((0 + g) ^ sw) * 16, so1 = ((4 + g) ^ sw) * 16;
+  const int a_row = (wr * 64 + n) * 128;
+  const int b_row = (wc * 32 + n) * 128;
+  h16x8 af[4][2], bfr[2][2];
+  auto load_a = [&](const unsigned char* piece) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *reinterpret_cast<const h16x8*>(piece + a_row + i * 2048 + so0);
+      af[i][1] = *reinterpret_cast<const h16x8*>(piece + a_row + i * 2048 + so1);
+    }
+  };
+  auto load_b = [&](const unsigned char* piece) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bfr[j][0] = *reinterpret_cast<const h16x8*>(piece + b_row + j * 2048 + so0);
+      bfr[j][1] = *reinterpret_cast<const h16x8*>(piece + b_row + j * 2048 + so1);
+    }
+  };
+
+  // ---- epilogue of one quadrant (QA, QB) of the tile (eyi, epb) ----
+  unsigned key = 0;
+  if (DROP) key = mix32((p.seed_dev ? *p.seed_dev : 0u) * 0x9E3779B1u + p.site * 0x85EBCA77u + 0x165667B1u);
+  const float lo = p.relu ? 0.f : -INFINITY;
+  const unsigned drop_lane = (unsigned)n * (unsigned)p.NO + (unsigned)(g * 4);     // the lane's part of the flat output index
+  // staging: row = token (n), 128 bytes = the quadrant's 64 channels; 16-byte chunk swizzle chunk ^= (row >> 1) & 7
+  const int st_w = n * 128 + g * 8;                         // + ((2 i + (g >> 1)) ^ (n >> 1)) ... written out below
+  const int rrow = lane >> 3, rcc = lane & 7;               // read-back: rows rrow, rrow + 8; chunk rcc
+  int eyi = 0, epb = 0;
+  // half J (N-tile 2 QB + J) of quadrant (QA, QB): bias, relu, dropout, pack -> 4 x 8 bytes per lane
+  auto pack_half = [&](auto qa_tag, auto qb_tag, auto j_tag, uint2 (&pk)[4]) {
+    constexpr int QA = decltype(qa_tag)::value, QB = decltype(qb_tag)::value, J = decltype(j_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + wr * 128 + (QA * 4 + i) * 16 + g * 4);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = fmaxf(acc[QA * 4 + i][QB * 2 + J][r] + bv[r], lo);
+        if (DROP) {
+          // flat output index of gemm256_nt's hash, 32 bit (the launcher sends M x NO >= 2^32 to the round-3 kernel)
+          const unsigned ubase = (unsigned)(epb * 256 + wc * 64 + (QB * 2 + J) * 16) * (unsigned)p.NO +
+                                 (unsigned)(eyi * 256 + wr * 128 + (QA * 4 + i) * 16 + r);
+          const unsigned hsh = mix32((ubase + drop_lane) ^ key);
+          v[r] = hsh >= p.thr ? v[r] * p.keep : 0.f;
+        }
+      }
+      pk[i] = make_uint2(f2h_pack(v[0], v[1]), f2h_pack(v[2], v[3]));
+    }
+  };
+  auto stage_write = [&](const uint2 (&pk)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = ((2 * i + (g >> 1)) ^ (n >> 1)) & 7;
+      *reinterpret_cast<uint2*>(stg + n * 128 + chunk * 16 + (g & 1) * 8) = pk[i];
+    }
+  };
+  struct Rd2 { uint4 a, b; };
+  const int rd_off0 = rrow * 128 + ((rcc ^ (rrow >> 1)) & 7) * 16;
+  const int rd_off1 = (rrow + 8) * 128 + ((rcc ^ ((rrow + 8) >> 1)) & 7) * 16;
+  auto stage_read = [&]() -> Rd2 {
+    Rd2 r;
+    r.a = *reinterpret_cast<const uint4*>(stg + rd_off0);
+    r.b = *reinterpret_cast<const uint4*>(stg + rd_off1);
+    return r;
+  };
+  // a lane's 16 bytes go to token row rrow (+ 8) of the half, chunk rcc: ONE 32-bit byte offset per lane, everything else
+  // (tile, wave, quadrant, half) is a wave-uniform displacement of the base -> scalar-base stores, no per-row 64-bit products
+  const unsigned st_lane = 2u * ((unsigned)rrow * (unsigned)p.NO + (unsigned)rcc * 8u);
+  auto store_half = [&](auto qa_tag, auto qb_tag, auto j_tag, const Rd2& rd) -> int {
+    constexpr int QA = decltype(qa_tag)::value, QB = decltype(qb_tag)::value, J = decltype(j_tag)::value;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int trow0 = epb * 256 + wc * 64 + (QB * 2 + J) * 16;                     // first token row of the half (uniform)
+    unsigned char* base = reinterpret_cast<unsigned char*>(p.out + (long)trow0 * p.NO + eyi * 256 + wr * 128 + QA * 64);
+    const u32x4 va = {rd.a.x, rd.a.y, rd.a.z, rd.a.w}, vb = {rd.b.x, rd.b.y, rd.b.z, rd.b.w};
+    u32x4* d0 = reinterpret_cast<u32x4*>(base + (size_t)st_lane);
+    u32x4* d1 = reinterpret_cast<u32x4*>(base + (size_t)(16u * (unsigned)p.NO) + (size_t)st_lane);
+    const bool ok0 = trow0 + 16 <= p.M || trow0 + rrow < p.M, ok1 = trow0 + 16 <= p.M || trow0 + rrow + 8 < p.M;
+    if (g_store_nt) {       // measurement switch (EVT_GEMM256_NT=1): streaming stores that do not allocate in the L2
+      if (ok0) __builtin_nontemporal_store(va, d0);
+      if (ok1) __builtin_nontemporal_store(vb, d1);
+    } else {
+      if (ok0) *d0 = va;
+      if (ok1) *d1 = vb;
+    }
+    return 2;
+  };
+  auto zero_quadrant = [&](auto qa_tag, auto qb_tag) {
+    constexpr int QA = decltype(qa_tag)::value, QB = decltype(qb_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[QA * 4 + i][QB * 2 + j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- queue model: VMEM instructions of the last four phases (1 = previous); c = all, post = those after the piece ----
+  int c1 = 2, c2 = 2, c3 = 2, post1 = 0, post2 = 0, post3 = 0, post4 = 0;
+
+  // ---- prologue: bias of the first tile, pieces 0 .. 4 (virtual phases -5 .. -1) ----
+  int lin_c = valid_from(blockIdx.x);
+  if (lin_c >= nvirt) return;
+  if (!p.bias && tid < 256) bias_l[tid] = 0.f;
+  issue_bias(tile_yi(lin_c));
+  using R0 = std::integral_constant<int, R_A0>;
+  using R1 = std::integral_constant<int, R_B0>;
+  using R2 = std::integral_constant<int, R_B1>;
+  using R3 = std::integral_constant<int, R_A1>;
+  issue_piece(R0{}); issue_piece(R1{}); issue_piece(R2{}); issue_piece(R3{}); issue_piece(R0{});
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+#define MMA_HALF(QA, QB, KS)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+      acc[QA * 4 + i][QB * 2 + j] = EVT_MFMA_16x16x32(af[i][KS], bfr[j][KS], acc[QA * 4 + i][QB * 2 + j], 0, 0, 0);
+
+  // one phase: READS = this phase's fragment reads, (QA, QB) = its MFMA quadrant, EP = an epilogue rides along:
+  // quadrant (EA, EB) of tile (eyi, epb); BIAS_YI >= 0: this phase also fetches the bias of the compute tile
+#define PHASE(READS, RISSUE, QA, QB, EP, EA, EB, BIAS_YI)                                                                    \
+  {                                                                                                                  \
+    wait_vmcnt_dyn(post4 + c3 + c2 + c1);                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    READS;                                                                                                           \
+    int pre_now = 0, post_now = 0;                                                                                   \
+    if ((BIAS_YI) >= 0) pre_now = issue_bias(BIAS_YI);                                                               \
+    const int dp_now = issue_piece(RISSUE{});                                                                               \
+    uint2 pk[4];                                                                                                     \
+    Rd2 rd;                                                                                                          \
+    if (EP) {                                                                                                        \
+      pack_half(I##EA{}, I##EB{}, I0{}, pk);                                                                         \
+      stage_write(pk);                                                                                               \
+      rd = stage_read();                                                                                             \
+    }                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    MMA_HALF(QA, QB, 0)                                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    if (EP) {                                                                                                        \
+      post_now += store_half(I##EA{}, I##EB{}, I0{}, rd);                                                            \
+      pack_half(I##EA{}, I##EB{}, I1{}, pk);                                                                         \
+      zero_quadrant(I##EA{}, I##EB{});                                                                               \
+      stage_write(pk);                                                                                               \
+      rd = stage_read();                                                                                             \
+    }                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    MMA_HALF(QA, QB, 1)                                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    if (EP) post_now += store_half(I##EA{}, I##EB{}, I1{}, rd);                                                      \
+    post4 = post3; post3 = post2; post2 = post1; post1 = post_now;                                                   \
+    c3 = c2; c2 = c1; c1 = pre_now + dp_now + post_now;                                                              \
+    asm volatile("" ::: "memory");                                                                                   \
+  }
+
+  // one K tile: EP0 = phase 0 carries quadrant (1,0) of the PREVIOUS tile and phase 1 fetches this tile's bias;
+  // EP123 = the last K tile: phases 1, 2, 3 carry quadrants (0,0), (0,1), (1,1) of this tile
+#define KTILE(EP0, EP123, YI)                                                                                        \
+  {                                                                                                                  \
+    const unsigned char* buf = smem + (kg_c & 1) * KTB;                                                              \
+    PHASE({ load_b(buf + R_B0 * PIECE); load_a(buf + R_A0 * PIECE); }, R1, 0, 0, EP0, 1, 0, -1)                          \
+    if (EP0) { eyi = tile_yi(lin_c); epb = tile_pb(lin_c); }                                                         \
+    PHASE(load_b(buf + R_B1 * PIECE), R2, 0, 1, EP123, 0, 0, (EP0) ? (YI) : -1)                                          \
+    PHASE(load_a(buf + R_A1 * PIECE), R3, 1, 1, EP123, 0, 1, -1)                                                         \
+    PHASE(load_b(buf + R_B0 * PIECE), R0, 1, 0, EP123, 1, 1, -1)                                                         \
+    ++kg_c;                                                                                                          \
+  }
+
+  int kg_c = 0;
+  bool has_prev = false;
+  eyi = tile_yi(lin_c);
+  epb = tile_pb(lin_c);
+  while (lin_c < nvirt) {
+    const int yi_c = tile_yi(lin_c);
+    if (has_prev) KTILE(1, 0, yi_c) else KTILE(0, 0, yi_c)
+    for (int kt = 1; kt < nt - 1; ++kt) KTILE(0, 0, yi_c)
+    KTILE(0, 1, yi_c)
+    has_prev = true;
+    lin_c = valid_from(lin_c + stride);
+  }
+#undef KTILE
+#undef PHASE
+#undef MMA_HALF
+  // ---- the last tile's quadrant (1,0): nothing left to multiply ----
+  {
+    uint2 pk[4];
+    pack_half(I1{}, I0{}, I0{}, pk);
+    stage_write(pk);
+    Rd2 rd = stage_read();
+    store_half(I1{}, I0{}, I0{}, rd);
+    pack_half(I1{}, I0{}, I1{}, pk);
+    stage_write(pk);
+    rd = stage_read();
+    store_half(I1{}, I0{}, I1{}, rd);
+  }
+}
+
 int g_variant = 0;     // measurement switch (evt_debug_gemm256_variant); 0 = the product kernel
 
 bool eligible(const evt_gemm_params* g, int kred, int nout) {
@@ -344,6 +689,26 @@ int launch(const evt_gemm_params* g, const void* a, const void* b, int kred, int
     if (ncu <= 0) ncu = 8;
   }
   const dim3 grid(nvirt < ncu ? nvirt : ncu);
+  // the pipelined kernel takes every launch without a gate / residual operand (EVT_GEMM256_PIPE=0: the round-3 kernel)
+  static const bool pipe_on = !(getenv("EVT_GEMM256_PIPE") && atoi(getenv("EVT_GEMM256_PIPE")) == 0);
+  // (one long-K tile per block -- [32768, 512, 2048]: 256 tiles, 32 K tiles each -- has no boundary to hide and runs 5 % faster
+  //  on the round-3 loop: 68 against 72 us)
+  static const int pipe_force = getenv("EVT_GEMM256_PIPE") ? atoi(getenv("EVT_GEMM256_PIPE")) : 1;
+  const bool pipe_shape = nvirt > (int)grid.x || (p.K >> 6) <= 12 || pipe_force == 2;
+  if (pipe_on && pipe_shape && g_variant == 0 && !p.gate && !p.add && (long)p.M * p.NO < (1L << 32)) {
+    evt_set_last_tag("gemm256_pipe<bf16, 256, 256, 64>");
+    static bool attr_p[2] = {false, false};
+    const int d = p.thr ? 1 : 0;
+    const void* fn = d ? reinterpret_cast<const void*>(&gemm256_pipe<true>) : reinterpret_cast<const void*>(&gemm256_pipe<false>);
+    if (!attr_p[d]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PIPE) != hipSuccess) return EVT_ELAUNCH;
+      attr_p[d] = true;
+    }
+    static const int nt_st = getenv("EVT_GEMM256_NT") ? atoi(getenv("EVT_GEMM256_NT")) : 0;
+    if (d) hipLaunchKernelGGL(gemm256_pipe<true>, grid, dim3(512), LDS_PIPE, st, p, nt_st);
+    else hipLaunchKernelGGL(gemm256_pipe<false>, grid, dim3(512), LDS_PIPE, st, p, nt_st);
+    return evt_check_launch();
+  }
   evt_set_last_tag("gemm256_nt<bf16, 256, 256, 64>");
 #define G256_LAUNCH(V)                                                                                                  \
   {                                                                                                                     \
