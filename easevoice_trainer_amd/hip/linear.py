@@ -86,6 +86,22 @@ class LinearBank:
         self._items = self._rows = None
         self._stamp = None
         self.dirty = True
+        # weight-gradient side stream (round 6): the dW launches of the dense layers produce parameter gradients only --
+        # nothing on the backward's critical path reads them -- so an engine may let them run next to the chain of
+        # backward-data GEMMs / attention / LayerNorm launches: their tails (a partial second round of blocks, the
+        # memory-side atomics of the split-K epilogue) fill with the next kernel's blocks.  Off until an engine turns it on.
+        self.side = None
+        self._side_used = False
+
+    def enable_side_stream(self):
+        if self.device.type == "cuda" and self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+
+    def join_side(self):
+        """the caller's stream waits for the weight-gradient launches handed to the side stream since the last join"""
+        if self.side is not None and self._side_used:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._side_used = False
 
     def _tables(self):
         items, rows = [], []
@@ -202,6 +218,18 @@ def gemm_bwd_weight(slot, x, dy, want_bias=True):
     else:
         dw_buf = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
         db_buf = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device) if want_b else None
+    bank = slot.bank
+    if sunk and bank.side is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        # straight into the arena, on the side stream: ordered behind what the current stream has enqueued (x, dy exist),
+        # the operands kept alive for the allocator until the launch has run; S1Engine joins before it reads the arena
+        bank.side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(bank.side):
+            L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
+                                                     L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
+        x.record_stream(bank.side)
+        dy.record_stream(bank.side)
+        bank._side_used = True
+        return None, None
     L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
                                              L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
     if sunk:

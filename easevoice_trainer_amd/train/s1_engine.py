@@ -36,6 +36,8 @@ class S1Engine:
         pad_rows = (w.size(0) + N_ALIGN - 1) // N_ALIGN * N_ALIGN
         self.arena = ParamArena(self.model, self.device, reserve={"ar_predict_layer.weight": pad_rows * w.size(1)})
         self.bank = self.model.attach_bank(dtype, self.device)
+        if os.environ.get("EVT_S1_WGRAD_SIDE", "1") != "0":       # the dense layers' dW launches next to the backward chain
+            self.bank.enable_side_stream()
         o = config["optimizer"]
         self.optimizer = ScaledAdam(self.arena, lr=0.01, betas=(0.9, 0.95), clipping_scale=2.0,
                                     clipping_update_period=1000)
@@ -88,6 +90,7 @@ class S1Engine:
             self.scaler.scale(loss).backward()
         finally:
             self.model.h.grad_hook = None
+        self.bank.join_side()          # the weight gradients of the dense layers are in the arena from here on
         hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
         self._gather(0, hi)
         for p, v in self._views:
@@ -136,6 +139,7 @@ class S1Engine:
         hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
         if lo >= hi:
             return
+        self.bank.join_side()          # the dense layers' dW launches of blocks > `block` run on the side stream
         self._gather(lo, hi)
         self.reducer.all_reduce(self.arena.grad[lo:hi], async_op=self.arena.grad.is_cuda, average=True)
         self._reduced_from = lo
