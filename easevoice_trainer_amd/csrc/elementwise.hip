@@ -74,6 +74,151 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const evt_wprep_item* item
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// wn_fold8_kernel (round 6): the same fold, EIGHT consecutive output rows per block, both images leaving in 16-byte pieces.
+//
+// What bounds wn_fold_kernel (0.34 ms per model and launch at 1.16 TB/s, 0.145 of the HBM rate): the ALT image is indexed
+// [d1][chunk(d0)][tap][d0 % ck], so the elements of ONE source row land 2 bytes at a time in n different 64-byte runs --
+// every wave store touches 64 lines, and a run is completed by 32 different blocks; the REG image [d0][chunk(d1)][tap]
+// [d1 % ck] is a permutation of the row, stored as 2-byte pieces 64 bytes apart.  The pass is bound by the number of L2
+// write requests, not by bytes.  With the rows d0 .. d0 + 7 of one layer in a block (same ALT chunk, consecutive d0 % ck):
+//   * the eight values of a (d1, tap) pair are ONE 16-byte ALT piece  -> 8 x fewer ALT requests;
+//   * REG: the row's elements of a segment of d1 columns are permuted in LDS and leave as contiguous 16-byte pieces.
+// The round-5 attempt at this (32 rows per block, wave-private transposes, 375 fat blocks) was 3.3 x slower: too few blocks.
+// Here a block is 8 rows (1.5 K blocks per model), a segment is 64 columns (a few KB of LDS: many blocks per CU).
+// Bit-identical images: the norm of a row is accumulated in wn_fold_kernel's order (thread-strided partial sums,
+// block_reduce_sum_256), the scaled value is the same product, the rounding the same f2h.
+// Groups the fast path does not take (fewer than 8 rows, fp32 images, rows not 16-byte aligned, an image missing) run the
+// per-row body on each of their rows.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int F8_ROW = 1536;            // staged source elements per row and segment: 8 rows x 1536 x 2 B = 24 KiB per block (48 KiB: 152 us, 24 KiB: 142 us)
+constexpr int F8_KMAX = 16;             // taps (incl. padding) of the fast path
+
+__device__ __forceinline__ void wn_fold_row(const evt_wprep_item& it, int d0, float* red) {
+  const evt_wlayout& L = it.lay;
+  const int n = (it.src_d1 ? it.src_d1 : L.d1) * L.k;
+  const float* v = it.v + (long)d0 * n;
+  float scale = 1.f;
+  if (it.g) {
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) ss += v[e] * v[e];
+    ss = block_reduce_sum_256(ss, red);
+    scale = it.g[d0] / sqrtf(ss);
+  }
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int d1 = e / L.k, kk = e - d1 * L.k;
+    const float w = v[e] * scale;
+    if (it.reg) store_w(it.reg, reg_idx(L, d0, d1, kk), w, it.dtype);
+    if (it.alt) store_w(it.alt, alt_idx(L, d0, d1, kk), w, it.dtype);
+  }
+}
+
+// block -> group: consecutive blockIdx values go round-robin over the 8 XCDs; the four groups that complete a 64-byte ALT
+// run (32 rows) are handed to ONE XCD so that the run leaves its L2 as a whole line
+__device__ __forceinline__ int fold_group_of_block(int b, int ngroups) {
+  const int xcd = b & 7, slot = b >> 3;
+  const int grp = ((slot >> 2) * 8 + xcd) * 4 + (slot & 3);
+  return grp < ngroups ? grp : -1;
+}
+
+__global__ __launch_bounds__(256) void wn_fold8_kernel(const evt_wprep_item* items, const int32_t* groups, int ngroups) {
+  __shared__ float red[4];
+  __shared__ float red8[8][4];
+  __shared__ float scale_s[8];
+  // the segment's scaled 16-bit values in SOURCE order, [row][column * k + tap]: written 8 bytes per lane, both images
+  // are gathered from it (2-byte LDS reads are cheap; 2-byte LDS WRITES 64 bytes apart were a 32-way bank conflict)
+  __shared__ __attribute__((aligned(16))) h16_t src_s[8][F8_ROW];
+  const int grp = fold_group_of_block(blockIdx.x, ngroups);
+  if (grp < 0) return;
+  const evt_wprep_item it = items[groups[3 * grp]];
+  const int d0 = groups[3 * grp + 1], nr = groups[3 * grp + 2];
+  const evt_wlayout& L = it.lay;
+  const int d1n = it.src_d1 ? it.src_d1 : L.d1;
+  const int n = d1n * L.k;
+  const bool fast = nr == 8 && it.dtype == EVT_DT_HALF && it.reg && it.alt && (d0 & 7) == 0 && (L.alt_ck & 7) == 0 &&
+                    (n & 3) == 0 && L.reg_kp <= F8_KMAX && L.k <= F8_KMAX && L.reg_ck * L.k <= F8_ROW &&
+                    (L.reg_ck & 7) == 0 && (L.d1 % L.reg_ck) == 0 && ((L.reg_ck * L.k) & 3) == 0;
+  if (!fast) {
+    for (int r = 0; r < nr; ++r) {
+      wn_fold_row(it, d0 + r, red);
+      __syncthreads();
+    }
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // ---- norms of the eight rows, each in wn_fold_kernel's summation order (thread-strided partial sums, wave tree, then
+  //      the four wave sums left to right), the eight rows' loads interleaved ----
+  if (it.g) {
+    float ss[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ss[r] = 0.f;
+    const float* v0 = it.v + (long)d0 * n;
+    for (int e = tid; e < n; e += 256) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const float x = v0[(long)r * n + e]; ss[r] += x * x; }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float w = wave_reduce_sum(ss[r]);
+      if (lane == 0) red8[r][wv] = w;
+    }
+    __syncthreads();
+    if (tid < 8) scale_s[tid] = it.g[d0 + tid] / sqrtf(red8[tid][0] + red8[tid][1] + red8[tid][2] + red8[tid][3]);
+  } else if (tid < 8) {
+    scale_s[tid] = 1.f;
+  }
+  __syncthreads();
+  const int k = L.k, kp = L.reg_kp, ck = L.reg_ck;
+  h16_t* regp = reinterpret_cast<h16_t*>(it.reg);
+  h16_t* altp = reinterpret_cast<h16_t*>(it.alt);
+  const long reg_row = (long)L.reg_nchunk * kp * ck;                       // elements per REG row
+  // columns per segment: as many whole REG chunks as the staging holds (k = 5: 288 columns, k = 11: 128, k = 1: 1536)
+  const int seg_max = (F8_ROW / (ck * k)) * ck;
+  for (int c0 = 0; c0 < L.d1; c0 += seg_max) {                             // (L.d1 >= d1n: padded columns stay zero)
+    const int seg = min(seg_max, L.d1 - c0);                               // a multiple of reg_ck
+    const int src_cols = max(0, min(seg, d1n - c0));                       // columns of this segment the parameter has
+    const int segk = src_cols * k;                                         // source elements per row (a multiple of 4)
+    // ---- source -> LDS: 4 consecutive elements of one row per lane, scaled and rounded ----
+    const int f4_per_row = segk >> 2;
+    for (int q = tid; q < 8 * f4_per_row; q += 256) {
+      const int r = q / f4_per_row, f = q - r * f4_per_row;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(it.v + (long)(d0 + r) * n + (long)c0 * k + 4 * f);
+      const float sc = scale_s[r];
+      h16_t w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = f2h(x[u] * sc);
+      *reinterpret_cast<uint2*>(&src_s[r][4 * f]) = *reinterpret_cast<uint2*>(w);
+    }
+    __syncthreads();
+    // ---- REG: row r's segment is the contiguous range [chunk0 * kp * ck, + seg * kp) of its image row; a 16-byte piece
+    //      = 8 consecutive columns of one (chunk, tap).  Padding taps / columns are written as zeros. ----
+    {
+      const int pieces = seg * kp / 8;
+      const int ck8 = ck >> 3;
+      for (int q = tid; q < 8 * pieces; q += 256) {
+        const int r = q / pieces, pc = q - r * pieces;
+        const int cc8 = pc % ck8, t2 = pc / ck8;
+        const int kk = t2 % kp, chl = t2 / kp;
+        const int dl0 = chl * ck + cc8 * 8;                                 // first of the piece's 8 columns
+        h16_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (kk < k && dl0 + j < src_cols) ? src_s[r][(dl0 + j) * k + kk] : (h16_t)0;
+        *reinterpret_cast<uint4*>(regp + (long)(d0 + r) * reg_row + (long)(c0 / ck) * kp * ck + pc * 8) =
+            *reinterpret_cast<uint4*>(w);
+      }
+    }
+    // ---- ALT: one 16-byte piece per (column, tap): rows d0 .. d0 + 7 are consecutive d0 % alt_ck ----
+    for (int q = tid; q < segk; q += 256) {
+      const int dl = q / k, kk = q - dl * k;
+      h16_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = src_s[j][q];
+      *reinterpret_cast<uint4*>(altp + alt_idx(L, d0, c0 + dl, kk)) = *reinterpret_cast<uint4*>(w);
+    }
+    __syncthreads();
+  }
+}
+
 // A deterministic split-K weight gradient (evt_conv1d_bwd_weight_parts) leaves its partial sums in slabs: slab 0 is the
 // image itself, slabs 1 .. n-1 are `stride` floats apart in `extra`.  This folds one d0-row of them into slab 0, in
 // index order, in place (the row belongs to this block alone).  Image order, 16 bytes per lane, eight slabs requested
@@ -486,6 +631,13 @@ int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int
   if (!items || !row_index || nrows <= 0) return EVT_EINVAL;
   const int nblocks = ((nrows + 255) / 256) * 256;        // whole 8 x 32 row groups (fold_row_of_block)
   hipLaunchKernelGGL(wn_fold_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, items, row_index, nrows);
+  return evt_check_launch();
+}
+
+int evt_wn_fold_groups(const evt_wprep_item* items, const int32_t* group_index, int32_t ngroups, void* stream) {
+  if (!items || !group_index || ngroups <= 0) return EVT_EINVAL;
+  const int nblocks = ((ngroups + 31) / 32) * 32;         // whole 8 x 4 group runs (fold_group_of_block)
+  hipLaunchKernelGGL(wn_fold8_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, items, group_index, ngroups);
   return evt_check_launch();
 }
 

@@ -254,8 +254,9 @@ class WeightBank:
     def build_tables(self):
         """(Re)build the device descriptor tables.  Must be called after parameters (and their .grad
         buffers) have reached their final storage (ParamArena.flatten)."""
-        items, rows = [], []
+        items, rows, groups = [], [], []
         self._slot_rows = []
+        self._group_of_row = {}       # first table row of a slot -> first group of that slot (and the end sentinel)
         for i, s in enumerate(self.slots):
             m = s.module
             self._slot_rows.append((len(rows), len(rows) + s.layout.d0))
@@ -286,9 +287,14 @@ class WeightBank:
                         bias.grad = torch.zeros_like(bias)
                     it.db_part, it.db = s.db_part.data_ptr(), bias.grad.data_ptr()
             items.append(it)
+            self._group_of_row[len(rows)] = len(groups)
             rows.extend((i, r) for r in range(s.layout.d0))
+            # the fold walks groups of eight consecutive rows (evt_wn_fold_groups): both images leave as 16-byte pieces
+            groups.extend((i, r, min(8, s.layout.d0 - r)) for r in range(0, s.layout.d0, 8))
+        self._group_of_row[len(rows)] = len(groups)
         self._items = L.struct_to_device(items, self.device)
         self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
+        self._groups = torch.tensor(groups, dtype=torch.int32, device=self.device).contiguous()
         self._nrows = len(rows)
         self._grad_stamp = self._grad_ptrs()
 
@@ -312,8 +318,14 @@ class WeightBank:
         hi = self._nrows if hi is None else hi
         if hi <= lo:
             return
-        rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
-        L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_fold_multi")
+        glo, ghi = self._group_of_row.get(lo), self._group_of_row.get(hi)
+        if glo is not None and ghi is not None and os.environ.get("EVT_FOLD_GROUPS", "1") != "0":
+            # row ranges start and end at layer boundaries (rows_of): the same rows as groups of eight
+            grp = C.c_void_p(self._groups.data_ptr() + 12 * glo)    # (item, first row, rows) int32 triples
+            L.check(L.lib().evt_wn_fold_groups(L.ptr(self._items), grp, ghi - glo, L.stream_ptr()), "evt_wn_fold_groups")
+        else:
+            rows = C.c_void_p(self._rows.data_ptr() + 8 * lo)       # (item, row) int32 pairs
+            L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), rows, hi - lo, L.stream_ptr()), "evt_wn_fold_multi")
         self._repack_frags(lo, hi)
 
     def frag(self, slot, which):

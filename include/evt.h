@@ -148,6 +148,10 @@ typedef struct evt_wprep_item {
 /* items is a DEVICE pointer to n items; row_index is a DEVICE int32 [nrows][2] table of
  * (item, d0-row) pairs, one workgroup each. */
 int evt_wn_fold_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream);
+/* The same fold over GROUPS of up to eight consecutive d0-rows of one item: group_index is a DEVICE int32 [ngroups][3] table
+ * of (item, first d0-row, rows in the group <= 8), one workgroup each.  A full group of a 16-bit image pair leaves as
+ * 16-byte pieces (csrc/elementwise.hip: wn_fold8_kernel); the images are bit-identical to evt_wn_fold_multi's. */
+int evt_wn_fold_groups(const evt_wprep_item* items, const int32_t* group_index, int32_t ngroups, void* stream);
 int evt_wn_grad_multi(const evt_wprep_item* items, const int32_t* row_index, int32_t nrows, void* stream);
 
 /* y[nseq][lout][cout] = act_out(conv(lrelu(x)) + bias) + res ; bias/res may be NULL.

@@ -65,3 +65,58 @@ def test_extra_slabs_start_as_zeros(gpu):
     HC, m, bank = _bank(gpu)
     assert bank.dw_extra_arena is not None and float(bank.dw_extra_arena.abs().max()) == 0.0
     assert float(bank.db_part_arena.abs().max()) == 0.0
+
+
+FOLD_CASES = [  # cin, cout, k, stride, groups, transposed, weight_norm
+    (64, 64, 3, 1, 1, False, True), (1024, 1024, 5, 1, 1, False, True), (128, 512, 5, 3, 1, False, True),
+    (192, 384, 5, 1, 1, False, True), (256, 128, 16, 8, 1, True, True), (16, 16, 11, 1, 1, False, True),
+    (64, 256, 41, 4, 16, False, True), (192, 1, 7, 1, 1, False, False), (1, 16, 15, 1, 1, False, True),
+    (96, 192, 1, 1, 1, False, False), (100, 72, 3, 1, 1, False, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_grouped_fold_writes_the_same_images(gpu, dtype, monkeypatch):
+    """evt_wn_fold_groups (eight rows per block, 16-byte pieces) against evt_wn_fold_multi (a row per block) on one bank of
+    layers of every geometry the models use -- stride 1 / polyphase ALT, ConvTranspose, grouped, 1-row and 1-column layers,
+    widths that are not multiples of 8 / 32, with and without weight norm: REG and ALT images BIT-identical, padding
+    included (the grouped kernel's norm is accumulated in the row kernel's order)"""
+    from easevoice_trainer_amd.hip import conv as HC
+
+    torch.manual_seed(11)
+    mods = []
+    for cin, cout, k, stride, groups, transposed, wn in FOLD_CASES:
+        pad = (k - stride) // 2 if transposed else k // 2
+        mods.append(HC.EvtConv1d(cin, cout, k, stride=stride, padding=pad, groups=groups, transposed=transposed,
+                                 weight_norm=wn))
+    m = torch.nn.ModuleList(mods).to(gpu)
+    bank = HC.WeightBank(m, dtype, gpu)
+    bank.build_tables()
+    monkeypatch.setenv("EVT_FOLD_GROUPS", "0")
+    bank.reg_arena.fill_(7.0); bank.alt_arena.fill_(7.0)         # padding the kernels do not write stays 7 in both runs
+    bank.fold()
+    torch.cuda.synchronize()
+    reg0, alt0 = bank.reg_arena.clone(), bank.alt_arena.clone()
+    monkeypatch.setenv("EVT_FOLD_GROUPS", "1")
+    bank.reg_arena.fill_(7.0); bank.alt_arena.fill_(7.0)
+    bank.fold()
+    torch.cuda.synchronize()
+    # the grouped kernel also writes the zero padding of the segments it stages (taps beyond k, columns beyond the
+    # parameter's): where the row kernel left the fill value, the image is never read -- compare what the row kernel wrote
+    wrote = reg0 != 7.0
+    assert torch.equal(bank.reg_arena[wrote], reg0[wrote])
+    pad = bank.reg_arena[~wrote]
+    assert bool(((pad == 0) | (pad == 7.0)).all())
+    assert torch.equal(bank.alt_arena, alt0)
+    # and a slot-aligned sub-range takes the grouped path too
+    lo, hi = bank.rows_of([m[1], m[2]])
+    bank.reg_arena.fill_(7.0); bank.alt_arena.fill_(7.0)
+    bank.fold(lo, hi)
+    torch.cuda.synchronize()
+    s1, s2 = bank.slots[1], bank.slots[2]
+    for s in (s1, s2):
+        ro = s.reg.data_ptr() - bank.reg_arena.data_ptr()
+        ro //= bank.reg_arena.element_size()
+        w = wrote[ro: ro + s.layout.reg_elems]
+        assert torch.equal(s.reg[w], reg0[ro: ro + s.layout.reg_elems][w])
+    assert float(bank.slots[0].reg.float().min()) == 7.0          # other layers untouched
