@@ -104,7 +104,7 @@ class LinearBank:
             self._side_used = False
 
     def _tables(self):
-        items, rows = [], []
+        items, rows, groups = [], [], []
         for i, s in enumerate(self.slots):
             it = L.WPrepItem()
             it.v, it.g = s.weight.data_ptr(), None
@@ -113,6 +113,9 @@ class LinearBank:
             it.lay, it.dtype = s.layout, self.dt
             items.append(it)
             rows.extend((i, r) for r in range(s.layout.d0))
+            groups.extend((i, r, min(8, s.layout.d0 - r)) for r in range(0, s.layout.d0, 8))
+        self._groups = torch.tensor(groups, dtype=torch.int32, device=self.device).contiguous()
+        self._ngroups = len(groups)
         self._items = L.struct_to_device(items, self.device)
         self._rows = torch.tensor(rows, dtype=torch.int32, device=self.device).contiguous()
         self._nrows = len(rows)
@@ -130,8 +133,9 @@ class LinearBank:
             self._tables()
             force = True
         if force or self.dirty or stamp != self._stamp:
-            L.check(L.lib().evt_wn_fold_multi(L.ptr(self._items), L.ptr(self._rows), self._nrows, L.stream_ptr()),
-                    "evt_wn_fold_multi")
+            # groups of eight rows: both images leave as 16-byte pieces (csrc/elementwise.hip: wn_fold8_kernel)
+            L.check(L.lib().evt_wn_fold_groups(L.ptr(self._items), L.ptr(self._groups), self._ngroups, L.stream_ptr()),
+                    "evt_wn_fold_groups")
             self._stamp, self.dirty = stamp, False
 
 

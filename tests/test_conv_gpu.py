@@ -158,6 +158,7 @@ DEEP_CASES = [
     (128, 512, 5, 3, 2, 1, 1, False, True, 207, 130),
     (256, 256, 7, 1, 9, 3, 1, False, True, 700, 20),      # dilated, long sequences
     (32, 128, 5, 3, 2, 1, 1, False, True, 1200, 64),      # K side of 32 channels -> 32-channel stages
+    (1024, 1024, 5, 1, 2, 1, 1, False, True, 127, 40),    # 5080 positions: enough 128 x 128 tiles to fill the chip
 ]
 
 
