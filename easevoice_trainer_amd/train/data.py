@@ -111,7 +111,16 @@ def open_source(kind, train_input_dir, device, synthetic_factory, batch_size=Non
             # core_vq.py:311-316); (3) the two random draws are per frame, so a seeded run with padding draws different noise
             # for the SAME frames than an unpadded one -- equal in distribution, not bit for bit.
             pad = int(os.environ.get("EVT_PAD_FRAMES", "16")) if str(device).startswith("cuda") else None
-            return S2Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world, pad_frames=pad)
+            # reader processes, as the reference's DataLoader(num_workers=6, persistent_workers=True, prefetch_factor=4)
+            # (sovits.py:258-267): on a GPU the one-thread reader was what set the real-data rate (profiles/
+            # r06_reader_processes.txt: 1591 -> 2848 audio-s/s over 400 steps, 1825 -> 3563 once the shapes are captured).
+            # EVT_READER_WORKERS overrides (0 = the prefetch thread); CPU runs keep the thread.
+            workers = None
+            if str(device).startswith("cuda") and "EVT_READER_WORKERS" not in os.environ:
+                ncpu = os.cpu_count() or 1
+                workers = 6 if ncpu >= 12 else max(0, min(4, ncpu // 2))
+            return S2Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world, pad_frames=pad,
+                            loader_workers=workers)
         return S1Reader(train_input_dir, cfg, batch_size, device, rank=rank, world=world)
     raise FileNotFoundError(
         f"no training input under {train_input_dir!r}: expected the reference's feature directory ({marker}), a tensor "

@@ -254,7 +254,7 @@ def _round_up(n, k):
     return -(-n // k) * k
 
 
-def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=True):
+def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=True, alloc=None):
     """TextAudioSpeakerCollate (data_utils.py:167-226) for items (ssl, wav, text, frames, ...): rows sorted by spectrogram
     length, longest first; ssl and spec time axes padded to 2*(max//2+1); everything else to the batch maximum.
     Returns the reference's 8-tuple with `spec_padded` zero-filled plus `order` (source index of each row): the caller
@@ -263,7 +263,9 @@ def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=Tru
     every consumer masks by the lengths, so the step's result does not change, but the batches of a run then repeat a
     few dozen shapes instead of several hundred -- what the trainer's per-shape HIP-graph replay needs.
     with_spec=False leaves `spec_padded` out (None; its shape is returned as the third element instead): the reader
-    creates it on the device, there is nothing in it to copy from the host."""
+    creates it on the device, there is nothing in it to copy from the host.
+    alloc(shape, dtype) -> zero-filled tensor: where the four padded tensors live (a reader process puts them into its
+    shared-memory slot); default: fresh (optionally pinned) tensors."""
     n = len(items)
     _, order = torch.sort(torch.tensor([it[3] for it in items], dtype=torch.long), dim=0, descending=True)
     order = order.tolist()
@@ -276,6 +278,8 @@ def collate_s2(items, spec_bins, pin=False, pad_frames=0, hop=640, with_spec=Tru
     max_text = max(it[2].size(0) for it in items)
 
     def buf(shape, dtype):
+        if alloc is not None:
+            return alloc(shape, dtype)
         return torch.zeros(shape, dtype=dtype, pin_memory=pin)
 
     def buffer_dtype(k):
@@ -342,11 +346,186 @@ class _Prefetch:
                     self.t.join(0.01)
 
 
+class _SlotAlloc:
+    """carves zero-filled tensors out of one flat uint8 buffer (a reader process's shared-memory slot), 64-byte aligned;
+    remembers (offset, shape, dtype) of each so that the parent can rebuild the views"""
+
+    def __init__(self, slab):
+        self.slab, self.off, self.metas = slab, 0, []
+
+    def __call__(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        off = (self.off + 63) // 64 * 64
+        if off + nbytes > self.slab.numel():
+            raise RuntimeError(f"reader slot of {self.slab.numel()} bytes is too small for a batch tensor {tuple(shape)} {dtype}")
+        t = self.slab[off: off + nbytes].view(dtype).view(*shape)
+        t.zero_()
+        self.off = off + nbytes
+        self.metas.append((off, tuple(int(d) for d in shape), dtype))
+        return t
+
+
+def _slot_views(slab, metas):
+    out = []
+    for off, shape, dtype in metas:
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        out.append(slab[off: off + nbytes].view(dtype).view(*shape))
+    return out
+
+
+def _s2_worker(exp_dir, data_cfg, symbol_to_id, spec_bins, pad_frames, hop, slabs, task_q, out_q):
+    """body of one reader process (S2Reader(loader_workers=N)): read + collate the batches whose (sequence number, slot,
+    item indices) arrive on task_q STRAIGHT INTO the shared-memory slot the parent named -- file dtypes: int16 samples,
+    fp16 features -- and answer with the layout only (offsets, shapes, lengths): no tensor crosses the queue (torch's
+    shared-memory pickler took 30-170 ms per 13 MB batch for its per-tensor shm files; the slots are made once).  Never
+    touches a GPU: this is the role of the reference's DataLoader workers (src/train/sovits.py:258-267: num_workers=6,
+    persistent, prefetch_factor=4)."""
+    torch.set_num_threads(1)
+    try:
+        ds = S2FeatureDir(exp_dir, data_cfg, symbol_to_id=symbol_to_id)
+        while True:
+            task = task_q.get()
+            if task is None:
+                return
+            seq, slot, indices = task
+            items = [ds.load(i, raw=True) for i in indices]
+            al = _SlotAlloc(slabs[slot])
+            batch, order = collate_s2(items, spec_bins, pad_frames=pad_frames, hop=hop, with_spec=False, alloc=al)
+            ssl_p, ssl_l, spec_shape, spec_l, wav_p, wav_l, text_p, text_l = batch
+            out_q.put((seq, slot, al.metas, ssl_l.tolist(), tuple(spec_shape), spec_l.tolist(), wav_l.tolist(),
+                       text_l.tolist(), [bool(items[src][4]) for src in order], None))
+    except BaseException as e:  # noqa: BLE001 -- surfaced on the consumer side
+        out_q.put((-1, -1, None, None, None, None, None, None, None, f"{e!r}\n{traceback.format_exc()}"))
+
+
+class _ProcPrefetch:
+    """read + collate on worker PROCESSES (one GIL each), batches delivered in sampler order; at most `depth` batches are
+    in flight, each in its own shared-memory slot (page-locked in the parent when the consumer is a GPU: the copy to the
+    device is then asynchronous straight from the slot).  The workers are started once per reader and stay
+    (persistent_workers=True there)."""
+
+    def __init__(self, reader, workers, depth):
+        import multiprocessing as mp
+
+        ds = reader.ds
+        self.depth = max(depth, workers)
+        # the largest batch the sampler can form: batch_size items of the longest clip (+ the pad_frames rounding)
+        frames = int(max(ds.lengths)) + 2 + max(reader.pad_frames, 0)
+        bsz = reader.sampler.batch_size
+        text_max = max((len(ids) for _name, ids in ds.items), default=1)
+        slot_bytes = bsz * (768 * frames * 4 + (frames + 4) * ds.hop_length * 4 + text_max * 8) + 4096
+        self.slabs = [torch.zeros(slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(self.depth)]
+        self.pinned = False
+        if reader.device.type == "cuda":
+            try:       # page-lock the slots once: non_blocking copies from their views are then truly asynchronous
+                rt = torch.cuda.cudart()
+                for sl in self.slabs:
+                    rt.cudaHostRegister(sl.data_ptr(), sl.numel(), 0)
+                self.pinned = True
+            except Exception:  # noqa: BLE001 -- unpinned slots still work (the copy is then staged by the runtime)
+                self.pinned = False
+        ctx = mp.get_context("spawn")          # the parent has a HIP context: never fork it
+        self.task_q, self.out_q = ctx.Queue(), ctx.Queue()
+        args = (reader._exp_dir, reader._data_cfg, reader._symbol_to_id, reader.spec_bins, reader.pad_frames, ds.hop_length,
+                self.slabs, self.task_q, self.out_q)
+        self.procs = [ctx.Process(target=_s2_worker, args=args, daemon=True) for _ in range(workers)]
+        for p in self.procs:
+            p.start()
+        self.free = list(range(self.depth))
+
+    def run(self, keys, release):
+        """generator over (batch, ok, slot) of `keys` (lists of item indices), in order.  `release` = list the consumer
+        appends a slot to once nothing reads it any more (after its device copies have completed)."""
+        keys = iter(keys)
+        sent = got = 0
+        held, done = {}, False
+
+        def feed():
+            nonlocal sent, done
+            while release:
+                self.free.append(release.pop())
+            while not done and self.free:
+                try:
+                    k = next(keys)
+                except StopIteration:
+                    done = True
+                    return
+                self.task_q.put((sent, self.free.pop(), list(k)))
+                sent += 1
+
+        try:
+            feed()
+            while got < sent:
+                while got not in held:
+                    msg = self.out_q.get()
+                    if msg[-1] is not None:
+                        raise RuntimeError(f"s2 reader worker failed: {msg[-1]}")
+                    held[msg[0]] = msg
+                _seq, slot, metas, ssl_l, spec_shape, spec_l, wav_l, text_l, ok, _err = held.pop(got)
+                got += 1
+                ssl_p, wav_p, text_p = _slot_views(self.slabs[slot], metas)
+                lt = lambda v: torch.tensor(v, dtype=torch.long)
+                yield (ssl_p, lt(ssl_l), spec_shape, lt(spec_l), wav_p, lt(wav_l), text_p, lt(text_l)), ok, slot
+                if isinstance(release, _AutoRelease):
+                    release.append(slot)      # the consumer came back for the next batch: it is done with this one
+                feed()
+        finally:
+            # an epoch left early: collect what the workers still produce for it (nothing may leak into the next epoch)
+            while got < sent:
+                try:
+                    msg = self.out_q.get(timeout=30)
+                except Exception:  # noqa: BLE001
+                    break
+                if msg[1] >= 0:
+                    self.free.append(msg[1])
+                got += 1
+            for seq, msg in held.items():
+                self.free.append(msg[1])
+
+    def close(self):
+        for _ in self.procs:
+            self.task_q.put(None)
+        for p in self.procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()          # by handle: our own children only
+        self.procs = []
+        if self.pinned:
+            try:
+                rt = torch.cuda.cudart()
+                for sl in self.slabs:
+                    rt.cudaHostUnregister(sl.data_ptr())
+            except Exception:  # noqa: BLE001
+                pass
+            self.pinned = False
+
+
+class _AutoRelease(list):
+    """release list of a consumer that is done with a slot as soon as it asks for the next batch (host-only consumers:
+    tools/bench_reader.py): run() hands the slot out, the consumer never appends -- so every slot handed out is recycled
+    on the next feed"""
+
+    def __init__(self):
+        super().__init__()
+        self.last = None
+
+
 class S2Reader:
     """Iterable of device batches with the layout of the reference's s2 DataLoader (src/train/sovits.py:229-267)."""
 
     def __init__(self, exp_dir, data_cfg, batch_size, device, rank=0, world=1, boundaries=None, prefetch=4,
-                 symbol_to_id=None, spec_fn=None, pad_frames=None, loader_threads=1):
+                 symbol_to_id=None, spec_fn=None, pad_frames=None, loader_threads=1, loader_workers=None):
+        """loader_workers (default: EVT_READER_WORKERS, else 0): that many reader PROCESSES read and collate the batches
+        (the reference's DataLoader(num_workers=6, persistent_workers=True, prefetch_factor=4), sovits.py:258-267); 0 keeps
+        the one prefetch thread.  The batches are the same either way (same sampler order, same collate); the GPU side --
+        copy, dtype conversion, spectrogram -- is unchanged."""
+        self._exp_dir, self._data_cfg, self._symbol_to_id = exp_dir, dict(data_cfg), symbol_to_id
         self.ds = S2FeatureDir(exp_dir, data_cfg, symbol_to_id=symbol_to_id)
         self.sampler = S2BucketSampler(self.ds.lengths, batch_size, boundaries, num_replicas=world, rank=rank)
         self.device, self.prefetch = torch.device(device), prefetch
@@ -362,6 +541,28 @@ class S2Reader:
         if spec_fn is None:
             from ..module.mel_processing import spectrogram_torch as spec_fn
         self.spec_fn = spec_fn
+        self.loader_workers = int(os.environ.get("EVT_READER_WORKERS", "0")) if loader_workers is None else int(loader_workers)
+        self._procs = None
+
+    def close(self):
+        """stop the reader processes (they are daemons: a parent that exits takes them along anyway)"""
+        if self._procs is not None:
+            self._procs.close()
+            self._procs = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _host_batches(self, release=None):
+        """iterator of (collated host batch, per-item ok flags[, slot]) in sampler order"""
+        if self.loader_workers > 0:
+            if self._procs is None:
+                self._procs = _ProcPrefetch(self, self.loader_workers, max(self.prefetch, 2 * self.loader_workers))
+            return self._procs.run(iter(self.sampler), release if release is not None else _AutoRelease())
+        return ((b, ok, None) for b, ok in _Prefetch(self._host_batch, iter(self.sampler), self.prefetch))
 
     def set_epoch(self, epoch):
         self.sampler.set_epoch(epoch)
@@ -378,9 +579,22 @@ class S2Reader:
 
     def __iter__(self):
         ds, dev = self.ds, self.device
-        for (ssl, ssl_l, spec, spec_l, wav, wav_l, text, text_l), ok in _Prefetch(self._host_batch, iter(self.sampler),
-                                                                                 self.prefetch):
+        release, pending = [], []             # slots the workers may refill; (slot, event of its device copies) in flight
+        for (ssl, ssl_l, spec, spec_l, wav, wav_l, text, text_l), ok, slot in self._host_batches(release):
+            if slot is not None and dev.type != "cuda":
+                ssl, wav, text = ssl.clone(), wav.clone(), text.clone()       # the slot is refilled behind the consumer
             ssl, wav, text = (t.to(dev, non_blocking=True) for t in (ssl, wav, text))
+            if slot is not None:
+                if dev.type == "cuda":
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    pending.append((slot, ev))
+                    while pending and (pending[0][1].query() or len(pending) >= self._procs.depth - 1):
+                        s0, e0 = pending.pop(0)
+                        e0.synchronize()                                      # (already complete unless the ring is full)
+                        release.append(s0)
+                else:
+                    release.append(slot)
             ssl = ssl.float()                                              # file dtype (fp16) -> float32, as the collate there
             if wav.dtype == torch.int16:
                 wav = wav.float() * (1.0 / 32768.0)                        # what ffmpeg's s16 -> flt does, exactly

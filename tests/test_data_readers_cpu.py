@@ -371,3 +371,32 @@ def test_collate_mixed_sample_dtypes():
     assert wav[0, 0, :4].tolist() == [0.5, -1.0, 0.0, 1.0 / 32768.0] and float(wav[1, 0, 0]) == 0.25
     (_, _, _, _, wav2, _, _, _), _ = D.collate_s2([a, a], 5, with_spec=False)
     assert wav2.dtype == torch.int16
+
+
+def test_s2_reader_worker_processes_same_batches(feature_dir):
+    """S2Reader(loader_workers=2): reader PROCESSES (the reference's DataLoader workers, sovits.py:258-267) deliver the very
+    batches of the one-thread reader, in the same order, over two epochs; an epoch left early leaks nothing into the next"""
+    a = D.S2Reader(feature_dir, CFG, batch_size=4, device="cpu", spec_fn=oracle_spec)
+    b = D.S2Reader(feature_dir, CFG, batch_size=4, device="cpu", spec_fn=oracle_spec, loader_workers=2, prefetch=3)
+    try:
+        for epoch in (1, 2):
+            a.set_epoch(epoch)
+            b.set_epoch(epoch)
+            n = 0
+            for ba, bb in zip(a, b):
+                n += 1
+                for x, y in zip(ba, bb):
+                    assert x.dtype == y.dtype and torch.equal(x, y)
+            assert n == len(a) == len(b) > 0
+        b.set_epoch(3)
+        it = iter(b)
+        first = next(it)
+        it.close()                                   # leave the epoch after one batch
+        a.set_epoch(4)
+        b.set_epoch(4)
+        for ba, bb in zip(a, b):
+            for x, y in zip(ba, bb):
+                assert torch.equal(x, y)
+        assert first[0].shape[0] == 4
+    finally:
+        b.close()

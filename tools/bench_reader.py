@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--max-seconds", type=float, default=10.0)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--train-steps", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=0, help="reader processes (S2Reader(loader_workers=N)); 0 = the one thread")
     args = ap.parse_args()
     from easevoice_trainer_amd.train import dataset as D
 
@@ -78,6 +79,20 @@ def main():
         n = sum(len(b) for b in batches)
         out["host"] = dict(items_per_s=round(n / dt, 1), ms_per_batch=round(1e3 * dt / len(batches), 2),
                            batches_per_epoch=len(batches), distinct_padded_lengths=len(shapes))
+        if args.workers > 0:
+            # the same epoch through reader processes: what the consumer sees per batch (second epoch: workers are up)
+            rw = D.S2Reader(root, cfg, args.batch, "cpu", loader_workers=args.workers, spec_fn=lambda y, *a, **k: torch.zeros(
+                1, 1025, D.spec_frames(y.size(1), 2048, 640)))
+            try:
+                for ep in (1, 2, 3):      # the third epoch: workers up, slot pages touched
+                    rw.set_epoch(ep)
+                    t0 = time.perf_counter()
+                    nb = sum(1 for _ in rw._host_batches())
+                    dtw = time.perf_counter() - t0
+                out["host_workers"] = dict(workers=args.workers, items_per_s=round(n / dtw, 1),
+                                           ms_per_batch=round(1e3 * dtw / nb, 2))
+            finally:
+                rw.close()
         if args.train_steps > 0:
             from easevoice_trainer_amd.train.s2_engine import S2Engine
             from easevoice_trainer_amd.train.dataset import S2Reader
@@ -91,7 +106,7 @@ def main():
             cb.inited.fill_(1.0)
             eng.build_optimizers()
             eng.enable_graphs(warmup_steps=2, max_shapes=int(os.environ.get("EVT_GRAPH_SHAPES", "64")))      # the trainer's default
-            src = S2Reader(root, cfg, args.batch, dev)
+            src = S2Reader(root, cfg, args.batch, dev, loader_workers=args.workers)
             steps, epoch, wait, audio_s = 0, 0, 0.0, 0.0
             tail_from = args.train_steps * 2 // 3           # the last third: most shapes are captured by then
             tail_t0 = tail_audio0 = tail_rep0 = None
