@@ -1452,9 +1452,11 @@ int launch_wgrad_gemm(const WgP& p_in, hipStream_t st) {
   if (noepi) p.parts = -1;
   const long tiles = (long)(p.CA / 128) * (p.CB / 128);
   const int nstages = (int)(((long)p.nseq * p.Q + WPOS - 1) / WPOS);
-  // one resident wave of blocks (2 per CU): more splits only add fp32 atomics (46 MB of them per launch was a third of
-  // wgrad_deep's traffic in round 1)
-  static const long target = getenv("EVT_WGRAD_GEMM_BLOCKS") ? atol(getenv("EVT_WGRAD_GEMM_BLOCKS")) : 512;
+  // Round 6: HALF a resident wave of blocks (one per CU).  The launch now runs on the s1 engine's side stream next to the
+  // backward chain, which fills whatever slots it leaves; what it still pays alone are its fp32 atomics -- memory-side,
+  // 1.31 TB/s whatever their scope (profiles/r06_atomics_vs_stores.txt), 15-24 us of a 48-100 us launch at 512 blocks --
+  // and half the blocks are half the partial tiles: s1 micro-step 36.43 (512) / 35.91 (384) / 35.83 ms (256) on one box.
+  static const long target = getenv("EVT_WGRAD_GEMM_BLOCKS") ? atol(getenv("EVT_WGRAD_GEMM_BLOCKS")) : 256;
   long split = (target + tiles - 1) / tiles;
   if (split > nstages / 8) split = nstages / 8;
   if (split < 1) split = 1;

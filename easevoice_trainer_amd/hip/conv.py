@@ -361,6 +361,11 @@ class WeightBank:
             one = L.struct_to_device([it], self.device)
             self._frag_tables[("one", len(self._frag_items))] = (one, 1)      # kept alive
             L.check(L.lib().evt_frag_pack(L.ptr(one), 1, L.stream_ptr()), "evt_frag_pack")
+            # the whole-model table is rebuilt NOW (images are registered by the first eager forward), so that the fold a
+            # later graph capture records finds it instead of building it -- a host-to-device copy -- inside the capture
+            if not torch.cuda.is_current_stream_capturing():
+                items = list(self._frag_items)
+                self._frag_tables[(0, self._nrows)] = (L.struct_to_device(items, self.device), len(items))
         return f
 
     def _repack_frags(self, lo, hi):
@@ -368,11 +373,6 @@ class WeightBank:
             return
         tab = self._frag_tables.get((lo, hi))
         if tab is None:
-            if torch.cuda.is_current_stream_capturing():
-                # the table is a synchronous host-to-device copy: not inside a capture (the eager steps that precede a
-                # capture fold the same row ranges, so this only fires for a range first seen while capturing)
-                raise L.EvtError(f"fragment-order table for rows [{lo}, {hi}) requested during a graph capture; fold the "
-                                 "same range once eagerly first")
             items = [it for it, (r0, r1) in zip(self._frag_items, self._frag_rows) if r0 < hi and r1 > lo]
             tab = self._frag_tables[(lo, hi)] = (L.struct_to_device(items, self.device) if items else None, len(items))
         if tab[1]:

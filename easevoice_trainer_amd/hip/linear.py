@@ -91,17 +91,26 @@ class LinearBank:
         # backward-data GEMMs / attention / LayerNorm launches: their tails (a partial second round of blocks, the
         # memory-side atomics of the split-K epilogue) fill with the next kernel's blocks.  Off until an engine turns it on.
         self.side = None
-        self._side_used = False
+        self.side_on = False          # only between an engine's side_begin() and join_side(): a caller that differentiates
+        self._side_used = False       # through the modules directly gets its weight gradients in stream order
 
     def enable_side_stream(self):
         if self.device.type == "cuda" and self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
+
+    def side_begin(self):
+        """from here to join_side() the weight-gradient launches go to the side stream"""
+        self.side_on = self.side is not None
 
     def join_side(self):
         """the caller's stream waits for the weight-gradient launches handed to the side stream since the last join"""
         if self.side is not None and self._side_used:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self._side_used = False
+
+    def side_end(self):
+        self.join_side()
+        self.side_on = False
 
     def _tables(self):
         items, rows, groups = [], [], []
@@ -223,7 +232,7 @@ def gemm_bwd_weight(slot, x, dy, want_bias=True):
         dw_buf = torch.zeros((slot.Np, slot.K), dtype=torch.float32, device=dy.device)
         db_buf = torch.zeros(slot.Np, dtype=torch.float32, device=dy.device) if want_b else None
     bank = slot.bank
-    if sunk and bank.side is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if sunk and bank.side_on and bank.side is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         # straight into the arena, on the side stream: ordered behind what the current stream has enqueued (x, dy exist),
         # the operands kept alive for the allocator until the launch has run; S1Engine joins before it reads the arena
         bank.side.wait_stream(torch.cuda.current_stream(x.device))

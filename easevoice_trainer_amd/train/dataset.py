@@ -560,7 +560,14 @@ class S2Reader:
         """iterator of (collated host batch, per-item ok flags[, slot]) in sampler order"""
         if self.loader_workers > 0:
             if self._procs is None:
-                self._procs = _ProcPrefetch(self, self.loader_workers, max(self.prefetch, 2 * self.loader_workers))
+                try:
+                    self._procs = _ProcPrefetch(self, self.loader_workers, max(self.prefetch, 2 * self.loader_workers))
+                except Exception as e:  # noqa: BLE001 -- e.g. a /dev/shm too small for the slots: read on the one thread
+                    import warnings
+
+                    warnings.warn(f"S2Reader: reader processes unavailable ({e!r}); using the prefetch thread")
+                    self.loader_workers = 0
+                    return ((b, ok, None) for b, ok in _Prefetch(self._host_batch, iter(self.sampler), self.prefetch))
             return self._procs.run(iter(self.sampler), release if release is not None else _AutoRelease())
         return ((b, ok, None) for b, ok in _Prefetch(self._host_batch, iter(self.sampler), self.prefetch))
 

@@ -86,11 +86,12 @@ class S1Engine:
             p.grad = None
         self._reduced_from = None
         self.model.h.grad_hook = self._piece_done if overlap else None
+        self.bank.side_begin()         # this backward's dense-layer dW launches run next to its chain (hip/linear.py)
         try:
             self.scaler.scale(loss).backward()
         finally:
             self.model.h.grad_hook = None
-        self.bank.join_side()          # the weight gradients of the dense layers are in the arena from here on
+            self.bank.side_end()       # joined: the weight gradients of the dense layers are in the arena from here on
         hi = self._reduced_from if self._reduced_from is not None else self.arena.grad.numel()
         self._gather(0, hi)
         for p, v in self._views:

@@ -25,7 +25,7 @@ def test_bench_two_ranks_one_device(gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up, all-reduce otherwise") and d["config"]["global_batch"] == 4
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2, reduce-scatter + all-gather for buckets >= 8 MiB from 3 ranks up (after a start-up equality check") and d["config"]["global_batch"] == 4
     # the collective plan of every reduced range is spelt out (two ranks: all-reduce throughout)
     assert "per range: D piece 1/6" in d["config"]["parallelism"] and "G rest" in d["config"]["parallelism"]
     # the line explains its own gradient exchange: collectives and MiB per step, and the wait the overlap did not hide

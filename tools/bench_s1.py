@@ -50,11 +50,17 @@ def attention_roofline(eng, batch, B, Lq, dtype_name, n_micro=2, x_len=256):
         for i in range(n_micro):
             eng.micro_step(batch, 1 + i)      # indices 1..: no optimiser step inside the profiled region
 
+    # per-kernel durations are taken with the weight-gradient side stream OFF: a kernel that shares the chip with another
+    # stream's kernel has a longer record without being slower (the timed steps of the bench line keep the side stream)
+    side, eng.bank.side = eng.bank.side, None
     try:
         kernels, _ = kernel_profile(run)
     except Exception as e:
+        eng.bank.side = side
         return dict(bound="mfma", achieved=None, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=None, traffic=None,
                     note=f"profiler unavailable: {e!r}")
+    eng.bank.side = side
+
     def pick(sub):
         v = [(k, c) for k, c in kernels.items() if sub in k]
         return (sum(c[0] for _, c in v), sum(c[1] for _, c in v)) if v else (0, 0.0)

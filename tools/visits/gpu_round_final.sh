@@ -13,7 +13,7 @@ timeout 500 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc
 mkdir -p $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python bench.py --workload s2 --steps 6 --warmup 3 --no-extras --graphs 0 > $O/p1.log 2>&1
 find $O/p1 -name '*kernel_stats.csv' -exec cp {} $O/s2_kernel_stats_eager.csv \;
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p2 -- python bench.py --workload s1 --steps 4 --warmup 2 --no-extras > $O/p2.log 2>&1
+EVT_S1_WGRAD_SIDE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p2 -- python bench.py --workload s1 --steps 4 --warmup 2 --no-extras > $O/p2.log 2>&1   # side stream off: per-kernel durations stand alone
 find $O/p2 -name '*kernel_stats.csv' -exec cp {} $O/s1_kernel_stats.csv \;
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p3 -- python bench.py --workload s2 --steps 2 --warmup 2 --no-extras --graphs 0 > $O/p3.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p4 -- python bench.py --workload s2 --steps 2 --warmup 2 --no-extras --graphs 0 > $O/p4.log 2>&1
