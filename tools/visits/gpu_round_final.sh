@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=gpurun_out/${1:-r04z}
 mkdir -p $O
 t0=$(date +%s)
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$? $(( $(date +%s)-t0 ))s" > $O/times.txt
+timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$? $(( $(date +%s)-t0 ))s" > $O/times.txt
 tail -3 $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/times.txt; tail -1 $O/smoke.log
 t1=$(date +%s)
