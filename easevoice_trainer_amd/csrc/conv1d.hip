@@ -1211,6 +1211,26 @@ int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c) {
   return (evt_conv::wgrad_deep_eligible(w, c->dtype) || evt_conv::wgrad_halo_eligible(w, c->dtype)) ? 1 : 0;
 }
 
+int32_t evt_conv1d_wants_plain_x(const evt_conv1d_params* c) {
+  if (!c || valid(c) != EVT_OK) return 0;
+  if (c->impl != EVT_IMPL_AUTO || c->dtype != EVT_DT_HALF || c->in_slope == 1.f || !igemm_ok(c)) return 0;
+  if (evt_grouped_supported(c) || evt_small_kind(c) != 0) return 0;
+  // same descriptor geometry evt_conv1d_fwd builds, with the load-side activation taken out
+  evt_wlayout l; evt_conv1d_layout(c, &l);
+  const int lout = evt_conv1d_lout(c);
+  ConvP p{};
+  p.in_slope = 1.f;
+  p.nseq = c->nseq;
+  int nphase = 1;
+  if (!c->transposed) { p.nchunk = l.reg_nchunk; p.KHp = l.reg_kp; p.Q = lout; }
+  else {
+    p.nchunk = l.alt_nchunk; p.KHp = l.alt_kp;
+    if (c->stride == 1) p.Q = lout;
+    else { nphase = c->stride; p.Q = (lout - 1 + c->pad) / c->stride + 1; }
+  }
+  return evt_conv::deep_eligible(p, c->dtype, c->cout, c->cin, nphase) ? 1 : 0;
+}
+
 int evt_conv1d_layout(const evt_conv1d_params* c, evt_wlayout* o) {
   if (!c || !o) return EVT_EINVAL;
   const int d0 = c->transposed ? c->cin : c->cout;

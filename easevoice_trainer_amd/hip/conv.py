@@ -533,6 +533,7 @@ class FrozenBank:
         self._stamp = stamp
 
 
+PLAIN_X = os.environ.get("EVT_CONV_PLAIN_X", "1") != "0"   # A/B switch: pre-activated input for GEMM-sized layers with a load-side leaky-relu
 TRACE = None   # profiling only (set_trace): (tag, kind, flops, bytes, ev0, ev1, shape, module) per launch
 
 
@@ -688,7 +689,22 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, res, slot, in_slope, out_act, out_slope):
-        y = _fwd(slot, x, res, in_slope, out_act, out_slope)
+        ctx.pre = False
+        if in_slope != 1.0 and x.is_cuda and x.dim() == 3 and PLAIN_X and L.lib().evt_conv1d_wants_plain_x(
+                C.byref(slot.params(x.size(0), x.size(1), in_slope, out_act, out_slope))):
+            # GEMM-sized layer with a leaky-relu on load (the vocoder's upsamplers): activate once, the forward and the
+            # weight gradient then take plain operands (LDS-DMA kernels); backward-data keeps its fused derivative,
+            # read from the sign of the activated tensor
+            xa = torch.empty_like(x)
+            e0 = _t0()
+            L.check(L.lib().evt_leaky_relu(L.dt_of(x), L.ptr(x), C.c_float(in_slope), L.ptr(xa), C.c_int64(x.numel()),
+                                           L.stream_ptr()), "evt_leaky_relu")
+            if e0 is not None:
+                _t1_elt(e0, "lrelu_kernel", 2 * x.numel() * x.element_size(), slot.module)
+            y = _fwd(slot, xa, res, 1.0, out_act, out_slope)
+            x, ctx.pre = xa, True
+        else:
+            y = _fwd(slot, x, res, in_slope, out_act, out_slope)
         ctx.slot, ctx.cfg = slot, (in_slope, out_act, out_slope)
         ctx.has_res = res is not None
         ctx.save_for_backward(x, y if out_act != L.ACT_NONE else None)
@@ -712,7 +728,8 @@ class ConvFn(torch.autograd.Function):
                 _t1_elt(e0, "dact_mul_kernel", 3 * dy.numel() * dy.element_size(), slot.module)
             dy, y, out_act, out_slope = dy_eff, None, L.ACT_NONE, 1.0
         if slot.bank.weight_grads:
-            _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope)
+            # (ctx.pre: x is the activated input -- plain operand for the weight gradient)
+            _bwd_weight(slot, x, dy, y, nseq, lin, 1.0 if ctx.pre else in_slope, out_act, out_slope)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _bwd_data(slot, dy, y, x, None, nseq, lin, in_slope, out_act, out_slope)

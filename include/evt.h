@@ -103,6 +103,12 @@ typedef struct evt_conv1d_params {
  * activation's derivative already applied (evt_dact_mul) and out_act = EVT_ACT_NONE in the backward calls; else 0. */
 int32_t evt_conv1d_wants_plain_dy(const evt_conv1d_params* c);
 
+/* 1 when the FORWARD of this conv (in_slope != 1: leaky-relu on load, the HiFi-GAN upsamplers of models.py:457-460) would
+ * run on the LDS-DMA GEMM path if it were handed the activated input: the caller then applies evt_leaky_relu once,
+ * calls forward and weight gradient with in_slope = 1 on the activated tensor, and backward-data with in_slope and the
+ * activated tensor as `x` (leaky-relu keeps the sign, the derivative is the same).  Else 0. */
+int32_t evt_conv1d_wants_plain_x(const evt_conv1d_params* c);
+
 int32_t evt_conv1d_lout(const evt_conv1d_params* p);
 
 /* Prepared-weight layouts.  The parameter tensor is W[d0][d1][k] (Conv1d: d0=cout, d1=cin/g;

@@ -238,6 +238,37 @@ def test_conv_deep_parity(gpu, ci):
             assert any(k == "bwd_weight" and t.startswith(("wgrad_deep<", "wgrad_halo<")) for k, t in tags), tags
 
 
+# the vocoder's upsamplers at the step's own geometry (models.py:424-436, 457-460: leaky-relu(0.1) on load): the input is
+# activated once (evt_conv1d_wants_plain_x) and the polyphase forward then runs on the LDS-DMA kernels
+UPS_CASES = [
+    (512, 256, 16, 10, 3, 1, 1, True, True, 32, 16),
+    (256, 128, 16, 8, 4, 1, 1, True, True, 320, 4),
+    (128, 64, 8, 2, 3, 1, 1, True, True, 640, 4),
+    (128, 64, 8, 2, 3, 1, 1, True, True, 333, 3),          # ragged: 999 positions per phase
+]
+
+
+@pytest.mark.parametrize("ci", range(len(UPS_CASES)))
+def test_upsampler_preactivated_parity(gpu, ci):
+    from easevoice_trainer_amd.hip import conv as HC
+
+    case = UPS_CASES[ci]
+    fusion = dict(in_slope=0.1, out_act=0, out_slope=1.0, res=False)
+    for plain in (True, False):
+        old = HC.PLAIN_X
+        HC.PLAIN_X = plain
+        HC.set_trace([])
+        try:
+            _run_case(gpu, case, fusion, HALF, 0)
+            tags = {(r[1], r[0]) for r in HC.TRACE}
+        finally:
+            HC.set_trace(None)
+            HC.PLAIN_X = old
+        fast = ("conv_ring<bf16, 64, 64, 64, x4>", "conv_deep<bf16, 128, 128, 64>", "conv_deep32<bf16, 128, 128, 32>")
+        assert any(k == "fwd" and t in fast for k, t in tags) == plain, tags
+        assert (("elt", "lrelu_kernel") in tags) == plain, tags
+
+
 # stride-1 layers with 3 / 5 / 7 / 11 taps and sequences long enough for sequence-local K stages -> wgrad_halo (one staged
 # window of x serves every tap): vocoder stages (dilated), WN in_layers, encoder FFN; tails that are not multiples of 64 / 32
 HALO_CASES = [
