@@ -172,6 +172,7 @@ class WeightBank:
         # (a fork every few convolutions) is what made EVT_ASYNC_WGRAD slower under replay.
         self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "64")) if self.device.type == "cuda" else 0
         self._deferred = []
+        self._deferred_on = set()
         self._side = None
         self._held = []
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -383,6 +384,7 @@ class WeightBank:
             # weight-gradient launches of a backward that never reached grads() (a standalone user, an exception in the
             # middle of a step): they would land in the images zeroed below -- drop them, wait for what already runs
             self._deferred.clear()
+            self._deferred_on.clear()
             self._deferred_bytes = 0
             if self._side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self._side)
@@ -411,6 +413,9 @@ class WeightBank:
             return
         side = self.side_stream()
         side.wait_stream(torch.cuda.current_stream(self.device))
+        for st in self._deferred_on:          # operands queued from another stream than the one that flushes
+            side.wait_stream(st)
+        self._deferred_on.clear()
         with torch.cuda.stream(side):
             for args in self._deferred:
                 _bwd_weight_now(*args)
@@ -636,6 +641,7 @@ def _bwd_weight(slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope):
                          "q / k / v projections of a windowed attention layer run (and are differentiated) as one pack")
     if bank.defer_n > 0 and TRACE is None:
         bank._deferred.append((slot, x, dy, y, nseq, lin, in_slope, out_act, out_slope))
+        bank._deferred_on.add(torch.cuda.current_stream(bank.device))   # a branch stream of the discriminators, or the main one
         bank._deferred_bytes += x.numel() * x.element_size() + dy.numel() * dy.element_size()
         if len(bank._deferred) >= bank.defer_n or bank._deferred_bytes >= bank.defer_bytes:
             bank.flush_deferred()

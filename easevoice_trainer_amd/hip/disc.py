@@ -12,11 +12,48 @@ half only (the real feature maps are detached, losses.py:11).  Here, per sub-dis
     no zero-padded slice gradients, no element-wise sums, ~45 autograd nodes less per sub-discriminator.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import conv as HC
 from . import lib as L
+
+# The six sub-discriminators are independent between the fold of their inputs and the loss launches: with
+# EVT_MPD_STREAMS = n > 1 they are dealt round-robin onto the current stream and n - 1 side streams (forward and
+# backward of the generator step's node), so that one's under-filled launches (backward-data over the generated half:
+# 264 blocks on 512 slots; the 520-block period-7 layers) run beside another's.  Every tensor a branch allocates
+# is allocated and freed on the branch's own stream; what the joining stream reads afterwards is record_stream()ed.
+MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "1"))
+_side = {}
+
+
+def _branches(dev, n_items):
+    """stream of every sub-discriminator (None = the current stream) and the distinct side streams among them"""
+    n = MPD_STREAMS if (dev.type == "cuda" and HC.TRACE is None) else 1
+    if n <= 1:
+        return [None] * n_items, []
+    pool = _side.setdefault(dev, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    lanes = [None] + pool[: n - 1]
+    per = [lanes[i % n] for i in range(n_items)]
+    return per, pool[: n - 1]
+
+
+class _On:
+    """`with _On(stream)`: torch.cuda.stream(stream), or nothing for None"""
+
+    def __init__(self, s):
+        self.cm = torch.cuda.stream(s) if s is not None else None
+
+    def __enter__(self):
+        if self.cm is not None:
+            self.cm.__enter__()
+
+    def __exit__(self, *a):
+        if self.cm is not None:
+            self.cm.__exit__(*a)
 
 
 def mpd_fold(periods, cd, src0, src1=None):
@@ -87,12 +124,22 @@ class MPDGenLossFn(torch.autograd.Function):
         # [real ; generated] of every sub-discriminator, prepared in one launch
         both = mpd_fold(periods, cd, y_real, y_hat)
         maps, saved = [], []           # per sub-D: list of batched outputs
-        for (slots, acts), x in zip(plan, both):
+        lanes, sides = _branches(dev, nd)
+        main = torch.cuda.current_stream(dev) if sides else None
+        for st in sides:
+            st.wait_stream(main)
+        for (slots, acts), x, lane in zip(plan, both, lanes):
             ys = []
-            for s, (act, slope) in zip(slots, acts):
-                x = HC._fwd(s, x, None, 1.0, act, slope)
-                ys.append(x)
+            with _On(lane):
+                for s, (act, slope) in zip(slots, acts):
+                    x = HC._fwd(s, x, None, 1.0, act, slope)
+                    ys.append(x)
+            if lane is not None:
+                for y in ys:
+                    y.record_stream(main)
             maps.append(ys)
+        for st in sides:
+            main.wait_stream(st)
         fa, fb, fs, la, ls = [], [], [], [], []
         for ys in maps:
             for y in ys:
@@ -146,29 +193,45 @@ class MPDGenLossFn(torch.autograd.Function):
         L.check(L.lib().evt_lsgan_multi_bwd(dt, L.ptr(_seg_table(la, [None] * nd, lgr, ls, dev)), nd, C.c_float(1.0),
                                             L.ptr(dl[:1]), L.stream_ptr()), "evt_lsgan_multi_bwd")
         grads, gi = [], 0
-        for (slots, acts), ys, lg_grad, in_shape in zip(plan, maps, lgr, ctx.in_shapes):
+        lanes, sides = _branches(dev, nd)
+        main = torch.cuda.current_stream(dev) if sides else None
+        for st in sides:
+            st.wait_stream(main)
+        for (slots, acts), ys, lg_grad, in_shape, lane in zip(plan, maps, lgr, ctx.in_shapes, lanes):
             nl = len(slots)
             mg = fg[gi: gi + nl]
             gi += nl
-            dy = mg[-1] + lg_grad                                    # the last map is also the logits (a few K values)
-            for l in reversed(range(nl)):
-                s, (act, slope) = slots[l], acts[l]
-                y_act = ys[l][ys[l].size(0) // 2:]
-                half = y_act.size(0)
-                lin = ys[l - 1].size(1) if l > 0 else in_shape[1]
-                add = mg[l - 1] if l > 0 else None
-                a_kind, a_slope, y_arg = act, slope, (y_act if act != L.ACT_NONE else None)
-                if act != L.ACT_NONE and L.lib().evt_conv1d_wants_plain_dy(C.byref(s.params(half, lin, 1.0, act, slope))):
-                    dy_eff = torch.empty_like(dy)
-                    L.check(L.lib().evt_dact_mul(dt, L.ptr(dy), L.ptr(y_act), int(act), C.c_float(slope), L.ptr(dy_eff),
-                                                 C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
-                    dy, y_arg, a_kind, a_slope = dy_eff, None, L.ACT_NONE, 1.0
-                if add is not None and s.module.groups > 1:
-                    # the grouped kernels take no add operand (the dispatcher would fall back to the generic path)
-                    dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, None, half, lin, 1.0, a_kind, a_slope)
-                    dy.add_(add)
-                else:
-                    dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, add, half, lin, 1.0, a_kind, a_slope)
+            with _On(lane):
+                dy = _branch_bwd(slots, acts, ys, mg, lg_grad, in_shape, dt)
+            if lane is not None:
+                dy.record_stream(main)
             grads.append(dy)
+        for st in sides:
+            main.wait_stream(st)
         n_items, T, wdt = ctx.wav
         return None, None, None, mpd_unfold(ctx.periods, grads, 0, n_items, T, wdt), None
+
+
+def _branch_bwd(slots, acts, ys, mg, lg_grad, in_shape, dt):
+    """backward-data chain of one sub-discriminator over the generated half; returns the gradient of its prepared input"""
+    nl = len(slots)
+    dy = mg[-1] + lg_grad                                    # the last map is also the logits (a few K values)
+    for l in reversed(range(nl)):
+        s, (act, slope) = slots[l], acts[l]
+        y_act = ys[l][ys[l].size(0) // 2:]
+        half = y_act.size(0)
+        lin = ys[l - 1].size(1) if l > 0 else in_shape[1]
+        add = mg[l - 1] if l > 0 else None
+        a_kind, a_slope, y_arg = act, slope, (y_act if act != L.ACT_NONE else None)
+        if act != L.ACT_NONE and L.lib().evt_conv1d_wants_plain_dy(C.byref(s.params(half, lin, 1.0, act, slope))):
+            dy_eff = torch.empty_like(dy)
+            L.check(L.lib().evt_dact_mul(dt, L.ptr(dy), L.ptr(y_act), int(act), C.c_float(slope), L.ptr(dy_eff),
+                                         C.c_int64(dy.numel()), L.stream_ptr()), "evt_dact_mul")
+            dy, y_arg, a_kind, a_slope = dy_eff, None, L.ACT_NONE, 1.0
+        if add is not None and s.module.groups > 1:
+            # the grouped kernels take no add operand (the dispatcher would fall back to the generic path)
+            dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, None, half, lin, 1.0, a_kind, a_slope)
+            dy.add_(add)
+        else:
+            dy = HC._bwd_data(s, dy.contiguous(), y_arg, None, add, half, lin, 1.0, a_kind, a_slope)
+    return dy

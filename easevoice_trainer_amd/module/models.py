@@ -718,8 +718,30 @@ class MultiPeriodDiscriminator(nn.Module):
         """the D step's pass: logits of every sub-discriminator over [real ; generated] as ONE tensor each ([2n, -1]; the
         first n rows are the real audio) -- for losses.discriminator_loss_batched, which needs no slices"""
         n = y.size(0)
-        return [d.forward_prepared(x)[0] for d, x in zip(self.discriminators,
-                                                         self._prepared(y.reshape(n, -1), y_hat.reshape(n, -1)))]
+        xs = self._prepared(y.reshape(n, -1), y_hat.reshape(n, -1))
+        if not y.is_cuda:
+            return [d.forward_prepared(x)[0] for d, x in zip(self.discriminators, xs)]
+        # the sub-discriminators are independent: dealt onto the current stream and a side stream (hip/disc.py, EVT_MPD_STREAMS);
+        # autograd runs every node's backward on the stream of its forward and orders the streams itself
+        from ..hip.disc import _On, _branches
+
+        bank = self.discriminators[0].convs[0]._slot.bank if self.discriminators[0].convs[0]._slot is not None else None
+        lanes, sides = _branches(y.device, len(self.discriminators)) if (bank is not None and bank.defer_n > 0) \
+            else ([None] * len(self.discriminators), [])
+        main = torch.cuda.current_stream(y.device) if sides else None
+        for st in sides:
+            st.wait_stream(main)
+        outs = []
+        for d, x, lane in zip(self.discriminators, xs, lanes):
+            with _On(lane):
+                o = d.forward_prepared(x)[0]
+            if lane is not None:
+                x.record_stream(lane)          # allocated on the current stream, read (and saved for backward) on the lane
+                o.record_stream(main)
+            outs.append(o)
+        for st in sides:
+            main.wait_stream(st)
+        return outs
 
     def forward(self, y, y_hat):
         n = y.size(0)
