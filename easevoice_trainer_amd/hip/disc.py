@@ -24,7 +24,7 @@ from . import lib as L
 # backward of the generator step's node), so that one's under-filled launches (backward-data over the generated half:
 # 264 blocks on 512 slots; the 520-block period-7 layers) run beside another's.  Every tensor a branch allocates
 # is allocated and freed on the branch's own stream; what the joining stream reads afterwards is record_stream()ed.
-MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "1"))
+MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "2"))
 _side = {}
 
 
@@ -39,6 +39,20 @@ def _branches(dev, n_items):
     lanes = [None] + pool[: n - 1]
     per = [lanes[i % n] for i in range(n_items)]
     return per, pool[: n - 1]
+
+
+ENC_STREAM = os.environ.get("EVT_ENC_STREAM", "1") != "0"
+
+
+def enc_lane(dev):
+    """side stream for the prior encoder of SynthesizerTrn.forward (independent of posterior encoder / flow / vocoder until
+    the KL term), or None"""
+    if not ENC_STREAM or dev.type != "cuda" or HC.TRACE is not None:
+        return None
+    pool = _side.setdefault(dev, [])
+    if not pool:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[0]
 
 
 class _On:

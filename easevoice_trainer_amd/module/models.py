@@ -871,10 +871,27 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             ref_in = y_cl[..., :self.spec_channels] if self.version == "v1" else y_cl[..., :704]
             ge = self.ref_enc(ref_in * y_mask.to(self.cd), y_mask, lens32)                     # [B, gin]
             quantized, _codes = self._quantize(ssl)
-            x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
+            split = self.split_backward and torch.is_grad_enabled()
+            # the prior encoder meets the rest of the model again only in the KL term: on a side stream (hip/disc.py,
+            # EVT_ENC_STREAM) its small-grid launches run beside posterior encoder / flow / vocoder, forward and -- autograd
+            # runs a node's backward on the stream of its forward -- backward.  Not in the data-parallel cut program, which
+            # sequences the sub-models' backward passes itself.
+            lane = None
+            if y.is_cuda and not split:
+                from ..hip.disc import _On, enc_lane
+
+                lane = enc_lane(dev)
+            if lane is not None:
+                main = torch.cuda.current_stream(dev)
+                lane.wait_stream(main)
+                with _On(lane):
+                    x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
+                for t in (quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths):
+                    t.record_stream(lane)
+            else:
+                x, m_p, logs_p = self.enc_p(quantized, y_mask, text, text_mask, ge, y_lengths, text_lengths)
             eps_cl = eps.transpose(1, 2) if eps is not None else None
             ym = y_mask.to(self.cd)      # 0/1 mask in the compute dtype: the WN stacks stay in one dtype (no cast kernels)
-            split = self.split_backward and torch.is_grad_enabled()
             ge_fq = ge
             if split:
                 # second cut of the data-parallel step (see below): posterior encoder and flow hang on their own copy of
@@ -900,6 +917,10 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
                 o = self.dec(z_cut, g=ge_cut)
             else:
                 o = self.dec(z_slice, g=ge)                                                    # [B, seg*hop, 1]
+            if lane is not None:
+                main.wait_stream(lane)
+                for t in (x, m_p, logs_p):
+                    t.record_stream(main)
         commit_loss = torch.zeros((), device=dev)   # quantizer in eval mode: core_vq.py:311-316 adds nothing
         tr = lambda t: t.transpose(1, 2)
         y_mask_ncl = y_mask.transpose(1, 2)

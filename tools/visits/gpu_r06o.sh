@@ -1,0 +1,8 @@
+#!/bin/bash
+# prior encoder on a side stream: s2 step A/B (with the discriminators on two streams)
+tag=${1:-r06o}
+out=gpurun_out/$tag
+mkdir -p $out
+for v in 0 1 0 1; do
+  EVT_MPD_STREAMS=2 EVT_ENC_STREAM=$v python bench.py --workload s2 --steps 30 --warmup 8 --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('enc_stream=$v', d['ms_per_step'], d['value'], d.get('losses'))" | tee -a $out/ab.txt
+done
