@@ -55,6 +55,20 @@ def enc_lane(dev):
     return pool[0]
 
 
+DEC_STREAM = os.environ.get("EVT_DEC_STREAM", "1") != "0"
+
+
+def dec_lane(dev):
+    """side stream for two of the three parallel ResBlocks of a wide vocoder stage (models.py:461-466: xs = sum of the blocks'
+    outputs; the narrow stages run the three as grouped launches instead), or None"""
+    if not DEC_STREAM or dev.type != "cuda" or HC.TRACE is not None:
+        return None
+    pool = _side.setdefault(dev, [])
+    while len(pool) < 2:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[1]
+
+
 class _On:
     """`with _On(stream)`: torch.cuda.stream(stream), or nothing for None"""
 

@@ -17,6 +17,8 @@ mrte_model.py:9-61, core_vq.py:172-228), re-laid-out for the hardware:
 There is no CPU / eager fallback: the modules need a WeightBank (hip/conv.py) and a GPU.
 """
 
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -570,7 +572,25 @@ class Generator(nn.Module, _ComputeDtype):
                 if xs is not None:
                     x = xs
                     continue
-            rs = [b(x) for b in blocks]
+            lane = None
+            if x.is_cuda and len(blocks) == 3:
+                from ..hip.disc import _On, dec_lane
+
+                lane = dec_lane(x.device)
+            if lane is not None:
+                # the k = 11 block on the current stream, the k = 3 and k = 7 blocks (about the same work together) beside it
+                main = torch.cuda.current_stream(x.device)
+                lane.wait_stream(main)
+                with _On(lane):
+                    r0, r1 = blocks[0](x), blocks[1](x)
+                x.record_stream(lane)
+                r2 = blocks[2](x)
+                main.wait_stream(lane)
+                r0.record_stream(main)
+                r1.record_stream(main)
+                rs = [r0, r1, r2]
+            else:
+                rs = [b(x) for b in blocks]
             while len(rs) < 3:
                 rs.append(None)
             x = Add3ScaleFn.apply(rs[0], rs[1], rs[2], 1.0 / self.num_kernels, self)

@@ -1,6 +1,7 @@
 """GPU: the s2 step with its independent sub-models on branch streams (hip/disc.py: the six sub-discriminators dealt onto two
 streams in the D step and in the generator step's discriminator node, EVT_MPD_STREAMS; the prior encoder beside posterior
-encoder / flow / vocoder, EVT_ENC_STREAM) must train exactly like the one-stream step.
+encoder / flow / vocoder, EVT_ENC_STREAM; two of the three parallel ResBlocks of the wide vocoder stages beside the third,
+EVT_DEC_STREAM) must train exactly like the one-stream step.
 
 Same launches on the same operands: what can go wrong is ORDER -- a branch reading an operand before its producer stream
 wrote it, a joined stream reading a branch's result early, a block handed out again while another stream still reads it.
@@ -20,10 +21,10 @@ def test_branch_streams_train_like_one_stream(gpu, graphs):
 
     args, kw = _batch(gpu)
     hist, final, grads1 = {}, {}, {}
-    old = (HD.MPD_STREAMS, HD.ENC_STREAM)
+    old = (HD.MPD_STREAMS, HD.ENC_STREAM, HD.DEC_STREAM)
     try:
         for mode in ("one", "one_again", "branches"):
-            HD.MPD_STREAMS, HD.ENC_STREAM = (2, True) if mode == "branches" else (1, False)
+            HD.MPD_STREAMS, HD.ENC_STREAM, HD.DEC_STREAM = (2, True, True) if mode == "branches" else (1, False, False)
             eng = _engine(gpu, False)
             if graphs:
                 eng.enable_graphs(warmup_steps=1)
@@ -41,7 +42,7 @@ def test_branch_streams_train_like_one_stream(gpu, graphs):
             final[mode] = (eng.rt_g.arena.param.clone(), eng.rt_d.arena.param.clone())
             del eng
     finally:
-        HD.MPD_STREAMS, HD.ENC_STREAM = old
+        HD.MPD_STREAMS, HD.ENC_STREAM, HD.DEC_STREAM = old
     # the one-stream step against itself gives the noise floor (fp32 atomics of a few gradient kernels)
     for a, b, c in zip(grads1["branches"], grads1["one"], grads1["one_again"]):
         noise = ((c - b).abs().max() / b.abs().max()).item()
