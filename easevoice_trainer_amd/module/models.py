@@ -889,18 +889,28 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
             # the spectrogram once as channels-last rows in the compute dtype, zero-padded to enc_q.pre's image width
             y_cl = ncl_to_nlc(y.float(), self.enc_q.pre.cin, self.cd)                          # [B, T, 1088]
             ref_in = y_cl[..., :self.spec_channels] if self.version == "v1" else y_cl[..., :704]
-            ge = self.ref_enc(ref_in * y_mask.to(self.cd), y_mask, lens32)                     # [B, gin]
-            quantized, _codes = self._quantize(ssl)
             split = self.split_backward and torch.is_grad_enabled()
-            # the prior encoder meets the rest of the model again only in the KL term: on a side stream (hip/disc.py,
-            # EVT_ENC_STREAM) its small-grid launches run beside posterior encoder / flow / vocoder, forward and -- autograd
-            # runs a node's backward on the stream of its forward -- backward.  Not in the data-parallel cut program, which
-            # sequences the sub-models' backward passes itself.
             lane = None
             if y.is_cuda and not split:
                 from ..hip.disc import _On, enc_lane
 
                 lane = enc_lane(dev)
+            if lane is not None and os.environ.get("EVT_QUANT_LANE", "1") != "0":
+                # the frozen ssl projection + quantizer (two fp32 convolutions, 0.2 ms) feed the prior encoder only: on its
+                # lane from the start, beside the style encoder
+                main = torch.cuda.current_stream(dev)
+                lane.wait_stream(main)
+                with _On(lane):
+                    quantized, _codes = self._quantize(ssl)
+                ssl.record_stream(lane)
+                ge = self.ref_enc(ref_in * y_mask.to(self.cd), y_mask, lens32)                 # [B, gin]
+            else:
+                ge = self.ref_enc(ref_in * y_mask.to(self.cd), y_mask, lens32)                 # [B, gin]
+                quantized, _codes = self._quantize(ssl)
+            # the prior encoder meets the rest of the model again only in the KL term: on a side stream (hip/disc.py,
+            # EVT_ENC_STREAM) its small-grid launches run beside posterior encoder / flow / vocoder, forward and -- autograd
+            # runs a node's backward on the stream of its forward -- backward.  Not in the data-parallel cut program, which
+            # sequences the sub-models' backward passes itself.
             if lane is not None:
                 main = torch.cuda.current_stream(dev)
                 lane.wait_stream(main)
@@ -939,7 +949,7 @@ class SynthesizerTrn(nn.Module, _ComputeDtype):
                 o = self.dec(z_slice, g=ge)                                                    # [B, seg*hop, 1]
             if lane is not None:
                 main.wait_stream(lane)
-                for t in (x, m_p, logs_p):
+                for t in (x, m_p, logs_p, quantized):
                     t.record_stream(main)
         commit_loss = torch.zeros((), device=dev)   # quantizer in eval mode: core_vq.py:311-316 adds nothing
         tr = lambda t: t.transpose(1, 2)

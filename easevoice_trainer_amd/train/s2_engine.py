@@ -158,10 +158,28 @@ class S2Engine:
         rt_d.prepare()
         (st.y_hat, st.kl_ssl, st.ids_slice, st.x_mask, st.z_mask, st.lat, st.q) = net_g(
             st.ssl, st.spec, st.spec_lengths, st.text, st.text_lengths, eps=st.eps, ids_slice=st.ids_slice_in)
-        st.y_mel = spec_to_mel_slices(st.spec, st.ids_slice, seg // hop, d["filter_length"], d["n_mel_channels"],
-                                      d["sampling_rate"], d["mel_fmin"], d["mel_fmax"])
-        st.y_hat_mel = mel_spectrogram_torch(st.y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
-                                             d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
+        # the two mel spectrograms are inputs of the generator step's mel loss only: beside the discriminator step, on the
+        # prior encoder's lane (hip/disc.py; joined at the end of this phase -- a graph of its own)
+        lane = None
+        if self.device.type == "cuda" and backward and os.environ.get("EVT_MEL_LANE", "1") != "0":
+            from ..hip.disc import enc_lane
+
+            lane = enc_lane(self.device)
+        if lane is not None:
+            main = torch.cuda.current_stream(self.device)
+            lane.wait_stream(main)
+            with torch.cuda.stream(lane):
+                st.y_mel = spec_to_mel_slices(st.spec, st.ids_slice, seg // hop, d["filter_length"], d["n_mel_channels"],
+                                              d["sampling_rate"], d["mel_fmin"], d["mel_fmax"])
+                st.y_hat_mel = mel_spectrogram_torch(st.y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
+                                                     d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
+            for t in (st.spec, st.ids_slice, st.y_hat):
+                t.record_stream(lane)
+        else:
+            st.y_mel = spec_to_mel_slices(st.spec, st.ids_slice, seg // hop, d["filter_length"], d["n_mel_channels"],
+                                          d["sampling_rate"], d["mel_fmin"], d["mel_fmax"])
+            st.y_hat_mel = mel_spectrogram_torch(st.y_hat.squeeze(1), d["filter_length"], d["n_mel_channels"],
+                                                 d["sampling_rate"], hop, d["win_length"], d["mel_fmin"], d["mel_fmax"])
         st.y_seg = commons.slice_segments_1d(st.y.squeeze(1), st.ids_slice * hop, seg)
         # ---- discriminator step (sovits.py:497-507) ----
         rt_d.bank.weight_grads = True
@@ -184,6 +202,10 @@ class S2Engine:
             return
         self.scaler.scale(st.loss_disc).backward()
         rt_d.finish_grads()
+        if lane is not None:
+            main.wait_stream(lane)
+            st.y_mel.record_stream(main)
+            st.y_hat_mel.record_stream(main)
 
     def _phase_b(self, st, backward=True):
         t = self.hps["train"]
