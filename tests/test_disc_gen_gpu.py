@@ -113,7 +113,7 @@ def test_discriminator_step_on_branch_streams(gpu, streams):
             loss.backward()
             rt.finish_grads()
             torch.cuda.synchronize()
-            return [o.detach().clone() for o in outs], rt.arena.grad.detach().clone(), float(loss)
+            return [o.detach().clone() for o in outs], rt.arena.grad.detach().clone(), float(loss.detach())
         finally:
             HD.MPD_STREAMS = old
 
