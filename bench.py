@@ -61,6 +61,20 @@ def synth_s2_batch(B, T, t_text, device, seed):
     return wav, ssl, text, lengths, tl
 
 
+def _lanes_note(eng):
+    """which independent sub-models of the step run on branch streams (hip/disc.py switches)"""
+    from easevoice_trainer_amd.hip import disc as HD
+
+    on = []
+    if HD.MPD_STREAMS > 1:
+        on.append(f"sub-discriminators on {HD.MPD_STREAMS} streams")
+    if HD.ENC_STREAM and not eng.net_g.split_backward:
+        on.append("prior encoder + quantizer + mel spectrograms on a lane")
+    if HD.DEC_STREAM:
+        on.append("two of three wide-stage ResBlocks on a lane")
+    return "; ".join(on) if on else "one stream"
+
+
 def run_s2(args, world, rank, local):
     from easevoice_trainer_amd.module.mel_processing import spectrogram_torch
     from easevoice_trainer_amd.train.s2_engine import S2Engine
@@ -129,7 +143,8 @@ def run_s2(args, world, rank, local):
                    "global_batch": world * B, "parallelism": (reducer.describe(eng.exchange_ranges()) if reducer is not None else "dp1")
                                   + (", cut (data-parallel) program without collectives" if eng.cut_only else ""),
                    "launch": (f"hip-graph replay ({len(eng._program())} graphs/step"
-                              f"{', gradient reductions between them' if reducer is not None else ''})") if eng.graphs_enabled else "eager"},
+                              f"{', gradient reductions between them' if reducer is not None else ''})") if eng.graphs_enabled else "eager",
+                   "streams": _lanes_note(eng)},
         "generated_seconds_per_sec": world * B * 0.64 / (dt / args.steps),
         "losses_last_step": losses, "losses_finite": finite,
     }
