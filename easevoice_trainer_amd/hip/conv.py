@@ -220,7 +220,11 @@ class WeightBank:
         total_mem = torch.cuda.get_device_properties(self.device).total_memory if self.device.type == "cuda" else 0
         mem_scale = min(1.0, total_mem / float(256 << 30)) if total_mem else 1.0
         budget = int(os.environ.get("EVT_WGRAD_SLAB_MB", str(max(4, int(48 * mem_scale))))) << 20
-        cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "32"))
+        # slabs per image: more slabs = more split-K blocks for the weight-gradient launches, and as many more bytes for the
+        # fold at the end of the backward (wn_grad).  32 until the launches moved off the critical path (side stream, branch
+        # streams); since then the fold's bytes weigh more: 16-24 measured level and 0.2 ms ahead of 32, 8 and 4 behind
+        # (profiles/r06_streams.txt)
+        cap = int(os.environ.get("EVT_WGRAD_PARTS_CAP", "20"))
         # operands held for the deferred weight-gradient launches: flushed on a byte budget as well as on a count
         self.defer_bytes = int(os.environ.get("EVT_WGRAD_DEFER_MB", str(max(256, int(4096 * mem_scale))))) << 20
         self._deferred_bytes = 0
