@@ -137,6 +137,8 @@ class AttnBlockFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, ap.H, Lq), dtype=torch.float32, device=x.device)
         esz, qb, gb = qkv.element_size(), qkv.data_ptr(), dqkv.data_ptr()
+        if si.bank.side_on:
+            si.bank.flush_pending()      # the queued dW GEMMs of this layer (and in_proj's of the one above) beside the attention kernels
         L.check(L.lib().evt_attn_prefixlm_bwd(
             C.byref(ap), C.c_void_p(qb), C.c_void_p(qb + E * esz), C.c_void_p(qb + 2 * E * esz), L.ptr(o), L.ptr(d_o),
             L.ptr(lse), L.ptr(x_lens), L.ptr(y_lens), C.c_void_p(gb), C.c_void_p(gb + E * esz),

@@ -9,6 +9,7 @@ W and of W^T per layer, rebuilt by ONE multi-tensor launch whenever the optimise
 the per-call `weight.to(bf16)` casts of a torch-level implementation.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -93,6 +94,11 @@ class LinearBank:
         self.side = None
         self.side_on = False          # only between an engine's side_begin() and join_side(): a caller that differentiates
         self._side_used = False       # through the modules directly gets its weight gradients in stream order
+        # ... and WHEN on the side stream: queued, and handed over in one go right before a layer's attention backward
+        # (auto_reg/blocks.py) -- four dW GEMMs (MFMA-bound) beside the three attention kernels (VALU-bound, the matrix pipe
+        # ~85 % idle) share the CUs better than dW GEMMs beside backward-data GEMMs do.  EVT_S1_WGRAD_PAIR=0: hand over at once.
+        self.pair = os.environ.get("EVT_S1_WGRAD_PAIR", "1") != "0"
+        self._pending = []
 
     def enable_side_stream(self):
         if self.device.type == "cuda" and self.side is None:
@@ -102,8 +108,23 @@ class LinearBank:
         """from here to join_side() the weight-gradient launches go to the side stream"""
         self.side_on = self.side is not None
 
+    def flush_pending(self):
+        """hand the queued weight-gradient launches to the side stream (behind everything the current stream has enqueued)"""
+        if not self._pending:
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            for p, x, dy, dw_buf, db_buf in self._pending:
+                L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
+                                                         L.stream_ptr()), "evt_gemm_bf16_bwd_weight")
+        for _p, x, dy, _w, _b in self._pending:
+            x.record_stream(self.side)
+            dy.record_stream(self.side)
+        self._pending.clear()
+
     def join_side(self):
         """the caller's stream waits for the weight-gradient launches handed to the side stream since the last join"""
+        self.flush_pending()
         if self.side is not None and self._side_used:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self._side_used = False
@@ -235,6 +256,12 @@ def gemm_bwd_weight(slot, x, dy, want_bias=True):
     if sunk and bank.side_on and bank.side is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         # straight into the arena, on the side stream: ordered behind what the current stream has enqueued (x, dy exist),
         # the operands kept alive for the allocator until the launch has run; S1Engine joins before it reads the arena
+        if bank.pair:
+            bank._pending.append((p, x, dy, dw_buf, db_buf))
+            bank._side_used = True
+            if len(bank._pending) >= 8:          # no attention backward in sight (a stack of plain linears)
+                bank.flush_pending()
+            return None, None
         bank.side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(bank.side):
             L.check(L.lib().evt_gemm_bf16_bwd_weight(C.byref(p), L.ptr(x), L.ptr(dy), L.ptr(dw_buf), L.ptr(db_buf),
