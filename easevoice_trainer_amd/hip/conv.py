@@ -170,7 +170,10 @@ class WeightBank:
         # but their two operands.  grads() joins.  The operands are held until the join.  Measured on MI355X, s2 step
         # under HIP-graph replay, three interleaved rounds: 27.85-27.95 ms without, 27.14-27.18 ms with N = 64; small N
         # (a fork every few convolutions) is what made EVT_ASYNC_WGRAD slower under replay.
-        self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "64")) if self.device.type == "cuda" else 0
+        # Round 6, under the branch streams (profiles/r06_streams.txt): the generator's ~150 launches flushed every 48 instead
+        # of every 64 is 0.3 ms ahead (40-56 level except 52; 32 and 80-96 behind -- it matters which stretch of the backward a
+        # flush lands beside); the discriminators' 42 stay one flush at the end either way (in pieces: +0.2 ms).
+        self.defer_n = int(os.environ.get("EVT_WGRAD_DEFER", "48")) if self.device.type == "cuda" else 0
         self._deferred = []
         self._deferred_on = set()
         self._side = None
