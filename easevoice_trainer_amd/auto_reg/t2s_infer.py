@@ -252,7 +252,7 @@ class T2SInfer:
         if use_graph and S.graph_key != gkey:
             # warm-up launches outside the capture, on throw-away counters: restore the state afterwards
             keep = (S.ctr.clone(), S.y.clone(), S.stop.clone(), S.xa.clone())
-            side = torch.cuda.Stream(device=dev)
+            side = L.role_stream(dev, "decode_warm", ring=1)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 S.step_launches(W, sp, noise, pe)

@@ -163,9 +163,11 @@ class GradReducer:
             s += "; per range: " + "; ".join(parts)
         return s
 
-    def _side_stream(self, device):
+    def _side_stream(self, device):   # (a library-owned HIP stream, not one of torch's 32 pooled ones: hip/lib.py::role_stream)
         if self._stream is None and device.type == "cuda":
-            self._stream = torch.cuda.Stream(device=device)
+            from .hip import lib as L
+
+            self._stream = L.role_stream(device, "comm")
         return self._stream
 
     def buckets(self, n):

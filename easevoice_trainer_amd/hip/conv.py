@@ -411,7 +411,7 @@ class WeightBank:
 
     def side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = L.role_stream(self.device, "bank")
         return self._side
 
     def flush_deferred(self):

@@ -28,6 +28,11 @@ MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "2"))
 _side = {}
 
 
+def _new_stream(dev, k):
+    """lane k of the device: a library-owned HIP stream (hip/lib.py::role_stream says why not a pooled torch stream)"""
+    return L.role_stream(dev, f"lane{k}", ring=1)
+
+
 def _branches(dev, n_items):
     """stream of every sub-discriminator (None = the current stream) and the distinct side streams among them"""
     n = MPD_STREAMS if (dev.type == "cuda" and HC.TRACE is None) else 1
@@ -35,7 +40,7 @@ def _branches(dev, n_items):
         return [None] * n_items, []
     pool = _side.setdefault(dev, [])
     while len(pool) < n - 1:
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(_new_stream(dev, len(pool)))
     lanes = [None] + pool[: n - 1]
     per = [lanes[i % n] for i in range(n_items)]
     return per, pool[: n - 1]
@@ -51,7 +56,7 @@ def enc_lane(dev):
         return None
     pool = _side.setdefault(dev, [])
     if not pool:
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(_new_stream(dev, 0))
     return pool[0]
 
 
@@ -65,7 +70,7 @@ def dec_lane(dev):
         return None
     pool = _side.setdefault(dev, [])
     while len(pool) < 2:
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(_new_stream(dev, len(pool)))
     return pool[1]
 
 

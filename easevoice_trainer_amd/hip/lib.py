@@ -223,6 +223,49 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_hip_rt = None
+_role_pools = {}
+
+
+def own_stream(device):
+    """a HIP stream created for the library (hipStreamCreateWithFlags, non-blocking), wrapped for torch.  torch.cuda.Stream()
+    hands out one of 32 pooled streams per device round-robin: in a process that has asked for more than that (every engine
+    takes a few; a test run takes hundreds) two "different" side streams -- or a side stream and torch's graph-capture
+    stream -- are the same HIP stream, and a capture that forks onto such a pair has ended in a segmentation fault inside
+    hipStreamEndCapture (round 6: tests in the order streams, book-pipe, graph; profiles/r06_streams.txt).  Never destroyed:
+    callers take theirs through role_stream(), which bounds the number."""
+    global _hip_rt
+    device = torch.device(device)
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+        _hip_rt.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        _hip_rt.hipStreamCreateWithFlags.restype = C.c_int
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _hip_rt.hipStreamCreateWithFlags(C.byref(h), 1)          # hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise EvtError(f"hipStreamCreateWithFlags failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+def role_stream(device, role: str, ring: int = 4):
+    """the next of `ring` library-owned streams kept per (device, role) -- "bank" (weight-gradient side streams), "book",
+    "lane0", "lane1", "comm" ...: streams of different roles are never the same HIP stream, streams of one role repeat
+    after `ring` requests (two banks of one engine get two; the engine after the next one re-uses the first pair)"""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if os.environ.get("EVT_POOL_STREAMS", "0") == "1":               # A/B switch: torch's pooled streams, as before
+        return torch.cuda.Stream(device=device)
+    pool = _role_pools.setdefault((device.index, role), [[], 0])
+    if len(pool[0]) < ring:
+        pool[0].append(own_stream(device))
+        return pool[0][-1]
+    st = pool[0][pool[1] % ring]
+    pool[1] += 1
+    return st
+
+
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

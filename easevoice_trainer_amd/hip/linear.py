@@ -102,7 +102,7 @@ class LinearBank:
 
     def enable_side_stream(self):
         if self.device.type == "cuda" and self.side is None:
-            self.side = torch.cuda.Stream(device=self.device)
+            self.side = L.role_stream(self.device, "lin", ring=2)
 
     def side_begin(self):
         """from here to join_side() the weight-gradient launches go to the side stream"""

@@ -306,7 +306,7 @@ class ModelRuntime:
     #      backward next to them is MFMA / latency bound.  Same kernels, same per-element arithmetic as the serial order.
     def book_stream(self):
         if self._book is None:
-            self._book = torch.cuda.Stream(device=self.device)
+            self._book = L.role_stream(self.device, "book")
         return self._book
 
     def gather_free_grads(self):
