@@ -158,13 +158,14 @@ class S2Engine:
         rt_d.prepare()
         (st.y_hat, st.kl_ssl, st.ids_slice, st.x_mask, st.z_mask, st.lat, st.q) = net_g(
             st.ssl, st.spec, st.spec_lengths, st.text, st.text_lengths, eps=st.eps, ids_slice=st.ids_slice_in)
-        # the two mel spectrograms are inputs of the generator step's mel loss only: beside the discriminator step, on the
-        # prior encoder's lane (hip/disc.py; joined at the end of this phase -- a graph of its own)
+        # the two mel spectrograms are inputs of the generator step's mel loss only: beside the discriminator step, on a
+        # lane (hip/disc.py; joined at the end of this phase -- a graph of its own)
         lane = None
         if self.device.type == "cuda" and backward and os.environ.get("EVT_MEL_LANE", "1") != "0":
-            from ..hip.disc import enc_lane
+            from ..hip.disc import dec_lane, enc_lane
 
-            lane = enc_lane(self.device)
+            # (the second lane when there is one: the first carries half of the sub-discriminators during the D step)
+            lane = dec_lane(self.device) or enc_lane(self.device)
         if lane is not None:
             main = torch.cuda.current_stream(self.device)
             lane.wait_stream(main)
