@@ -24,7 +24,8 @@ from . import lib as L
 # backward of the generator step's node), so that one's under-filled launches (backward-data over the generated half:
 # 264 blocks on 512 slots; the 520-block period-7 layers) run beside another's.  Every tensor a branch allocates
 # is allocated and freed on the branch's own stream; what the joining stream reads afterwards is record_stream()ed.
-MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "2"))
+_ALL = os.environ.get("EVT_BRANCH_STREAMS", "1") != "0"       # master switch: "0" = the one-stream step, whatever the others say
+MPD_STREAMS = int(os.environ.get("EVT_MPD_STREAMS", "2")) if _ALL else 1
 _side = {}
 
 
@@ -46,7 +47,7 @@ def _branches(dev, n_items):
     return per, pool[: n - 1]
 
 
-ENC_STREAM = os.environ.get("EVT_ENC_STREAM", "1") != "0"
+ENC_STREAM = _ALL and os.environ.get("EVT_ENC_STREAM", "1") != "0"
 
 
 def enc_lane(dev):
@@ -60,7 +61,7 @@ def enc_lane(dev):
     return pool[0]
 
 
-DEC_STREAM = os.environ.get("EVT_DEC_STREAM", "1") != "0"
+DEC_STREAM = _ALL and os.environ.get("EVT_DEC_STREAM", "1") != "0"
 
 
 def dec_lane(dev):
