@@ -237,7 +237,18 @@ def own_stream(device):
     global _hip_rt
     device = torch.device(device)
     if _hip_rt is None:
-        _hip_rt = C.CDLL("libamdhip64.so")
+        # the HIP runtime this process already runs on (torch's): opened by the path it is mapped from, so that dlopen can
+        # only hand back that instance -- a second copy of the runtime would create streams the first does not know
+        path = "libamdhip64.so"
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64.so" in line:
+                        path = line.split(None, 5)[-1].strip()
+                        break
+        except OSError:
+            pass
+        _hip_rt = C.CDLL(path)
         _hip_rt.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
         _hip_rt.hipStreamCreateWithFlags.restype = C.c_int
     h = C.c_void_p()
